@@ -1,0 +1,236 @@
+/* echoscene_hip.h -- C ABI of libechoscene_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (ymxlzgy/echoscene) has no FFI: its hot path is Python calling ATen ops
+ * (SURVEY.md section 1).  This header is therefore the boundary the *build* defines
+ * (last row): the host-side mirror of model/SGDiff.py
+ * (echoscene_amd/model/*.py) calls these entry points through ctypes; each entry point
+ * cites the reference function(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory unless its name starts with h_; row-major, contiguous
+ *    unless an explicit leading dimension (ld, in elements) is given;
+ *  - I/O dtype is IEEE fp32; index arrays are int32; "f16" buffers are IEEE binary16;
+ *  - all work is enqueued on the caller's hipStream_t (pass torch's current stream);
+ *    nothing synchronises the device unless stated;
+ *  - return value 0 = ok; otherwise es_last_error() holds a thread-local message.
+ *    The Python wrapper turns a non-zero status into RuntimeError.
+ *  - inputs are borrowed for the duration of the enqueued work; outputs are caller-owned.
+ */
+#ifndef ECHOSCENE_HIP_H
+#define ECHOSCENE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* es_stream;          /* hipStream_t */
+typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
+
+#define ES_ABI_VERSION 1
+int es_abi_version(void);
+const char* es_last_error(void);
+/* device name / CU count of the current device (diagnostics for bench.py) */
+int es_device_info(char* name_out, int name_cap, int* cu_count);
+
+/* ------------------------------------------------------------------------------------------
+ * "rows" path -- fp32 node / triple matrices with M <= a few hundred rows.
+ * Replaces: nn.Linear + BatchNorm1d(eval) + ReLU chains of build_mlp (model/layers.py:21-38),
+ * GraphTripleConv's gather / scatter_add average pooling (model/graph.py:146-199), and -- for
+ * the 1-D box denoiser whose signal length is 1 -- GroupNorm/SiLU/Conv1d(centre tap),
+ * LayerNorm/attention-with-one-key/GEGLU (denoise_net.py:293-313, attention.py:172-245).
+ *
+ * One generic fused kernel:  out = act( prologue(A) @ W^T + bias ) + res
+ *   A is the horizontal concatenation of up to 3 segments, each either direct rows, rows
+ *   gathered through an index (obj_vecs[s_idx]), or a CSR segment-mean (the scatter_add/avg pool).
+ * ---------------------------------------------------------------------------------------- */
+enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2 };
+enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
+enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2 };
+
+typedef struct es_seg {
+    const float* ptr;      /* source matrix                                                     */
+    const int32_t* idx;    /* GATHER: row index [M];  CSRMEAN: row pointer [M+1]                */
+    const int32_t* ent_row;/* CSRMEAN: source row of each entry                                 */
+    const int32_t* ent_off;/* CSRMEAN: column offset of each entry inside the source row        */
+    const int32_t* step;   /* optional device scalar: ptr += (*step) * step_stride  (sampler loops) */
+    int32_t step_stride;
+    int32_t ld;            /* leading dimension of the source (0 = broadcast one row to all M)  */
+    int32_t width;         /* columns this segment contributes to K (multiple of 4)             */
+    int32_t mode;          /* ES_SEG_*                                                          */
+} es_seg;
+
+typedef struct es_linear_args {
+    es_seg seg[3];
+    int32_t nseg;
+    int32_t M, K, N;          /* K = sum of widths (GEGLU: the source holds 2K columns: value | gate) */
+    const float* wpack;       /* W[N,K] packed by es_pack_linear_f32 (MFMA 16x16x4 fragment order) */
+    const float* bias;        /* [N] or NULL                                                   */
+    int32_t prologue;         /* ES_PRO_*  (GN*: 32 groups over K; LN: over K)                 */
+    const float* gamma;       /* [K] affine of the norm prologue                               */
+    const float* beta;
+    float eps;
+    int32_t act;              /* ES_ACT_*                                                      */
+    const float* res;         /* residual [M, N] added AFTER the activation, or NULL           */
+    int32_t res_ld;
+    float* out;               /* [M, N]                                                        */
+    int32_t out_ld;
+} es_linear_args;
+
+/* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
+ * (h_w, h_out are HOST pointers).  Layout: [ceil(N/16)][ceil(K/16)][64 lanes][4], lane = q*16+j
+ * holds W[nt*16+j][kb*16+4q .. +3], zero padded. */
+size_t es_pack_linear_f32_size(int N, int K);
+int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
+
+int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diffusion updates.
+ * es_ddpm_update: GaussianDiffusion.p_mean_variance + p_sample_sg with eps-prediction,
+ *   'fixedsmall' variance, clip_denoised=False  (diffusion_ddpm.py:220-264, 296-309):
+ *     x0   = c[0]*x - c[1]*eps;  mean = c[2]*x0 + c[3]*x;  x <- mean + c[4]*noise
+ *   with c = coef[5*step ..] = {sqrt_recip_ac, sqrt_recipm1_ac, post_coef1, post_coef2,
+ *   (t!=0)*exp(0.5*post_logvar)} prepared on the host in fp32 exactly as the reference's tables.
+ * es_ddim_update: DDIMSampler.p_sample_ddim, eta = 0  (samplers/ddim.py:236-262):
+ *     pred_x0 = (x - c[0]*e)/c[1];  x <- c[2]*pred_x0 + c[3]*e
+ *   with c = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)}.
+ * `step` is a device scalar; when inc_step != 0 the kernel increments it after use.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct es_update_args {
+    float* x;               /* [n] state, updated in place                                      */
+    const float* eps;       /* [n] network output                                               */
+    const float* noise;     /* DDPM: noise + (*step)*noise_stride is this step's draw; DDIM: NULL */
+    int32_t noise_stride;
+    const float* coef;      /* [n_steps][coef_stride]                                           */
+    int32_t coef_stride;
+    int32_t* step;
+    int32_t n;
+    int32_t inc_step;
+} es_update_args;
+int es_ddpm_update(const es_update_args* args, es_stream stream);
+int es_ddim_update(const es_update_args* args, es_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * "volume" path -- the 3-D latent-SDF UNet (openai_model_3d.py:816-863).  Activations are
+ * channels-last [O, D, H, W, C]; the residual stream is fp32, every contraction reads fp16
+ * operands and accumulates in fp32 on MFMA (v_mfma_f32_16x16x32_f16).
+ * ---------------------------------------------------------------------------------------- */
+enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2 };
+
+typedef struct es_conv_args {
+    const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
+    const void* w;            /* f16 packed [Npad][taps][Cin]  (K contiguous per output channel) */
+    int32_t O, D, H, W;       /* OUTPUT spatial size                                             */
+    int32_t Cin, N;           /* N = true number of output channels                              */
+    int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
+    int32_t mode;             /* ES_CONV_*: SAME; DOWN_HW = stride (1,2,2) (Downsample, :188);
+                                 UP_HW = nearest x2 on H,W folded into addressing (Upsample, :150-153) */
+    /* optional second contraction accumulated into the same tile: the 1x1 skip_connection of a
+       ResBlock whose channel count changes (out = conv2(h) + skip(x), :294-314) */
+    const void* a2; const void* w2; int32_t Cin2;
+    const float* bias;        /* [N] (sum of both biases when a2 is used) or NULL                */
+    const float* rowvec;      /* [O, N] per-object vector broadcast over voxels (emb_layers output /
+                                 cross-attention-with-one-key output), or NULL                   */
+    const float* res;         /* fp32 residual [M, N] or NULL                                    */
+    float* out_f32;           /* [M, N] or NULL                                                  */
+    void* out_f16;            /* [M, N] or NULL                                                  */
+    int32_t out_ld;           /* leading dimension of both outputs (>= N)                        */
+} es_conv_args;
+int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
+/* host helper: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16
+ * [Npad][taps][Cin] image (Npad = N rounded up to 16). h_out holds uint16 bit patterns. */
+size_t es_pack_conv_f16_size(int N, int Cin, int taps);
+int es_pack_conv_f16(const float* h_w, int N, int Cin, int taps, uint16_t* h_out);
+
+typedef struct es_gn_args {
+    const float* x1; int32_t C1;     /* fp32 channels-last source 1 [O, V, C1]                  */
+    const float* x2; int32_t C2;     /* optional source 2 (skip concat, th.cat([h, hs.pop()]))  */
+    int32_t O, V;                    /* objects, voxels per object                              */
+    int32_t groups; float eps;
+    const float* gamma; const float* beta;   /* [C1+C2]                                         */
+    int32_t silu;
+    float* stats;                    /* scratch [O, groups, 2]                                  */
+    void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
+    void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
+} es_gn_args;
+/* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
+ * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats, apply. */
+int es_groupnorm_vol(const es_gn_args* args, es_stream stream);
+
+typedef struct es_ln_args {
+    const float* x; int32_t M, C; float eps; const float* gamma; const float* beta; void* y_f16;
+} es_ln_args;
+int es_layernorm_tokens(const es_ln_args* args, es_stream stream);      /* nn.LayerNorm, attention.py:229-231 */
+
+typedef struct es_attn_args {
+    const void* qkv;      /* f16 [B*Ntok, 3*C]: q | k | v, heads packed as (h d)                */
+    int32_t B, Ntok, heads, dhead;
+    float scale;          /* dhead^-0.5 (attention.py:158)                                      */
+    void* out_f16;        /* [B*Ntok, C]                                                        */
+} es_attn_args;
+int es_attention_f16(const es_attn_args* args, es_stream stream);       /* CrossAttention.forward self-attn, attention.py:172-219 */
+
+typedef struct es_geglu_args { const void* h_f16; int32_t M, C4; void* out_f16; } es_geglu_args;
+int es_geglu_f16(const es_geglu_args* args, es_stream stream);          /* GEGLU: x * gelu(gate), attention.py:39-46 */
+
+/* NCDHW fp32 latent <-> channels-last helpers, the 3->32->64 conv-pool stem of
+ * shape_messsage_passing (openai_model_3d.py:757-764) and the final 224->3 conv. */
+int es_latent_to_cl_f16(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f16, es_stream s);
+typedef struct es_stem_args {
+    const float* x;        /* [O,3,16,16,16] fp32 NCDHW                                          */
+    const float* w0; const float* b0;   /* Conv3d(3,32,3)  weights [32,3,3,3,3]                   */
+    const float* w1; const float* b1;   /* Conv3d(32,64,3) weights [64,32,3,3,3]                  */
+    float* scratch;        /* [O,32,8,8,8] pooled stage-1 output                                 */
+    float* out;            /* [O,512] = flatten(MaxPool3d(k2,s4)(conv2)) in NCDHW order          */
+    int32_t O;
+} es_stem_args;
+int es_shape_stem(const es_stem_args* args, es_stream stream);
+typedef struct es_convout_args {
+    const void* a_f16;     /* [O,D,H,W,Cin] f16 (already GN+SiLU)                                */
+    const float* w;        /* [Cout, 27, Cin] fp32                                               */
+    const float* bias; int32_t O, D, H, W, Cin, Cout;
+    float* out_ncdhw;      /* [O,Cout,D,H,W] fp32                                                */
+} es_convout_args;
+int es_conv_out_small(const es_convout_args* args, es_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plans: an ordered op list enqueued by the native runtime (no Python between kernels), and
+ * optionally captured once into a hipGraph and replayed per denoising step.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    ES_OP_LINEAR = 1, ES_OP_DDPM = 2, ES_OP_DDIM = 3, ES_OP_COPY = 4, ES_OP_CONV = 5, ES_OP_GN = 6,
+    ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_CONVOUT = 12,
+    ES_OP_FORK = 13, ES_OP_JOIN = 14
+};
+typedef struct es_copy_args { void* dst; const void* src; size_t bytes; } es_copy_args;
+typedef struct es_tocl_args { const float* x; int32_t O, C, V, Cpad; void* out; } es_tocl_args;
+typedef struct es_op {
+    int32_t kind;
+    int32_t lane;    /* execution lane (0 = main stream; >0 = side stream forked/joined with ES_OP_FORK/JOIN) */
+    union {
+        es_linear_args linear; es_update_args update; es_copy_args copy; es_conv_args conv;
+        es_gn_args gn; es_ln_args ln; es_attn_args attn; es_geglu_args geglu; es_tocl_args tocl;
+        es_stem_args stem; es_convout_args convout;
+    } u;
+} es_op;
+
+es_plan* es_plan_create(const es_op* ops, int n_ops);
+void es_plan_destroy(es_plan* plan);
+int es_plan_num_ops(const es_plan* plan);
+/* enqueue every op once, in order, on `stream` (side lanes use internal streams + events) */
+int es_plan_run(es_plan* plan, es_stream stream);
+/* capture es_plan_run into a hipGraph (idempotent) */
+int es_plan_capture(es_plan* plan, es_stream stream);
+/* The sampling loops.  `step` is the device scalar the plan's ops read; it is set to first_step,
+ * then the (captured) plan is launched n_steps times -- the plan's last update op increments it.
+ *   layout: GaussianDiffusion.p_sample_loop_sg  (diffusion_ddpm.py:330-345), 1000 iterations
+ *   shape : DDIMSampler.ddim_sampling           (samplers/ddim.py:127-181),   100 iterations   */
+int es_sampler_run(es_plan* plan, int32_t* step, int first_step, int n_steps, int use_graph, es_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHOSCENE_HIP_H */

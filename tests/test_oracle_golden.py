@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/echoscene_oracle.py) to golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  Weights are regenerated on this side from
+the seeded rule, through this build's own parameter-holder trees -- so these tests also pin
+the holders' state_dict key names and shapes to the reference's (any mismatch would change
+the seeded values and fail numerically).
+
+Tolerances: same arithmetic (ATen fp32 on CPU) on both sides, only op grouping differs
+-> 2e-5 abs on O(1) values; the tables must be bit-identical.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, seeded_state_dict
+from echoscene_amd import synth, config as escfg
+from echoscene_amd.model.graph import GraphTripleConvNet
+from echoscene_amd.model.unet import UNet1DModel, DiffusionUNet
+from oracle import echoscene_oracle as orc
+
+
+def _close(a, b, atol, rtol=1e-5):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), 'max abs err %.3e (ref scale %.3e)' % (
+        err, b.abs().max().item())
+
+
+@pytest.mark.parametrize('tag', ['res_bn', 'plain'])
+def test_gcn(tag):
+    g = load_golden('gcn_' + tag)
+    din, dp, nl, H, res, bn, dout = [int(v) for v in g['cfg']]
+    net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res),
+                             mlp_normalization='batch' if bn else 'none', output_dim=dout)
+    sd = seeded_state_dict(net, 'gcn_%s.' % tag)
+    tri = g['triples']
+    edges = torch.stack([tri[:, 0], tri[:, 2]], 1)
+    o, p = orc.gcn_net({'n.' + k: v for k, v in sd.items()}, 'n', g['obj'], g['pred'], edges)
+    _close(o, g['out_obj'], 1e-5)
+    _close(p, g['out_pred'], 1e-5)
+
+
+def _unet1d_sd(mc, ctx, prefix):
+    kw = dict(escfg.layout_denoiser_kwargs(mc))
+    kw['concat_dim'] = kw['crossattn_dim'] = ctx
+    return seeded_state_dict(UNet1DModel(**kw), prefix)
+
+
+def test_unet1d_tiny():
+    g = load_golden('unet1d_tiny')
+    sd = _unet1d_sd(64, 128, 'unet1d_tiny.')
+    eps = orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'])
+    _close(eps, g['eps'], 2e-5)
+
+
+def test_ddpm_tables_bit_exact():
+    g = load_golden('ddpm_tables_1000')
+    tab = orc.ddpm_tables(1e-4, 0.02, 1000)
+    for k, v in tab.items():
+        assert torch.equal(v, g[k]), k
+    g100 = load_golden('layout_loop_tiny')
+    tab = orc.ddpm_tables(1e-4, 0.02, 100)
+    for k, v in tab.items():
+        assert torch.equal(v, g100['tab100_' + k]), k
+
+
+def test_layout_loop_tiny_100_steps():
+    """BASELINE.json configs[0]: 8-node graph, 100 DDPM steps, injected noise."""
+    g = load_golden('layout_loop_tiny')
+    sd = _unet1d_sd(64, 128, 'unet1d_tiny.')
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    x = orc.layout_sample_loop(sd, g['obj_embed'], g['triples'], noise, time_num=100)
+    _close(x, g['x_final'], 1e-4)
+
+
+@pytest.mark.slow
+def test_unet1d_full():
+    g = load_golden('unet1d_full')
+    sd = _unet1d_sd(512, 1280, 'unet1d_full.')
+    for O in (8, 32):
+        t = torch.full((O,), 617, dtype=torch.int64)
+        eps = orc.unet1d_forward(sd, g['box%d' % O], g['obj_embed%d' % O], g['triples%d' % O], t)
+        _close(eps, g['eps%d' % O], 5e-5)
+    noise = synth.layout_noise(8, 8, 1000, seed=7)[:11]
+    tr = []
+    x = orc.layout_sample_loop(sd, g['loop_obj_embed'], g['loop_triples'], noise, time_num=1000,
+                               n_steps=10, trace=tr)
+    _close(tr[0], g['loop_x1'], 5e-5)
+    _close(x, g['loop_x10'], 1e-4)
+
+
+def _unet3d_sd(mc, ctx, prefix):
+    p = escfg.shape_unet_params(mc)
+    p['context_dim'] = ctx
+    sd = seeded_state_dict(DiffusionUNet(p), prefix)
+    return {k[len('diffusion_net.'):]: v for k, v in sd.items()}
+
+
+def test_unet3d_tiny():
+    g = load_golden('unet3d_tiny')
+    sd = _unet3d_sd(32, 64, 'unet3d_tiny.')
+    eps = orc.unet3d_forward(sd, g['x'], g['uc_s'], g['triples'], g['t'])
+    _close(eps, g['eps'], 5e-5)
+
+
+def test_ddim_schedule_and_loop_tiny():
+    g = load_golden('ddim_tiny')
+    ac = orc.shape_alphas_cumprod()
+    assert torch.equal(ac, g['alphas_cumprod'])
+    ts, a, ap, s1m = orc.ddim_schedule(ac, 4)
+    assert (ts == g['ddim_timesteps'].numpy()).all()
+    assert torch.equal(a, g['ddim_alphas'])
+    assert torch.equal(ap, g['ddim_alphas_prev'].float())
+    assert torch.equal(s1m, g['ddim_sqrt_one_minus_alphas'])
+    g100 = load_golden('ddim_schedule_100')
+    ts, a, ap, s1m = orc.ddim_schedule(ac, 100)
+    assert (ts == g100['ddim_timesteps'].numpy()).all() and ts[0] == 1 and ts[-1] == 991
+    assert torch.equal(a, g100['ddim_alphas']) and torch.equal(ap, g100['ddim_alphas_prev'].float())
+    sd = _unet3d_sd(32, 64, 'unet3d_tiny.')
+    z = orc.shape_sample_loop(sd, g['uc_s'], g['triples'], synth.shape_noise(seed=7), S=4)
+    _close(z, g['z_final'], 2e-4)
+
+
+@pytest.mark.slow
+def test_unet3d_full():
+    g = load_golden('unet3d_full')
+    sd = _unet3d_sd(224, 1280, 'unet3d_full.')
+    eps = orc.unet3d_forward(sd, g['x'], g['uc_s'], g['triples'], g['t'])
+    _close(eps, g['eps'], 2e-4)
+
+
+@pytest.mark.parametrize('tag', ['tiny', pytest.param('full', marks=pytest.mark.slow)])
+def test_vqvae_decode(tag):
+    from echoscene_amd.model.vqvae import VQVAE
+    g = load_golden('vqvae_' + tag)
+    ch, ne = [int(v) for v in g['cfg']]
+    c = escfg.vqvae_conf(ch).model.params
+    sd = seeded_state_dict(VQVAE(dict(c.ddconfig), ne, c.embed_dim), 'vqvae_%s.' % tag)
+    _, idx = orc.vq_quantize(sd, g['z'])
+    assert torch.equal(idx, g['idx'])
+    sdf = orc.vqvae_decode_no_quant(sd, g['z'])
+    assert tuple(sdf.shape[2:]) == (64, 64, 64)
+    _close(sdf[:, :, ::4, ::4, ::4], g['sdf_sub'], 1e-4)
+    assert abs(sdf.double().abs().sum().item() - g['sdf_abs'].item()) < 1e-4 * g['sdf_abs'].item()
