@@ -1,0 +1,323 @@
+// "rows" path: fp32 fused linear over small-M node/triple matrices + the diffusion updates.
+//
+// Roofline note: one layout denoising step streams ~524 MB of fp32 weights
+// for ~8.9 GFLOP (17 flop/B) -- HBM-bound, and in practice launch/latency-bound because it is a
+// chain of ~140 dependent [32 x K] @ [K x N] products.  Design consequences:
+//   * weights are pre-packed in MFMA-fragment order so that every wave-level load is one
+//     contiguous 1 KiB global_load_dwordx4 that lands directly in B-operand registers
+//     (no LDS round trip for the streamed operand -- it is used once per workgroup);
+//   * the small activation tile (<= 32 rows x 1024 cols) is staged ONCE per workgroup in LDS,
+//     where the norm/activation prologue (GroupNorm+SiLU / LayerNorm / GEGLU / gather /
+//     CSR mean pooling) is applied, so no separate elementwise kernels (= no extra launches);
+//   * exact fp32 on the matrix pipe: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain);
+//   * K is split over the 8 waves of a workgroup and reduced through LDS in a fixed order
+//     (deterministic, no float atomics).
+#include "es_common.h"
+
+namespace {
+
+constexpr int MT = 32;          // rows per workgroup (two 16-row MFMA tiles)
+constexpr int KC = 1024;        // K chunk staged in LDS
+constexpr int LDX = KC + 8;     // +8 floats: conflict-free ds_read_b128 of A fragments
+constexpr int NWAVE = 8;
+constexpr int NTHREAD = NWAVE * 64;
+constexpr int MAXJ = KC / 16 / NWAVE;   // 16-wide k-blocks per wave per chunk
+
+struct Smem {
+    float x[MT][LDX];
+};
+
+__device__ __forceinline__ const float* seg_base(const es_seg& s) {
+    const float* p = s.ptr;
+    if (s.step) p += (long)(*s.step) * s.step_stride;
+    return p;
+}
+
+// raw load of 4 consecutive virtual columns [k, k+4) of row m of the concatenated A operand
+// (v = value, g = GEGLU gate).  Kept free of arithmetic so that the staging loop can keep several
+// of these loads in flight before the first use.
+__device__ __forceinline__ void load_a4_raw(const es_linear_args& a, int m, int k, f4& v, f4& g) {
+    v = f4{0.f, 0.f, 0.f, 0.f};
+    g = v;
+    if (m >= a.M || k >= a.K) return;
+    int c = k;
+    int si = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (si == s && s + 1 < a.nseg && c >= a.seg[s].width) { c -= a.seg[s].width; si = s + 1; }
+    }
+    const es_seg& sg = a.seg[si];
+    const float* base = seg_base(sg);
+    if (sg.mode == ES_SEG_DIRECT) {
+        const float* p = base + (long)m * sg.ld + c;
+        v = *(const f4*)p;
+        if (a.prologue == ES_PRO_GEGLU) g = *(const f4*)(p + a.K);
+    } else if (sg.mode == ES_SEG_GATHER) {
+        v = *(const f4*)(base + (long)sg.idx[m] * sg.ld + c);
+    } else {  // CSR mean: sum entries in stored order (== scatter_add order of the reference), / max(cnt,1)
+        const int e0 = sg.idx[m], e1 = sg.idx[m + 1];
+        for (int e = e0; e < e1; ++e) {
+            f4 t = *(const f4*)(base + (long)sg.ent_row[e] * sg.ld + sg.ent_off[e] + c);
+            v += t;
+        }
+        const float cnt = (float)max(e1 - e0, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / cnt;
+    }
+}
+
+__device__ __forceinline__ f4 post_a4(const es_linear_args& a, f4 v, f4 g) {
+    if (a.prologue == ES_PRO_GEGLU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * es_gelu(g[e]);
+    } else if (a.prologue == ES_PRO_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = es_silu(v[e]);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a) {
+    __shared__ Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x;
+    const int m0 = blockIdx.y * MT;
+    const int Kp = (a.K + 15) & ~15;
+    const int nkb_total = Kp >> 4;
+    const f4* wp = (const f4*)a.wpack + (size_t)nt * nkb_total * 64;
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+
+    for (int kc0 = 0; kc0 < Kp; kc0 += KC) {
+        const int kc = min(KC, Kp - kc0);
+        const int nkb = kc >> 4;
+        // (1) issue this wave's weight-fragment loads first: HBM latency overlaps the staging below
+        f4 bf[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int kb = wave + j * NWAVE;
+            if (kb < nkb) bf[j] = __builtin_nontemporal_load(&wp[(size_t)((kc0 >> 4) + kb) * 64 + lane]);
+        }
+        // (2) stage the activation chunk (prologue elementwise part applied on the fly)
+        if (kc0 > 0) __syncthreads();
+        const int c4n = kc >> 2, total = MT * c4n;
+        for (int base0 = 0; base0 < total; base0 += NTHREAD * 8) {
+            f4 v[8], gt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                 // 8 independent loads in flight per thread
+                const int idx = base0 + u * NTHREAD + tid;
+                if (idx < total) {
+                    const int r = idx / c4n, c4 = idx - r * c4n;
+                    load_a4_raw(a, m0 + r, kc0 + 4 * c4, v[u], gt[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base0 + u * NTHREAD + tid;
+                if (idx < total) {
+                    const int r = idx / c4n, c4 = idx - r * c4n;
+                    *(f4*)&sm.x[r][4 * c4] = post_a4(a, v[u], gt[u]);
+                }
+            }
+        }
+        __syncthreads();
+        // (3) norm prologues (host guarantees K <= KC for these)
+        if (a.prologue == ES_PRO_GN || a.prologue == ES_PRO_GN_SILU || a.prologue == ES_PRO_LN) {
+            const int r = tid >> 4, sub = tid & 15;     // 16 lanes per row
+            const int K = a.K;
+            if (a.prologue == ES_PRO_LN) {
+                float s = 0.f;
+                for (int k = sub; k < K; k += 16) s += sm.x[r][k];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+                const float mean = s / (float)K;
+                float v = 0.f;
+                for (int k = sub; k < K; k += 16) { const float d = sm.x[r][k] - mean; v += d * d; }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+                const float rstd = 1.0f / sqrtf(v / (float)K + a.eps);
+                for (int k = sub; k < K; k += 16)
+                    sm.x[r][k] = (sm.x[r][k] - mean) * rstd * a.gamma[k] + a.beta[k];
+            } else {
+                const int gs = K >> 5;                  // 32 groups of gs (= 16 or 32) channels
+                const int gs4 = gs >> 2;
+                if (gs & 3) {                           // narrow test configs (gs = 1, 2): scalar path
+                    for (int h = 0; h < 2; ++h) {
+                        const int g = sub + 16 * h;
+                        float s = 0.f;
+                        for (int k = 0; k < gs; ++k) s += sm.x[r][g * gs + k];
+                        const float mean = s / (float)gs;
+                        float var = 0.f;
+                        for (int k = 0; k < gs; ++k) { const float d = sm.x[r][g * gs + k] - mean; var += d * d; }
+                        const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
+                        for (int k = 0; k < gs; ++k) {
+                            const int kk = g * gs + k;
+                            float y = (sm.x[r][kk] - mean) * rstd * a.gamma[kk] + a.beta[kk];
+                            if (a.prologue == ES_PRO_GN_SILU) y = es_silu(y);
+                            sm.x[r][kk] = y;
+                        }
+                    }
+                } else
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int g = sub + 16 * h;
+                    f4 v[8];
+                    float s = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < gs4) { v[u] = *(const f4*)&sm.x[r][g * gs + 4 * u]; s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]); }
+                    const float mean = s / (float)gs;
+                    float var = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < gs4) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var += d * d; }
+                        }
+                    const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < gs4) {
+                            const int kk = g * gs + 4 * u;
+                            const f4 ga = *(const f4*)&a.gamma[kk], be = *(const f4*)&a.beta[kk];
+                            f4 y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                y[e] = (v[u][e] - mean) * rstd * ga[e] + be[e];
+                                if (a.prologue == ES_PRO_GN_SILU) y[e] = es_silu(y[e]);
+                            }
+                            *(f4*)&sm.x[r][kk] = y;
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        // (4) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block, 2 row tiles
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int kb = wave + j * NWAVE;
+            if (kb < nkb) {
+                const f4 a0 = *(const f4*)&sm.x[i16][kb * 16 + 4 * q];
+                const f4 a1 = *(const f4*)&sm.x[16 + i16][kb * 16 + 4 * q];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bf[j][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bf[j][s], acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // (5) fixed-order cross-wave reduction through LDS, then the epilogue: one output per thread
+    __syncthreads();
+    float* red = &sm.x[0][0];                            // [NWAVE][2][256]
+    *(f4*)&red[(wave * 2 + 0) * 256 + lane * 4] = acc0;
+    *(f4*)&red[(wave * 2 + 1) * 256 + lane * 4] = acc1;
+    __syncthreads();
+    const int ml = tid >> 4, nl = tid & 15;              // 32 x 16 outputs
+    const int mt = ml >> 4, row = ml & 15;
+    // D layout of mfma 16x16: lane = (row>>2)*16 + col holds D[row][col] in register row&3
+    const int off = mt * 256 + ((row >> 2) * 16 + nl) * 4 + (row & 3);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) s += red[w * 512 + off];
+    const int m = m0 + ml, n = nt * 16 + nl;
+    if (m < a.M && n < a.N) {
+        if (a.bias) s += a.bias[n];
+        if (a.act == ES_ACT_RELU) s = fmaxf(s, 0.f);
+        else if (a.act == ES_ACT_SILU) s = es_silu(s);
+        if (a.res) s += a.res[(long)m * a.res_ld + n];
+        if (a.res2) s += a.res2[(long)m * a.res2_ld + n];
+        a.out[(long)m * a.out_ld + n] = s;
+    }
+}
+
+__global__ void k_ddpm_update(const es_update_args a) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int st = *a.step;
+    if (i < a.n) {
+        const float* c = a.coef + (long)st * a.coef_stride;
+        const float x = a.x[i], e = a.eps[i];
+        const float nz = a.noise[(long)st * a.noise_stride + i];
+        const float x0 = c[0] * x - c[1] * e;
+        const float mean = c[2] * x0 + c[3] * x;
+        a.x[i] = mean + c[4] * nz;
+    }
+}
+
+__global__ void k_ddim_update(const es_update_args a) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int st = *a.step;
+    if (i < a.n) {
+        const float* c = a.coef + (long)st * a.coef_stride;
+        const float x = a.x[i], e = a.eps[i];
+        const float px0 = (x - c[0] * e) / c[1];
+        a.x[i] = c[2] * px0 + c[3] * e;
+    }
+}
+
+__global__ void k_step_inc(int32_t* step) { *step += 1; }
+
+}  // namespace
+
+extern "C" size_t es_pack_linear_f32_size(int N, int K) {
+    return (size_t)((N + 15) / 16) * ((K + 15) / 16) * 256;
+}
+
+extern "C" int es_pack_linear_f32(const float* w, int N, int K, float* out) {
+    const int NT = (N + 15) / 16, KB = (K + 15) / 16;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, q = lane >> 4;
+                const int n = nt * 16 + j;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kb * 16 + 4 * q + e;
+                    out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + e] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+                }
+            }
+    return 0;
+}
+
+extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
+    ES_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "es_linear_rows_f32: nseg=%d", a->nseg);
+    int ksum = 0;
+    for (int s = 0; s < a->nseg; ++s) {
+        ES_REQUIRE(a->seg[s].width % 4 == 0 && a->seg[s].ld % 4 == 0,
+                   "es_linear_rows_f32: segment %d width/ld must be multiples of 4 (width=%d ld=%d)", s,
+                   a->seg[s].width, a->seg[s].ld);
+        ksum += a->seg[s].width;
+    }
+    ES_REQUIRE(ksum == a->K, "es_linear_rows_f32: segment widths sum to %d, K=%d", ksum, a->K);
+    ES_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "es_linear_rows_f32: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+    const bool norm = a->prologue == ES_PRO_GN || a->prologue == ES_PRO_GN_SILU || a->prologue == ES_PRO_LN;
+    if (norm) {
+        ES_REQUIRE(a->K <= KC, "es_linear_rows_f32: norm prologue needs K <= %d (K=%d)", KC, a->K);
+        ES_REQUIRE(a->gamma && a->beta, "es_linear_rows_f32: norm prologue without affine");
+        if (a->prologue != ES_PRO_LN)
+            ES_REQUIRE(a->K % 32 == 0, "es_linear_rows_f32: GroupNorm32 prologue needs K %% 32 == 0 (K=%d)", a->K);
+    }
+    if (a->prologue == ES_PRO_GEGLU)
+        ES_REQUIRE(a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
+    dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT);
+    hipLaunchKernelGGL(k_linear_rows, grid, dim3(NTHREAD), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_ddpm_update(const es_update_args* a, es_stream stream) {
+    ES_REQUIRE(a->n > 0 && a->step && a->noise, "es_ddpm_update: bad args");
+    hipLaunchKernelGGL(k_ddpm_update, dim3((a->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->inc_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, a->step);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_ddim_update(const es_update_args* a, es_stream stream) {
+    ES_REQUIRE(a->n > 0 && a->step, "es_ddim_update: bad args");
+    hipLaunchKernelGGL(k_ddim_update, dim3((a->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->inc_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, a->step);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}

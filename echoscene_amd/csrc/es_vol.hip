@@ -1,0 +1,614 @@
+// "volume" path: the 3-D latent-SDF UNet (reference openai_model_3d.py:816-863).
+//
+// Roofline: 557.8 GFLOP per object per DDIM step, 87 % of it 3x3x3 Conv3d
+// -> MFMA-bound.  Layout: channels-last [O][D][H][W][C] so that an implicit-GEMM conv reads
+// K-contiguous rows: out[m][n] = sum_{tap} sum_c A[shift(m,tap)][c] * W[n][tap][c].
+//   * residual stream fp32; every contraction takes fp16 operands and accumulates fp32 on
+//     v_mfma_f32_16x16x32_f16;
+//   * A/B tiles go HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip); zero padding
+//     of the 3x3x3 halo is done by pointing out-of-volume rows at a zero page;
+//   * LDS tiles are [rows][32 halfs] with a 16-B-chunk XOR swizzle applied on the (per-lane)
+//     SOURCE address and on the fragment read (glds destinations are lane-linear);
+//   * GroupNorm/SiLU, LayerNorm and GEGLU are bandwidth-trivial side kernels that emit the fp16
+//     operand of the next contraction; bias / time-embedding / residual adds are fused into the
+//     contraction epilogue.
+#include "es_common.h"
+
+namespace {
+
+__device__ __forceinline__ int f_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm over channels-last volumes.  Pass 1: per (object, 64-voxel tile) partial sums.
+// ---------------------------------------------------------------------------------------------
+constexpr int GN_VT = 64;
+
+__global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* part) {
+    // part: [O][ntiles][groups][2]
+    __shared__ float ssum[2048], ssq[2048];
+    const int o = blockIdx.y, tile = blockIdx.x, C = a.C1 + a.C2;
+    const int v0 = tile * GN_VT;
+    const int nv = min(GN_VT, a.V - v0);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* src; int ld, cc;
+        if (c < a.C1) { src = a.x1; ld = a.C1; cc = c; } else { src = a.x2; ld = a.C2; cc = c - a.C1; }
+        const float* p = src + ((long)o * a.V + v0) * ld + cc;
+        float s = 0.f, q = 0.f;
+        for (int v = 0; v < nv; ++v) { const float x = p[(long)v * ld]; s += x; q += x * x; }
+        ssum[c] = s; ssq[c] = q;
+    }
+    __syncthreads();
+    const int gs = C / a.groups;
+    if (threadIdx.x < a.groups) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < gs; ++k) { s += ssum[threadIdx.x * gs + k]; q += ssq[threadIdx.x * gs + k]; }
+        float* dst = part + (((long)o * gridDim.x + tile) * a.groups + threadIdx.x) * 2;
+        dst[0] = s; dst[1] = q;
+    }
+}
+
+// Pass 2: finalize statistics (fixed order, double) and apply; 8 channels per thread -> 16-B f16 stores.
+__global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const float* part, int ntiles, int vox_per_block) {
+    __shared__ float smean[64], srstd[64];
+    const int o = blockIdx.y, C = a.C1 + a.C2, gs = C / a.groups;
+    if (threadIdx.x < a.groups) {
+        double s = 0.0, q = 0.0;
+        for (int t = 0; t < ntiles; ++t) {
+            const float* p = part + (((long)o * ntiles + t) * a.groups + threadIdx.x) * 2;
+            s += p[0]; q += p[1];
+        }
+        const double n = (double)gs * a.V;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        smean[threadIdx.x] = (float)mean;
+        srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    const int c8n = C >> 3;
+    const int v0 = blockIdx.x * vox_per_block;
+    const int total = vox_per_block * c8n;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int vl = idx / c8n, c8 = idx - vl * c8n;
+        const int v = v0 + vl;
+        if (v >= a.V) break;
+        const int c = c8 * 8;
+        const float* src; int ld, cc;
+        if (c < a.C1) { src = a.x1; ld = a.C1; cc = c; } else { src = a.x2; ld = a.C2; cc = c - a.C1; }
+        const float* p = src + ((long)o * a.V + v) * ld + cc;
+        const f4 x0 = *(const f4*)p, x1 = *(const f4*)(p + 4);
+        float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        h8 y, r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / gs;
+            float t = (x[e] - smean[g]) * srstd[g] * a.gamma[c + e] + a.beta[c + e];
+            if (a.silu) t = es_silu_fast(t);
+            y[e] = (_Float16)t;
+            r[e] = (_Float16)x[e];
+        }
+        const long off = ((long)o * a.V + v) * C + c;
+        *(h8*)((_Float16*)a.y_f16 + off) = y;
+        if (a.raw_f16) *(h8*)((_Float16*)a.raw_f16 + off) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over tokens: one wave per row, fp32 in, fp16 out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layernorm(const es_ln_args a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.M) return;
+    const float* p = a.x + (long)row * a.C;
+    float v[16];                                   // C <= 1024
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int c = lane + 64 * j; v[j] = c < a.C ? p[c] : 0.f; s += v[j]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)a.C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int c = lane + 64 * j; const float d = c < a.C ? v[j] - mean : 0.f; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+    _Float16* y = (_Float16*)a.y_f16 + (long)row * a.C;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = lane + 64 * j;
+        if (c < a.C) y[c] = (_Float16)((v[j] - mean) * rstd * a.gamma[c] + a.beta[c]);
+    }
+}
+
+// GEGLU: h fp32 [M, 2*C4] (value | gate) -> fp16 [M, C4]
+__global__ __launch_bounds__(256) void k_geglu(const es_geglu_args a) {
+    const long n4 = (long)a.M * (a.C4 >> 2);
+    const int c4n = a.C4 >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long m = i / c4n;
+        const int c = (int)(i - m * c4n) * 4;
+        const float* p = a.h_f32 + m * 2 * a.C4 + c;
+        const f4 x = *(const f4*)p, g = *(const f4*)(p + a.C4);
+        h4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * es_gelu(g[e]));
+        *(h4*)((_Float16*)a.out_f16 + m * a.C4 + c) = y;
+    }
+}
+
+// NCDHW fp32 [O,C,V] -> channels-last f16 [O,V,Cpad] (zero padded channels)
+__global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int V, int Cpad, _Float16* out) {
+    const long n = (long)O * V * Cpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const long ov = i / Cpad;
+        const long o = ov / V, v = ov - o * V;
+        out[i] = c < C ? (_Float16)x[(o * C + c) * V + v] : (_Float16)0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv-pool stem of shape_messsage_passing (openai_model_3d.py:757-764), fp32, tiny.
+//   stage 1: Conv3d(3->32,k3,p1) @16^3 then MaxPool3d(2,2)  -> [O,32,8,8,8]
+//   stage 2: Conv3d(32->64,k3,p1) @8^3 then MaxPool3d(k=2,s=4) -> [O,64,2,2,2] -> flatten(512)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stem1(const es_stem_args a) {
+    // one thread per pooled output element [o][c][8][8][8]
+    const long n = (long)a.O * 32 * 512;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int pw = i & 7, ph = (i >> 3) & 7, pd = (i >> 6) & 7, c = (i >> 9) & 31;
+    const long o = i >> 14;
+    const float* x = a.x + o * 3 * 4096;
+    const float* w = a.w0 + c * 81;
+    float best = -INFINITY;
+    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+        const int d = 2 * pd + dz, h = 2 * ph + dy, ww = 2 * pw + dx;
+        float s = a.b0[c];
+        for (int ci = 0; ci < 3; ++ci)
+            for (int kd = 0; kd < 3; ++kd) { const int id = d + kd - 1; if (id < 0 || id > 15) continue;
+                for (int kh = 0; kh < 3; ++kh) { const int ih = h + kh - 1; if (ih < 0 || ih > 15) continue;
+                    for (int kw = 0; kw < 3; ++kw) { const int iw = ww + kw - 1; if (iw < 0 || iw > 15) continue;
+                        s += x[ci * 4096 + id * 256 + ih * 16 + iw] * w[ci * 27 + kd * 9 + kh * 3 + kw]; } } }
+        best = fmaxf(best, s);
+    }
+    a.scratch[i] = best;
+}
+
+__global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
+    // one thread per output [o][c=64][2][2][2]; pooling windows start at 0 and 4 (kernel 2, stride 4)
+    const long n = (long)a.O * 512;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int pw = i & 1, ph = (i >> 1) & 1, pd = (i >> 2) & 1, c = (i >> 3) & 63;
+    const long o = i >> 9;
+    const float* x = a.scratch + o * 32 * 512;
+    const float* w = a.w1 + c * 32 * 27;
+    float best = -INFINITY;
+    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+        const int d = 4 * pd + dz, h = 4 * ph + dy, ww = 4 * pw + dx;
+        float s = a.b1[c];
+        for (int ci = 0; ci < 32; ++ci)
+            for (int kd = 0; kd < 3; ++kd) { const int id = d + kd - 1; if (id < 0 || id > 7) continue;
+                for (int kh = 0; kh < 3; ++kh) { const int ih = h + kh - 1; if (ih < 0 || ih > 7) continue;
+                    for (int kw = 0; kw < 3; ++kw) { const int iw = ww + kw - 1; if (iw < 0 || iw > 7) continue;
+                        s += x[ci * 512 + id * 64 + ih * 8 + iw] * w[ci * 27 + kd * 9 + kh * 3 + kw]; } } }
+        best = fmaxf(best, s);
+    }
+    a.out[i] = best;       // i = o*512 + c*8 + pd*4 + ph*2 + pw  == nn.Flatten order of [O,64,2,2,2]
+}
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / linear on MFMA (fp16 in, fp32 accumulate).
+//   workgroup tile 128 (voxels) x 224 (output channels), K step 32, 4 waves as 2(M) x 2(N),
+//   wave tile 64 x 112 = 4 x 7 MFMA 16x16x32 tiles (112 accumulator VGPRs).
+//   N = 224 / 448 / 672 (and 3*C, 8*C) are all multiples of 224 at full width; ragged N / M are
+//   handled by zero-page rows and masked stores (narrow test configs).
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 224, BK = 32;
+constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 8192 + 14336
+
+struct ConvGeom {
+    int O, D, H, W;          // output grid
+    int Hi, Wi;              // input grid (H,W may differ from output for DOWN/UP)
+    int lw, lh, ld;          // log2 of W, H, D (output)
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.O * g.D * g.H * g.W;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-lane staging roles (fixed for the whole K loop) ----
+    // A: 512 16-B slots (128 rows x 4 chunks): slot p = tid + 256*j, j = 0,1
+    int a_row[2], a_lc[2];
+    int a_o[2], a_d[2], a_h[2], a_w[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = tid + 256 * j;
+        a_row[j] = p >> 2;
+        a_lc[j] = (p & 3) ^ f_swz(a_row[j]);
+        const long m = m0 + a_row[j];
+        a_ok[j] = m < M;
+        const long mm = a_ok[j] ? m : 0;
+        a_w[j] = (int)(mm & (g.W - 1));
+        a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
+        a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+        a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
+    }
+    // B: 896 slots (224 rows x 4 chunks): slot p = tid + 256*j, j = 0..3 (j = 3 only for tid < 128)
+    int b_row[4], b_lc[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = tid + 256 * j;
+        b_row[j] = p >> 2;
+        b_lc[j] = (p & 3) ^ f_swz(b_row[j]);
+        b_ok[j] = (p < BN * 4) && (n0 + b_row[j] < a.N);
+    }
+
+    f4 acc[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // K steps: phase 0 = taps x (Cin/32) of the main contraction, phase 1 = Cin2/32 steps of the
+    // optional fused 1x1 skip connection (accumulated into the same tile).
+    const int kch0 = a.Cin >> 5;
+    const int nks0 = a.taps * kch0;
+    const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
+
+    auto stage = [&](int ks, int b) {
+        char* As = smem + b * STAGE_BYTES;
+        char* Bs = As + A_BYTES;
+        const bool p1 = ks >= nks0;
+        const _Float16* Ag = (const _Float16*)(p1 ? a.a2 : a.a);
+        const _Float16* Wg = (const _Float16*)(p1 ? a.w2 : a.w);
+        const int Cin = p1 ? a.Cin2 : a.Cin;
+        const int taps = p1 ? 1 : a.taps;
+        const int mode = p1 ? (int)ES_CONV_SAME : a.mode;
+        const int Hi = p1 ? g.H : g.Hi, Wi = p1 ? g.W : g.Wi;
+        const int kk = p1 ? ks - nks0 : ks;
+        const int kch = p1 ? (a.Cin2 >> 5) : kch0;
+        const int tap = kk / kch, c0 = (kk - tap * kch) << 5;
+        int kd = 0, kh = 0, kw = 0;
+        if (taps == 27) { kd = tap / 9 - 1; kh = (tap / 3) % 3 - 1; kw = tap % 3 - 1; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const _Float16* src = zero_page;
+            const int id = a_d[j] + kd;
+            int ih, iw;
+            bool ok = a_ok[j] && id >= 0 && id < g.D;
+            if (mode == ES_CONV_DOWN_HW) {
+                ih = 2 * a_h[j] + kh; iw = 2 * a_w[j] + kw;
+                ok = ok && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+            } else {
+                ih = a_h[j] + kh; iw = a_w[j] + kw;
+                ok = ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                if (mode == ES_CONV_UP_HW) { ih >>= 1; iw >>= 1; }
+            }
+            if (ok) src = Ag + ((((long)a_o[j] * g.D + id) * Hi + ih) * Wi + iw) * Cin + c0 + a_lc[j] * 8;
+            glds16(src, As + (wave * 64 + 256 * j) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3 || wave < 2) {
+                const _Float16* src = zero_page;
+                if (b_ok[j]) src = Wg + ((long)(n0 + b_row[j]) * taps + tap) * Cin + c0 + b_lc[j] * 8;
+                glds16(src, Bs + (wave * 64 + 256 * j) * 16);
+            }
+        }
+    };
+
+    const int i16 = lane & 15, q = lane >> 4;
+    int buf = 0;
+    stage(0, 0);
+    for (int ks = 0; ks < nks; ++ks) {
+        __syncthreads();       // tile ks has landed (the barrier release waits vmcnt(0)) and every wave is
+                               // done reading the other buffer, which is refilled next
+        if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+        const char* As = smem + buf * STAGE_BYTES;
+        const char* Bs = As + A_BYTES;
+        h8 af[4], bfr[7];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + i16;
+            af[i] = *(const h8*)(As + row * 64 + ((q ^ f_swz(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int row = wn * 112 + j * 16 + i16;
+            bfr[j] = *(const h8*)(Bs + row * 64 + ((q ^ f_swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        buf ^= 1;
+    }
+
+    // ---- epilogue: D[row=(lane>>4)*4+r][col=lane&15] ----
+    const int col16 = i16, rq = q;
+    const int V = g.D * g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + wm * 64 + i * 16 + rq * 4 + r;
+            if (m >= M) continue;
+            const long o = m / V;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = n0 + wn * 112 + j * 16 + col16;
+                if (n >= a.N) continue;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[n];
+                if (a.rowvec) v += a.rowvec[o * a.rowvec_ld + n];
+                if (a.res) v += a.res[m * a.out_ld + n];
+                if (ncdhw) {
+                    a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
+                } else {
+                    if (a.out_f32) a.out_f32[m * a.out_ld + n] = v;
+                    if (a.out_f16) ((_Float16*)a.out_f16)[m * a.out_ld + n] = (_Float16)v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention, flash style, fp16 MFMA.  One workgroup = 64 query rows of one (batch, head);
+// 4 waves x 16 rows.  K tile [64 keys][dp], V tile transposed [dp][64 keys] in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int AT_Q = 64, AT_K = 64;
+
+template <int DP>   // padded head dim: 32, 64 or 96
+__global__ __launch_bounds__(256) void k_attention(const es_attn_args a) {
+    constexpr int KLD = DP + 8;              // halfs; +8 keeps 16-B alignment and skews banks
+    constexpr int VLD = AT_K + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[AT_K * KLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[DP * VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Ps[4][16 * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int C = a.heads * a.dhead, ldq = 3 * C;
+    const _Float16* base = (const _Float16*)a.qkv + (long)b * a.Ntok * ldq + h * a.dhead;
+    const int q0 = blockIdx.x * AT_Q + wave * 16;
+
+    // Q fragments for this wave's 16 rows: A[i=row][k=d], lane holds d = q4*8.. +7 of each 32-chunk
+    h8 qf[DP / 32];
+#pragma unroll
+    for (int kc = 0; kc < DP / 32; ++kc) {
+        const int d0 = kc * 32 + q4 * 8;
+        const _Float16* p = base + (long)(q0 + i16) * ldq + d0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kc][e] = (d0 + e < a.dhead && q0 + i16 < a.Ntok) ? p[e] : (_Float16)0.f;
+    }
+    f4 oacc[DP / 16];
+#pragma unroll
+    for (int j = 0; j < DP / 16; ++j) oacc[j] = f4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+
+    for (int k0 = 0; k0 < a.Ntok; k0 += AT_K) {
+        __syncthreads();
+        // stage K [64][DP] and V^T [DP][64]; 4-half (8 B) granularity (dhead % 4 == 0)
+        for (int idx = tid; idx < AT_K * (DP / 4); idx += 256) {
+            const int key = idx / (DP / 4), d = (idx - key * (DP / 4)) * 4;
+            h4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (d < a.dhead && k0 + key < a.Ntok) {
+                const _Float16* p = base + (long)(k0 + key) * ldq + d;
+                kv = *(const h4*)(p + C);
+                vv = *(const h4*)(p + 2 * C);
+            }
+            *(h4*)&Ks[key * KLD + d] = kv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Vt[(d + e) * VLD + key] = vv[e];
+        }
+        __syncthreads();
+        // S = Q K^T  (16 x 64 per wave): B[k=d][j=key] = K[key][d]
+        f4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < DP / 32; ++kc) {
+                const h8 kf = *(const h8*)&Ks[(t * 16 + i16) * KLD + kc * 32 + q4 * 8];
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kc], kf, s[t], 0, 0, 0);
+            }
+        }
+        // online softmax; lane holds S[row = q4*4 + r][key = t*16 + i16]
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t][r] = (k0 + t * 16 + i16 < a.Ntok) ? s[t][r] * a.scale : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+            const float mnew = fmaxf(mrow[r], mx);
+            alpha[r] = __expf(mrow[r] - mnew);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float p = __expf(s[t][r] - mnew); s[t][r] = p; ps += p; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 16);
+            lrow[r] = lrow[r] * alpha[r] + ps;
+            mrow[r] = mnew;
+        }
+        // P (fp16) through LDS into A-fragment order; rescale O
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[wave][(q4 * 4 + r) * VLD + t * 16 + i16] = (_Float16)s[t][r];
+#pragma unroll
+        for (int j = 0; j < DP / 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[j][r] *= alpha[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own LDS writes visible to own wave
+        __builtin_amdgcn_wave_barrier();
+        // O += P V : A[i=row][k=key], B[k=key][j=d] = Vt[d][key]
+#pragma unroll
+        for (int kc = 0; kc < AT_K / 32; ++kc) {
+            const h8 pf = *(const h8*)&Ps[wave][i16 * VLD + kc * 32 + q4 * 8];
+#pragma unroll
+            for (int j = 0; j < DP / 16; ++j) {
+                const h8 vf = *(const h8*)&Vt[(j * 16 + i16) * VLD + kc * 32 + q4 * 8];
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, oacc[j], 0, 0, 0);
+            }
+        }
+    }
+    // write O / l : lane holds O[row = q4*4 + r][d = j*16 + i16]
+    _Float16* out = (_Float16*)a.out_f16 + (long)b * a.Ntok * C + h * a.dhead;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q0 + q4 * 4 + r;
+        if (row >= a.Ntok) continue;
+        const float inv = 1.0f / lrow[r];
+#pragma unroll
+        for (int j = 0; j < DP / 16; ++j) {
+            const int d = j * 16 + i16;
+            if (d < a.dhead) out[(long)row * C + d] = (_Float16)(oacc[j][r] * inv);
+        }
+    }
+}
+
+_Float16* g_zero_page = nullptr;
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+}  // namespace
+
+// called outside of stream capture (es_plan_create / first direct call)
+int es_vol_init(void) {
+    if (!g_zero_page) {
+        ES_CHECK_HIP(hipMalloc((void**)&g_zero_page, 256));
+        ES_CHECK_HIP(hipMemset(g_zero_page, 0, 256));
+    }
+    return 0;
+}
+
+extern "C" size_t es_pack_conv_f16_size(int N, int Cin, int taps) { return (size_t)((N + 15) / 16 * 16) * taps * Cin; }
+
+static inline uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;     // round-to-nearest-even, as torch .half()
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+// h_w: [N][CinW][taps] (PyTorch conv weight flattened over kd,kh,kw) with CinW <= Cin (Cin = padded width)
+extern "C" int es_pack_conv_f16(const float* h_w, int N, int CinW, int taps, uint16_t* h_out) {
+    const int Cin = (CinW + 31) / 32 * 32;
+    const int Np = (N + 15) / 16 * 16;
+    for (int n = 0; n < Np; ++n)
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < Cin; ++c)
+                h_out[((size_t)n * taps + t) * Cin + c] =
+                    (n < N && c < CinW) ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + t]) : 0;
+    return 0;
+}
+
+extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
+    ES_REQUIRE(a->Cin % 32 == 0 && a->Cin > 0, "es_conv_mfma_f16: Cin=%d must be a positive multiple of 32", a->Cin);
+    ES_REQUIRE(a->taps == 27 || a->taps == 1, "es_conv_mfma_f16: taps=%d", a->taps);
+    ES_REQUIRE(!a->a2 || (a->Cin2 % 32 == 0 && a->Cin2 > 0), "es_conv_mfma_f16: Cin2=%d", a->Cin2);
+    ES_REQUIRE(a->out_f32 || a->out_f16, "es_conv_mfma_f16: no output");
+    ConvGeom g;
+    g.O = a->O; g.D = a->D; g.H = a->H; g.W = a->W;
+    g.Hi = a->H; g.Wi = a->W;
+    if (a->mode == ES_CONV_DOWN_HW) { g.Hi = 2 * a->H; g.Wi = 2 * a->W; }
+    if (a->mode == ES_CONV_UP_HW) { g.Hi = a->H / 2; g.Wi = a->W / 2; }
+    g.lw = ilog2_exact(a->W); g.lh = ilog2_exact(a->H); g.ld = ilog2_exact(a->D);
+    ES_REQUIRE(g.lw >= 0 && g.lh >= 0 && g.ld >= 0, "es_conv_mfma_f16: D,H,W must be powers of two (%d,%d,%d)", a->D, a->H, a->W);
+    const int ncdhw = a->out_ld < 0 ? 1 : 0;      // out_ld < 0 selects NCDHW fp32 output [O,N,V]
+    ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
+    if (!g_zero_page) if (int rc = es_vol_init()) return rc;
+    const long M = (long)a->O * a->D * a->H * a->W;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (a->N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
+    const int C = a->C1 + a->C2;
+    ES_REQUIRE(C % a->groups == 0 && C <= 2048 && a->groups <= 64, "es_groupnorm_vol: C=%d groups=%d", C, a->groups);
+    ES_REQUIRE(a->C1 % 8 == 0 && a->C2 % 8 == 0, "es_groupnorm_vol: channel counts must be multiples of 8 (%d,%d)", a->C1, a->C2);
+    ES_REQUIRE(a->stats != nullptr, "es_groupnorm_vol: stats scratch missing");
+    const int ntiles = (a->V + GN_VT - 1) / GN_VT;
+    float* part = a->stats;      // caller-provided scratch of O*ntiles*groups*2 floats
+    hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part);
+    const int vpb = 16;
+    hipLaunchKernelGGL(k_gn_apply, dim3((a->V + vpb - 1) / vpb, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, vpb);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
+    ES_REQUIRE(a->C <= 1024 && a->C > 0, "es_layernorm_tokens: C=%d (max 1024)", a->C);
+    hipLaunchKernelGGL(k_layernorm, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_attention_f16(const es_attn_args* a, es_stream stream) {
+    ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 96 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 96)", a->dhead);
+    dim3 grid((a->Ntok + AT_Q - 1) / AT_Q, a->B * a->heads);
+    if (a->dhead <= 32) hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->dhead <= 64) hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_geglu_f16(const es_geglu_args* a, es_stream stream) {
+    ES_REQUIRE(a->C4 % 4 == 0, "es_geglu_f16: C4=%d", a->C4);
+    const long n4 = (long)a->M * (a->C4 / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_geglu, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_latent_to_cl_f16(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) {
+    const long n = (long)O * V * Cpad;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_to_cl, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, O, C, V, Cpad, (_Float16*)out);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
+    const long n1 = (long)a->O * 32 * 512, n2 = (long)a->O * 512;
+    hipLaunchKernelGGL(k_stem1, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,159 @@
+"""ctypes binding of libechoscene_hip.so (include/echoscene_hip.h).
+
+The library is the product's only compute path.  ``lib()`` fails loudly when the shared
+object is missing -- there is no PyTorch / CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libechoscene_hip.so')
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+
+# enums (include/echoscene_hip.h)
+SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
+PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+CONV_SAME, CONV_DOWN_HW, CONV_UP_HW = 0, 1, 2
+(OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
+OP_FORK, OP_JOIN = 13, 14
+
+
+class Seg(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('idx', C.c_void_p), ('ent_row', C.c_void_p), ('ent_off', C.c_void_p),
+                ('step', C.c_void_p), ('step_stride', C.c_int32), ('ld', C.c_int32), ('width', C.c_int32),
+                ('mode', C.c_int32)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [('seg', Seg * 3), ('nseg', C.c_int32), ('M', C.c_int32), ('K', C.c_int32), ('N', C.c_int32),
+                ('wpack', C.c_void_p), ('bias', C.c_void_p), ('prologue', C.c_int32), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('eps', C.c_float), ('act', C.c_int32), ('res', C.c_void_p),
+                ('res_ld', C.c_int32), ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
+                ('out_ld', C.c_int32)]
+
+
+class UpdateArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('noise', C.c_void_p), ('noise_stride', C.c_int32),
+                ('coef', C.c_void_p), ('coef_stride', C.c_int32), ('step', C.c_void_p), ('n', C.c_int32),
+                ('inc_step', C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('w', C.c_void_p), ('O', C.c_int32), ('D', C.c_int32), ('H', C.c_int32),
+                ('W', C.c_int32), ('Cin', C.c_int32), ('N', C.c_int32), ('taps', C.c_int32), ('mode', C.c_int32),
+                ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
+                ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
+                ('out_ld', C.c_int32)]
+
+
+class GNArgs(C.Structure):
+    _fields_ = [('x1', C.c_void_p), ('C1', C.c_int32), ('x2', C.c_void_p), ('C2', C.c_int32), ('O', C.c_int32),
+                ('V', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('silu', C.c_int32), ('stats', C.c_void_p), ('y_f16', C.c_void_p),
+                ('raw_f16', C.c_void_p)]
+
+
+class LNArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('M', C.c_int32), ('C', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('y_f16', C.c_void_p)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('qkv', C.c_void_p), ('B', C.c_int32), ('Ntok', C.c_int32), ('heads', C.c_int32),
+                ('dhead', C.c_int32), ('scale', C.c_float), ('out_f16', C.c_void_p)]
+
+
+class GegluArgs(C.Structure):
+    _fields_ = [('h_f32', C.c_void_p), ('M', C.c_int32), ('C4', C.c_int32), ('out_f16', C.c_void_p)]
+
+
+class CopyArgs(C.Structure):
+    _fields_ = [('dst', C.c_void_p), ('src', C.c_void_p), ('bytes', C.c_size_t)]
+
+
+class ToClArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('O', C.c_int32), ('C', C.c_int32), ('V', C.c_int32), ('Cpad', C.c_int32),
+                ('out', C.c_void_p)]
+
+
+class StemArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p),
+                ('scratch', C.c_void_p), ('out', C.c_void_p), ('O', C.c_int32)]
+
+
+class _OpU(C.Union):
+    _fields_ = [('linear', LinearArgs), ('update', UpdateArgs), ('copy', CopyArgs), ('conv', ConvArgs),
+                ('gn', GNArgs), ('ln', LNArgs), ('attn', AttnArgs), ('geglu', GegluArgs), ('tocl', ToClArgs),
+                ('stem', StemArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('lane', C.c_int32), ('u', _OpU)]
+
+
+EXPORTS = {
+    'es_abi_version': (C.c_int, []),
+    'es_last_error': (C.c_char_p, []),
+    'es_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    'es_pack_linear_f32_size': (C.c_size_t, [C.c_int, C.c_int]),
+    'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
+    'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
+    'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'es_groupnorm_vol': (C.c_int, [C.POINTER(GNArgs), C.c_void_p]),
+    'es_layernorm_tokens': (C.c_int, [C.POINTER(LNArgs), C.c_void_p]),
+    'es_attention_f16': (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    'es_geglu_f16': (C.c_int, [C.POINTER(GegluArgs), C.c_void_p]),
+    'es_latent_to_cl_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_shape_stem': (C.c_int, [C.POINTER(StemArgs), C.c_void_p]),
+    'es_init': (C.c_int, []),
+    'es_plan_create': (C.c_void_p, [C.POINTER(Op), C.c_int]),
+    'es_plan_destroy': (None, [C.c_void_p]),
+    'es_plan_num_ops': (C.c_int, [C.c_void_p]),
+    'es_plan_run': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'es_plan_capture': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'es_sampler_run': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  -- torch's bundled HIP runtime must be the one the process binds first
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libechoscene_hip.so is missing (%s). Build it with `python -m echoscene_amd.build` '
+                '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.es_abi_version() != 1:
+            raise RuntimeError('libechoscene_hip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise RuntimeError('%s failed (status %d): %s' % (what or 'echoscene_hip call', rc,
+                                                          lib().es_last_error().decode()))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

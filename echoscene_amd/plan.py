@@ -1,0 +1,461 @@
+"""Plan compiler: turns a reference-keyed ``state_dict`` + a scene graph into the op list that the
+native runtime (csrc/es_runtime.hip) enqueues / graph-replays.
+
+Python runs only at build time (once per model and once per graph size); the per-step hot loop is
+``es_sampler_run`` in C++.  No arithmetic of the hot path is done by PyTorch here: torch is used
+for device allocations, host-side weight preparation (BatchNorm folding, centre-tap extraction,
+concatenation of projection matrices) and host->device copies.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import hip
+from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, Op
+
+
+class View:
+    """Pointer + leading dimension into a device matrix (column slices without copies)."""
+
+    def __init__(self, t, col=0, ld=None, width=None):
+        self.t = t
+        self.col = col
+        self.ld = (t.shape[-1] if t.dim() > 1 else 0) if ld is None else ld
+        self.width = (t.shape[-1] - col) if width is None else width
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.col
+
+
+def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=None, step_stride=0, width=None):
+    s = Seg()
+    s.ptr = view.ptr
+    s.idx = idx.data_ptr() if idx is not None else None
+    s.ent_row = ent_row.data_ptr() if ent_row is not None else None
+    s.ent_off = ent_off.data_ptr() if ent_off is not None else None
+    s.step = step.data_ptr() if step is not None else None
+    s.step_stride = step_stride
+    s.ld = view.ld
+    s.width = view.width if width is None else width
+    s.mode = mode
+    return s
+
+
+class PackedLinear:
+    """Device image of one (possibly fused) linear layer in MFMA fragment order."""
+
+    def __init__(self, W, b, device):
+        W = W.detach().to(torch.float32).contiguous().cpu()
+        self.N, self.K = W.shape
+        L = hip.lib()
+        n = L.es_pack_linear_f32_size(self.N, self.K)
+        out = torch.empty(n, dtype=torch.float32)
+        hip.check(L.es_pack_linear_f32(C.c_void_p(W.data_ptr()), self.N, self.K, C.c_void_p(out.data_ptr())),
+                  'es_pack_linear_f32')
+        self.w = out.to(device)
+        self.b = None if b is None else b.detach().to(torch.float32).contiguous().to(device)
+        self.weight_bytes = self.N * self.K * 4
+
+
+def fold_bn(sd, lin, bn):
+    """Linear followed by eval-mode BatchNorm1d -> one affine map (fp64 fold, fp32 result).
+    y = ((xW^T + b) - mean) * gamma / sqrt(var + eps) + beta   (model/layers.py:27-31)."""
+    W = sd[lin + '.weight'].double()
+    b = sd[lin + '.bias'].double()
+    s = sd[bn + '.weight'].double() / torch.sqrt(sd[bn + '.running_var'].double() + 1e-5)
+    return (W * s[:, None]).float(), ((b - sd[bn + '.running_mean'].double()) * s + sd[bn + '.bias'].double()).float()
+
+
+def centre_tap(w):
+    """Conv1d(k=3, pad=1) on a length-1 signal touches only the centre tap;
+    k=1 convs pass through."""
+    return w[:, :, w.shape[2] // 2] if w.dim() == 3 else w
+
+
+class GraphIndex:
+    """Device index arrays of one scene graph: gather indices for s/o and the CSR that turns
+    scatter_add + average (model/graph.py:172-199) into a deterministic segmented mean whose
+    summation order equals the reference's (s-messages in triple order, then o-messages)."""
+
+    def __init__(self, triples, num_objs, device):
+        tri = triples.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
+        self.O, self.T = int(num_objs), int(tri.shape[0])
+        if self.T and (tri[:, [0, 2]].min() < 0 or tri[:, [0, 2]].max() >= self.O):
+            raise IndexError('triple endpoint out of range')
+        self.s = torch.from_numpy(tri[:, 0].astype(np.int32)).to(device)
+        self.o = torch.from_numpy(tri[:, 2].astype(np.int32)).to(device)
+        self.p_host = tri[:, 1].copy()
+        self.tri_host = tri
+        self.device = device
+        self._csr = {}
+
+    def csr(self, off_s, off_o):
+        key = (off_s, off_o)
+        if key not in self._csr:
+            tri = self.tri_host
+            rows, offs, ptr = [], [], [0]
+            for n in range(self.O):
+                ts = np.nonzero(tri[:, 0] == n)[0]
+                to = np.nonzero(tri[:, 2] == n)[0]
+                rows += ts.tolist() + to.tolist()
+                offs += [off_s] * len(ts) + [off_o] * len(to)
+                ptr.append(len(rows))
+            mk = lambda a: torch.tensor(a, dtype=torch.int32).to(self.device)
+            self._csr[key] = (mk(ptr), mk(rows if rows else [0]), mk(offs if offs else [0]))
+        return self._csr[key]
+
+
+class Builder:
+    """Accumulates ops + keeps every referenced device tensor alive."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops = []
+        self.keep = []
+        self.weight_bytes = 0      # algorithmic weight bytes streamed per plan execution
+        self.tags = {}             # name -> View of an intermediate (parity debugging)
+        self.flops = 0
+
+    def buf(self, *shape, dtype=torch.float32, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def dev(self, t, dtype=torch.float32):
+        t = t.detach().to(dtype).contiguous().to(self.device)
+        self.keep.append(t)
+        return t
+
+    def linear(self, segs, pl, M, out, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
+               res=None, res2=None, lane=0, use_bias=True):
+        a = LinearArgs()
+        for i, s in enumerate(segs):
+            a.seg[i] = s
+        a.nseg = len(segs)
+        a.M, a.K, a.N = M, pl.K, pl.N
+        a.wpack = pl.w.data_ptr()
+        a.bias = pl.b.data_ptr() if (pl.b is not None and use_bias) else None
+        a.prologue = prologue
+        a.gamma = gamma.data_ptr() if gamma is not None else None
+        a.beta = beta.data_ptr() if beta is not None else None
+        a.eps = eps
+        a.act = act
+        a.res = res.ptr if res is not None else None
+        a.res_ld = res.ld if res is not None else 0
+        a.res2 = res2.ptr if res2 is not None else None
+        a.res2_ld = res2.ld if res2 is not None else 0
+        a.out = out.ptr
+        a.out_ld = out.ld
+        op = Op()
+        op.kind, op.lane = hip.OP_LINEAR, lane
+        op.u.linear = a
+        self.ops.append(op)
+        self.keep += [pl, gamma, beta]
+        self.weight_bytes += pl.weight_bytes
+        self.flops += 2 * M * pl.K * pl.N
+        return out
+
+    def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True):
+        a = UpdateArgs()
+        a.x, a.eps = x.data_ptr(), eps.data_ptr()
+        a.noise = noise.ptr if noise is not None else None
+        a.noise_stride = noise_stride
+        a.coef, a.coef_stride = coef.data_ptr(), coef.shape[1]
+        a.step = step.data_ptr()
+        a.n = x.numel()
+        a.inc_step = 1 if inc_step else 0
+        op = Op()
+        op.kind, op.lane = kind, 0
+        op.u.update = a
+        self.ops.append(op)
+
+    def copy(self, dst, src, nbytes):
+        a = CopyArgs()
+        a.dst, a.src, a.bytes = dst, src, nbytes
+        op = Op()
+        op.kind, op.lane = hip.OP_COPY, 0
+        op.u.copy = a
+        self.ops.append(op)
+
+    def finish(self):
+        return Plan(self)
+
+
+class Plan:
+    def __init__(self, b):
+        self.keep = b.keep
+        self.tags = b.tags
+        self.n_ops = len(b.ops)
+        self.weight_bytes = b.weight_bytes
+        self.flops = b.flops
+        arr = (Op * len(b.ops))(*b.ops)
+        self._arr = arr
+        self.handle = hip.lib().es_plan_create(arr, len(b.ops))
+        if not self.handle:
+            raise RuntimeError('es_plan_create: ' + hip.lib().es_last_error().decode())
+
+    def run(self):
+        hip.check(hip.lib().es_plan_run(C.c_void_p(self.handle), hip.current_stream()), 'es_plan_run')
+
+    def sample(self, step, first_step, n_steps, use_graph=True):
+        hip.check(hip.lib().es_sampler_run(C.c_void_p(self.handle), C.c_void_p(step.data_ptr()), first_step,
+                                           n_steps, 1 if use_graph else 0, hip.current_stream()), 'es_sampler_run')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                hip.lib().es_plan_destroy(C.c_void_p(self.handle))
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# GraphTripleConvNet  (reference model/graph.py:89-250)
+# ------------------------------------------------------------------------------------------------
+class GCNWeights:
+    """Packed weights of one GraphTripleConvNet: BatchNorm folded into the Linears."""
+
+    def __init__(self, sd, prefix, device):
+        self.layers = []
+        i = 0
+        while f'{prefix}.gconvs.{i}.net1.0.weight' in sd:
+            p = f'{prefix}.gconvs.{i}'
+            bn = (p + '.net1.1.running_mean') in sd
+            j2 = 3 if bn else 2                     # index of the second Linear inside build_mlp
+
+            def lin(name, idx):
+                q = f'{p}.{name}.{idx}'
+                if bn:
+                    W, b = fold_bn(sd, q, f'{p}.{name}.{idx + 1}')
+                else:
+                    W, b = sd[q + '.weight'], sd[q + '.bias']
+                return PackedLinear(W, b, device)
+
+            L = dict(n1a=lin('net1', 0), n1b=lin('net1', j2), n2a=lin('net2', 0), n2b=lin('net2', j2))
+            L['H'] = L['n2a'].K
+            L['Dout'] = L['n2b'].N
+            L['Dobj'] = None
+            if (p + '.linear_projection.weight') in sd:
+                L['proj'] = PackedLinear(sd[p + '.linear_projection.weight'], sd[p + '.linear_projection.bias'], device)
+                L['projp'] = PackedLinear(sd[p + '.linear_projection_pred.weight'],
+                                          sd[p + '.linear_projection_pred.bias'], device)
+                L['Dobj'] = L['proj'].K
+            self.layers.append(L)
+            i += 1
+        if not self.layers:
+            raise KeyError('no GraphTripleConvNet under ' + prefix)
+
+
+def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
+    """obj: View [O, Dobj]; pred: View [T, Dp]; returns View of the last layer's object output
+    (and the predicate output when ``want_pred`` -- the samplers never consume it)."""
+    O, T = g.O, g.T
+    n = len(gw.layers)
+    b.keep.append(g)            # the plan references the graph's device index arrays
+    for li, L in enumerate(gw.layers):
+        H, Dout = L['H'], L['Dout']
+        W2 = 2 * H + Dp
+        t1 = View(b.buf(T, H))
+        b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
+                  seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, t1, act=hip.ACT_RELU)
+        t2 = View(b.buf(T, W2))
+        b.linear([seg(t1)], L['n1b'], T, t2, act=hip.ACT_RELU)
+        last = li == n - 1
+        if 'proj' in L:
+            proj = View(b.buf(O, Dout))
+            b.linear([seg(obj, width=Dobj)], L['proj'], O, proj)
+            if not last or want_pred:
+                newp = View(b.buf(T, Dp))
+                b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp))
+        else:
+            proj = None
+            newp = View(t2.t, col=H, ld=W2, width=Dp)
+        ptr, rows, offs = g.csr(0, H + Dp)
+        n1 = View(b.buf(O, H))
+        b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRMEAN, idx=ptr, ent_row=rows, ent_off=offs)],
+                 L['n2a'], O, n1, act=hip.ACT_RELU)
+        dst = out if (last and out is not None) else View(b.buf(O, Dout))
+        b.linear([seg(n1)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
+        obj, Dobj = dst, Dout
+        if not last or want_pred:
+            pred = newp
+    return (obj, pred) if want_pred else obj
+
+
+# ------------------------------------------------------------------------------------------------
+# UNet1DModel -- the layout denoiser as a chain of fused row-linears
+# (reference denoise_net.py:773-806; block semantics :293-313, attention.py:172-245, 385-396)
+# ------------------------------------------------------------------------------------------------
+class UNet1DWeights:
+    def __init__(self, sd, net, device):
+        """sd: state_dict of the UNet1DModel holder ``net`` (keys without prefix)."""
+        self.device = device
+        self.mc = net.model_channels
+        self.topo = net.topo
+        self.enable_t_emb = net.enable_t_emb
+        self.in_ch, self.out_ch = net.in_channels, net.out_channels
+        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        P = lambda w, bname: PackedLinear(centre_tap(sd[w]), sd[bname] if bname else None, device)
+        self.te0 = P('time_embed.0.weight', 'time_embed.0.bias')
+        self.te2 = P('time_embed.2.weight', 'time_embed.2.bias')
+        self.box_emb = P('box_embeddings.weight', 'box_embeddings.bias')
+        self.box_t = P('box_time_emb.weight', 'box_time_emb.bias') if net.enable_t_emb else None
+        self.pred_table = sd['pred_embeddings.weight'].detach().float().cpu()
+        self.gcn = GCNWeights(sd, 'box_graph_cov', device)
+        self.ctx_dim = self.gcn.layers[-1]['Dout']
+        inp, mid, out = net.topo
+        names = [(f'input_blocks.{i}.{j}', it) for i, blk in enumerate(inp) for j, it in enumerate(blk)]
+        names += [(f'middle_block.{j}', it) for j, it in enumerate(mid)]
+        names += [(f'output_blocks.{i}.{j}', it) for i, blk in enumerate(out) for j, it in enumerate(blk)]
+        self.items = {}
+        emb_w, emb_b, self.emb_slices, off = [], [], {}, 0
+        ca_v, self.ca = [], {}
+        for name, it in names:
+            kind = it[0]
+            d = {}
+            if kind == 'conv_in':
+                d['conv'] = P(name + '.weight', name + '.bias')
+            elif kind == 'res':
+                d['gn1'] = (dv(name + '.in_layers.0.weight'), dv(name + '.in_layers.0.bias'))
+                d['conv1'] = P(name + '.in_layers.2.weight', name + '.in_layers.2.bias')
+                d['gn2'] = (dv(name + '.out_layers.0.weight'), dv(name + '.out_layers.0.bias'))
+                d['conv2'] = P(name + '.out_layers.3.weight', name + '.out_layers.3.bias')
+                if (name + '.skip_connection.weight') in sd:
+                    d['skip'] = P(name + '.skip_connection.weight', name + '.skip_connection.bias')
+                emb_w.append(sd[name + '.emb_layers.1.weight'])
+                emb_b.append(sd[name + '.emb_layers.1.bias'])
+                self.emb_slices[name] = (off, it[2])
+                off += it[2]
+            elif kind == 'attn':
+                tb = name + '.transformer_blocks.0'
+                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
+                d['proj_in'] = P(name + '.proj_in.weight', name + '.proj_in.bias')
+                d['ln1'] = (dv(tb + '.norm1.weight'), dv(tb + '.norm1.bias'))
+                d['ln3'] = (dv(tb + '.norm3.weight'), dv(tb + '.norm3.bias'))
+                # one token, one key: softmax == 1, so attention(x) = to_out(to_v(.)) exactly
+                d['v1'] = P(tb + '.attn1.to_v.weight', None)
+                d['o1'] = P(tb + '.attn1.to_out.0.weight', tb + '.attn1.to_out.0.bias')
+                d['o2'] = P(tb + '.attn2.to_out.0.weight', tb + '.attn2.to_out.0.bias')
+                d['ff1'] = P(tb + '.ff.net.0.proj.weight', tb + '.ff.net.0.proj.bias')
+                d['ff2'] = P(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
+                d['proj_out'] = P(name + '.proj_out.weight', name + '.proj_out.bias')
+                self.ca[name] = (len(ca_v), it[1])
+                ca_v.append(sd[tb + '.attn2.to_v.weight'])
+            elif kind == 'down':
+                d['conv'] = P(name + '.op.weight', name + '.op.bias')
+            elif kind == 'up':
+                d['conv'] = P(name + '.conv.weight', name + '.conv.bias')
+            self.items[name] = d
+        # all ResBlock emb projections / all cross-attention value projections as ONE product each
+        self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
+        self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
+        self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
+        self.out_conv = P('out.2.weight', 'out.2.bias')
+
+
+def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
+    """One UNet1DModel.forward on x [O, in_ch] -> eps_out [O, out_ch]."""
+    O, mc = g.O, w.mc
+    E = 4 * mc
+    gdim = 64
+    # timestep MLP (all nodes share t: the table row is broadcast with ld = 0)
+    e1 = View(b.buf(O, E))
+    b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
+    emb = View(b.buf(O, E))
+    b.linear([seg(e1)], w.te2, O, emb)
+    # GCN input  [obj_embed | box_embeddings(x_t) | box_time_emb(emb)]   (denoise_net.py:758-771)
+    Dobj = obj_embed_dev.shape[1] + gdim + (gdim if w.enable_t_emb else 0)
+    objbuf = b.buf(O, Dobj)
+    oe_w = obj_embed_dev.shape[1]
+    objbuf[:, :oe_w].copy_(obj_embed_dev)        # constant over the loop: written once at plan build
+    b.linear([seg(View(x))], w.box_emb, O, View(objbuf, col=oe_w, ld=Dobj, width=gdim))
+    if w.enable_t_emb:
+        b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
+    pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
+    ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
+    b.tags.update(emb=emb, ctx=ctx, gcn_in=View(objbuf))
+    # batched per-step side products
+    emb_all = b.buf(O, w.emb_all.N)
+    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
+    cav = b.buf(O, w.cav_all.N)
+    b.linear([seg(ctx)], w.cav_all, O, View(cav))
+    cavo = {}
+    for name, (k, C) in w.ca.items():
+        o = View(b.buf(O, C))
+        off = sum(c for (_, c) in list(w.ca.values())[:k])
+        b.linear([seg(View(cav, col=off, ld=w.cav_all.N, width=C))], w.items[name]['o2'], O, o)
+        cavo[name] = o
+
+    def run_block(name_prefix, blk, h_segs, hC):
+        """h_segs: list of Views forming the (possibly concatenated) input; returns (View, C)."""
+        for j, it in enumerate(blk):
+            name = f'{name_prefix}.{j}'
+            d = w.items[name]
+            kind = it[0]
+            if kind == 'conv_in':
+                o = View(b.buf(O, mc))
+                b.linear([seg(v) for v in h_segs], d['conv'], O, o)
+                h_segs, hC = [o], mc
+            elif kind == 'res':
+                cin, cout = it[1], it[2]
+                assert cin == hC
+                eo, _ = w.emb_slices[name]
+                h1 = View(b.buf(O, cout))
+                b.linear([seg(v) for v in h_segs], d['conv1'], O, h1, prologue=hip.PRO_GN_SILU,
+                         gamma=d['gn1'][0], beta=d['gn1'][1], eps=1e-5,
+                         res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout))
+                if 'skip' in d:
+                    sk = View(b.buf(O, cout))
+                    b.linear([seg(v) for v in h_segs], d['skip'], O, sk)
+                    resv = sk
+                else:
+                    assert len(h_segs) == 1
+                    resv = h_segs[0]
+                o = View(b.buf(O, cout))
+                b.linear([seg(h1)], d['conv2'], O, o, prologue=hip.PRO_GN_SILU, gamma=d['gn2'][0],
+                         beta=d['gn2'][1], eps=1e-5, res=resv)
+                h_segs, hC = [o], cout
+            elif kind == 'attn':
+                C = it[1]
+                xin = h_segs[0]
+                t0 = View(b.buf(O, C))
+                b.linear([seg(xin)], d['proj_in'], O, t0, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1],
+                         eps=1e-6)
+                v1 = View(b.buf(O, C))
+                b.linear([seg(t0)], d['v1'], O, v1, prologue=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5)
+                # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one key the second line adds the
+                # per-node vector to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
+                t2 = View(b.buf(O, C))
+                b.linear([seg(v1)], d['o1'], O, t2, res=t0, res2=cavo[name])
+                b.tags[name + '.transformer_blocks.0:in'] = t0
+                b.tags[name + '.transformer_blocks.0:attn2'] = t2
+                gl = View(b.buf(O, 8 * C))
+                b.linear([seg(t2)], d['ff1'], O, gl, prologue=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5)
+                t3 = View(b.buf(O, C))
+                b.linear([seg(View(gl.t, ld=8 * C, width=4 * C))], d['ff2'], O, t3, prologue=hip.PRO_GEGLU, res=t2)
+                b.tags[name + '.transformer_blocks.0:ff'] = t3
+                o = View(b.buf(O, C))
+                b.linear([seg(t3)], d['proj_out'], O, o, res=xin)
+                h_segs, hC = [o], C
+            elif kind in ('down', 'up'):
+                o = View(b.buf(O, hC))
+                b.linear([seg(v) for v in h_segs], d['conv'], O, o)
+                h_segs = [o]
+            b.tags[name] = h_segs[0]
+        return h_segs, hC
+
+    inp, mid, out = w.topo
+    hs = []
+    h_segs, hC = [View(x)], w.in_ch
+    for i, blk in enumerate(inp):
+        h_segs, hC = run_block(f'input_blocks.{i}', blk, h_segs, hC)
+        hs.append((h_segs[0], hC))
+    h_segs, hC = run_block('middle_block', mid, h_segs, hC)
+    for i, blk in enumerate(out):
+        sk, sC = hs.pop()
+        h_segs, hC = run_block(f'output_blocks.{i}', blk, [h_segs[0], sk], hC + sC)
+    b.linear([seg(h_segs[0])], w.out_conv, O, View(eps_out), prologue=hip.PRO_GN_SILU, gamma=w.out_gn[0],
+             beta=w.out_gn[1], eps=1e-5)
+    return objbuf

@@ -1,0 +1,332 @@
+"""Plan compiler for the 3-D latent-SDF denoiser (reference UNet3DModel.forward,
+model/networks/diffusion_shape/openai_model_3d.py:816-863, block semantics :294-314 and
+attention.py:172-245, 335-351).
+
+Per-object vectors (time MLP, conv-pool stem code, shape GCN, ResBlock time projections,
+cross-attention-with-one-key vectors) run on the fp32 "rows" path; everything with a voxel
+dimension runs on the "volume" path (channels-last, fp16 MFMA operands, fp32 accumulate and
+fp32 residual stream).
+"""
+import ctypes as C
+import torch
+
+from . import hip
+from .hip import ConvArgs, GNArgs, LNArgs, AttnArgs, GegluArgs, ToClArgs, StemArgs, Op
+from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn)
+
+
+class PackedConv:
+    """f16 [Npad][taps][Cin32] image of a conv / linear weight + fp32 bias on the device."""
+
+    def __init__(self, W, b, device):
+        W = W.detach().float().contiguous().cpu()
+        self.N, cin = W.shape[0], W.shape[1]
+        self.taps = 1 if W.dim() == 2 else int(W[0, 0].numel())
+        if self.taps not in (1, 27):
+            raise ValueError('conv kernel must be 1x1x1 or 3x3x3')
+        self.Cin = (cin + 31) // 32 * 32
+        L = hip.lib()
+        n = L.es_pack_conv_f16_size(self.N, self.Cin, self.taps)
+        out = torch.empty(n, dtype=torch.int16)
+        hip.check(L.es_pack_conv_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())),
+                  'es_pack_conv_f16')
+        self.w = out.to(device)
+        self.b = None if b is None else b.detach().float().contiguous().to(device)
+        self.weight_bytes = self.N * cin * self.taps * 2
+        self.cin_true = cin
+
+
+class UNet3DWeights:
+    def __init__(self, sd, net, device):
+        """sd: state_dict of the UNet3DModel holder ``net`` (keys without 'diffusion_net.')."""
+        self.device, self.mc, self.topo = device, net.model_channels, net.topo
+        self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
+        self.heads = net.num_heads
+        if not self.mp:
+            raise NotImplementedError('shape denoiser without message passing (config full.yaml) is not built yet')
+        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        PL = lambda w, b: PackedLinear(sd[w], sd[b] if b else None, device)
+        PC = lambda w, b: PackedConv(sd[w], sd[b] if b else None, device)
+        self.te0 = PL('time_embed.0.weight', 'time_embed.0.bias')
+        self.te2 = PL('time_embed.2.weight', 'time_embed.2.bias')
+        self.stem = [dv('shape_embeddings.0.weight'), dv('shape_embeddings.0.bias'),
+                     dv('shape_embeddings.2.weight'), dv('shape_embeddings.2.bias')]
+        self.stem_lin = PL('shape_embeddings.5.weight', 'shape_embeddings.5.bias')
+        self.shape_t = PL('shape_time_emb.weight', 'shape_time_emb.bias') if net.enable_t_emb else None
+        self.pred_table = sd['pred_embeddings.weight'].detach().float().cpu()
+        self.gcn = GCNWeights(sd, 'shape_code_graph_cov', device)
+        inp, mid, out = net.topo
+        names = [(f'input_blocks.{i}.{j}', it) for i, blk in enumerate(inp) for j, it in enumerate(blk)]
+        names += [(f'middle_block.{j}', it) for j, it in enumerate(mid)]
+        names += [(f'output_blocks.{i}.{j}', it) for i, blk in enumerate(out) for j, it in enumerate(blk)]
+        self.items, self.emb_slices, self.ca = {}, {}, {}
+        emb_w, emb_b, ca_v, off = [], [], [], 0
+        for name, it in names:
+            kind, d = it[0], {}
+            if kind == 'conv_in':
+                d['conv'] = PC(name + '.weight', name + '.bias')
+            elif kind == 'res':
+                d['gn1'] = (dv(name + '.in_layers.0.weight'), dv(name + '.in_layers.0.bias'))
+                d['conv1'] = PC(name + '.in_layers.2.weight', name + '.in_layers.2.bias')
+                d['gn2'] = (dv(name + '.out_layers.0.weight'), dv(name + '.out_layers.0.bias'))
+                d['conv2'] = PC(name + '.out_layers.3.weight', name + '.out_layers.3.bias')
+                if (name + '.skip_connection.weight') in sd:
+                    d['skip'] = PackedConv(sd[name + '.skip_connection.weight'].flatten(1), None, device)
+                    # both biases are added once in the fused epilogue
+                    d['bias2'] = (sd[name + '.out_layers.3.bias'].float() +
+                                  sd[name + '.skip_connection.bias'].float()).contiguous().to(device)
+                emb_w.append(sd[name + '.emb_layers.1.weight'])
+                emb_b.append(sd[name + '.emb_layers.1.bias'])
+                self.emb_slices[name] = (off, it[2])
+                off += it[2]
+            elif kind == 'attn':
+                tb = name + '.transformer_blocks.0'
+                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
+                d['proj_in'] = PackedConv(sd[name + '.proj_in.weight'].flatten(1), sd[name + '.proj_in.bias'], device)
+                d['ln1'] = (dv(tb + '.norm1.weight'), dv(tb + '.norm1.bias'))
+                d['ln3'] = (dv(tb + '.norm3.weight'), dv(tb + '.norm3.bias'))
+                d['qkv'] = PackedConv(torch.cat([sd[tb + '.attn1.to_q.weight'], sd[tb + '.attn1.to_k.weight'],
+                                                 sd[tb + '.attn1.to_v.weight']], 0), None, device)
+                d['o1'] = PC(tb + '.attn1.to_out.0.weight', tb + '.attn1.to_out.0.bias')
+                d['o2'] = PL(tb + '.attn2.to_out.0.weight', tb + '.attn2.to_out.0.bias')     # rows path
+                d['ff1'] = PC(tb + '.ff.net.0.proj.weight', tb + '.ff.net.0.proj.bias')
+                d['ff2'] = PC(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
+                d['proj_out'] = PackedConv(sd[name + '.proj_out.weight'].flatten(1), sd[name + '.proj_out.bias'], device)
+                self.ca[name] = (len(ca_v), it[1])
+                ca_v.append(sd[tb + '.attn2.to_v.weight'])
+            elif kind == 'down':
+                d['conv'] = PC(name + '.op.weight', name + '.op.bias')
+            elif kind == 'up':
+                d['conv'] = PC(name + '.conv.weight', name + '.conv.bias')
+            self.items[name] = d
+        self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
+        self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
+        self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
+        self.out_conv = PC('out.2.weight', 'out.2.bias')
+        self.in_ch, self.out_ch = net.in_channels, net.out_channels
+
+
+class VolBuilderMixin:
+    """Volume-path op emitters, mixed into plan.Builder."""
+
+    def _push(self, kind, field, a):
+        op = Op()
+        op.kind, op.lane = kind, 0
+        setattr(op.u, field, a)
+        self.ops.append(op)
+        return len(self.ops) - 1
+
+    def conv(self, a_f16, pc, O, dims, mode=hip.CONV_SAME, bias=None, rowvec=None, res=None, out_f32=None,
+             out_f16=None, skip=None, ncdhw=False):
+        """dims = (D,H,W) of the OUTPUT grid. skip = (raw_f16 tensor, PackedConv) for the fused 1x1 skip."""
+        D, H, W = dims
+        a = ConvArgs()
+        a.a, a.w = a_f16.data_ptr(), pc.w.data_ptr()
+        a.O, a.D, a.H, a.W = O, D, H, W
+        a.Cin, a.N, a.taps, a.mode = pc.Cin, pc.N, pc.taps, mode
+        if skip is not None:
+            a.a2, a.w2, a.Cin2 = skip[0].data_ptr(), skip[1].w.data_ptr(), skip[1].Cin
+            self.weight_bytes += skip[1].weight_bytes
+            self.flops += 2 * O * D * H * W * skip[1].Cin * pc.N
+        bt = pc.b if bias is None else bias
+        a.bias = bt.data_ptr() if bt is not None else None
+        if rowvec is not None:
+            a.rowvec, a.rowvec_ld = rowvec.ptr, rowvec.ld
+        a.res = res.data_ptr() if res is not None else None
+        a.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
+        a.out_f16 = out_f16.data_ptr() if out_f16 is not None else None
+        a.out_ld = -1 if ncdhw else pc.N
+        self.keep += [pc, bt, skip]
+        self.weight_bytes += pc.weight_bytes
+        self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
+        return self._push(hip.OP_CONV, 'conv', a)
+
+    def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None):
+        a = GNArgs()
+        a.x1, a.C1 = x1.data_ptr(), C1
+        a.x2, a.C2 = (x2.data_ptr(), C2) if x2 is not None else (None, 0)
+        a.O, a.V, a.groups, a.eps = O, V, 32, eps
+        a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0
+        ntiles = (V + 63) // 64
+        a.stats = self.buf(O * ntiles * 32 * 2).data_ptr()
+        a.y_f16 = y_f16.data_ptr()
+        a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
+        self.keep += [gamma, beta]
+        return self._push(hip.OP_GN, 'gn', a)
+
+    def layernorm(self, x, M, Cc, gamma, beta, y_f16):
+        a = LNArgs()
+        a.x, a.M, a.C, a.eps = x.data_ptr(), M, Cc, 1e-5
+        a.gamma, a.beta, a.y_f16 = gamma.data_ptr(), beta.data_ptr(), y_f16.data_ptr()
+        self.keep += [gamma, beta]
+        return self._push(hip.OP_LN, 'ln', a)
+
+    def attention(self, qkv, B, Ntok, heads, dhead, out_f16):
+        a = AttnArgs()
+        a.qkv, a.B, a.Ntok, a.heads, a.dhead = qkv.data_ptr(), B, Ntok, heads, dhead
+        a.scale = float(dhead) ** -0.5
+        a.out_f16 = out_f16.data_ptr()
+        self.flops += 4 * B * heads * Ntok * Ntok * dhead
+        return self._push(hip.OP_ATTN, 'attn', a)
+
+    def geglu(self, h_f32, M, C4, out_f16):
+        a = GegluArgs()
+        a.h_f32, a.M, a.C4, a.out_f16 = h_f32.data_ptr(), M, C4, out_f16.data_ptr()
+        return self._push(hip.OP_GEGLU, 'geglu', a)
+
+    def to_cl(self, x, O, Cc, V, Cpad, out):
+        a = ToClArgs()
+        a.x, a.O, a.C, a.V, a.Cpad, a.out = x.data_ptr(), O, Cc, V, Cpad, out.data_ptr()
+        return self._push(hip.OP_TO_CL, 'tocl', a)
+
+    def stem(self, x, w, scratch, out, O):
+        a = StemArgs()
+        a.x = x.data_ptr()
+        a.w0, a.b0, a.w1, a.b1 = [t.data_ptr() for t in w]
+        a.scratch, a.out, a.O = scratch.data_ptr(), out.data_ptr(), O
+        self.keep += list(w)
+        return self._push(hip.OP_STEM, 'stem', a)
+
+
+def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16)):
+    """One UNet3DModel.forward: x f32 [O,3,D,H,W] (NCDHW) -> eps_out f32 [O,3,D,H,W]."""
+    O, mc, E, gdim = g.O, w.mc, 4 * w.mc, 64
+    D0, H0, W0 = dims
+    V0 = D0 * H0 * W0
+    f16 = torch.float16
+    # ---- per-object (rows path) ----
+    e1 = View(b.buf(O, E))
+    b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
+    emb = View(b.buf(O, E))
+    b.linear([seg(e1)], w.te2, O, emb)
+    ucw = uc_dev.shape[1]
+    Dobj = ucw + gdim + (gdim if w.enable_t_emb else 0)
+    objbuf = b.buf(O, Dobj)
+    objbuf[:, :ucw].copy_(uc_dev)
+    code512 = b.buf(O, 512)
+    b.stem(x, w.stem, b.buf(O, 32 * 512), code512, O)
+    b.linear([seg(View(code512))], w.stem_lin, O, View(objbuf, col=ucw, ld=Dobj, width=gdim))
+    if w.enable_t_emb:
+        b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
+    pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
+    ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
+    b.tags.update(emb=emb, ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
+    emb_all = b.buf(O, w.emb_all.N)
+    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
+    cav = b.buf(O, w.cav_all.N)
+    b.linear([seg(ctx)], w.cav_all, O, View(cav))
+    cavo, coff = {}, 0
+    for name, (k, Cc) in w.ca.items():
+        o = View(b.buf(O, Cc))
+        b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
+        cavo[name] = o
+        coff += Cc
+
+    # ---- volume path ----
+    state = dict(h=None, C=0, dims=dims, last_op=None, h16=None)
+
+    def V_(dm):
+        return dm[0] * dm[1] * dm[2]
+
+    def need_f16():
+        """f16 copy of the current fp32 activation (for convs that read it un-normalised)."""
+        if state['h16'] is None:
+            t = b.buf(O * V_(state['dims']), state['C'], dtype=f16)
+            op = b.ops[state['last_op']]
+            op.u.conv.out_f16 = t.data_ptr()
+            state['h16'] = t
+        return state['h16']
+
+    def run_block(prefix, blk, skip=None):
+        for j, it in enumerate(blk):
+            name, kind = f'{prefix}.{j}', it[0]
+            d = w.items[name]
+            dm = state['dims']
+            M = O * V_(dm)
+            if kind == 'conv_in':
+                xcl = b.buf(O * V0, 32, dtype=f16)
+                b.to_cl(x, O, w.in_ch, V0, 32, xcl)
+                o = b.buf(M, mc)
+                state['last_op'] = b.conv(xcl, d['conv'], O, dm, out_f32=o)
+                state.update(h=o, C=mc, h16=None)
+            elif kind == 'res':
+                cin, cout = it[1], it[2]
+                x1, C1 = state['h'], state['C']
+                x2, C2 = (skip if skip is not None else (None, 0))
+                assert C1 + C2 == cin, (name, C1, C2, cin)
+                eo, _ = w.emb_slices[name]
+                y1 = b.buf(M, cin, dtype=f16)
+                raw = b.buf(M, cin, dtype=f16) if 'skip' in d else None
+                b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
+                h1 = b.buf(M, cout)
+                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), out_f32=h1)
+                y2 = b.buf(M, cout, dtype=f16)
+                b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
+                o = b.buf(M, cout)
+                if 'skip' in d:
+                    state['last_op'] = b.conv(y2, d['conv2'], O, dm, bias=d['bias2'], skip=(raw, d['skip']), out_f32=o)
+                else:
+                    assert x2 is None
+                    state['last_op'] = b.conv(y2, d['conv2'], O, dm, res=x1, out_f32=o)
+                state.update(h=o, C=cout, h16=None)
+                skip = None
+            elif kind == 'attn':
+                Cc = it[1]
+                xin = state['h']
+                yn = b.buf(M, Cc, dtype=f16)
+                b.groupnorm(xin, Cc, None, 0, O, V_(dm), d['gn'][0], d['gn'][1], 1e-6, False, yn)
+                t0 = b.buf(M, Cc)
+                b.conv(yn, d['proj_in'], O, dm, out_f32=t0)
+                l1 = b.buf(M, Cc, dtype=f16)
+                b.layernorm(t0, M, Cc, d['ln1'][0], d['ln1'][1], l1)
+                qkv = b.buf(M, 3 * Cc, dtype=f16)
+                b.conv(l1, d['qkv'], O, dm, out_f16=qkv)
+                at = b.buf(M, Cc, dtype=f16)
+                b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
+                # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
+                t2 = b.buf(M, Cc)
+                b.conv(at, d['o1'], O, dm, rowvec=cavo[name], res=t0, out_f32=t2)
+                l3 = b.buf(M, Cc, dtype=f16)
+                b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
+                gl = b.buf(M, 8 * Cc)
+                b.conv(l3, d['ff1'], O, dm, out_f32=gl)
+                gg = b.buf(M, 4 * Cc, dtype=f16)
+                b.geglu(gl, M, 4 * Cc, gg)
+                t3 = b.buf(M, Cc, dtype=f16)
+                b.conv(gg, d['ff2'], O, dm, res=t2, out_f16=t3)
+                o = b.buf(M, Cc)
+                state['last_op'] = b.conv(t3, d['proj_out'], O, dm, res=xin, out_f32=o)
+                b.tags[name + '.transformer_blocks.0:in'] = View(t0)
+                b.tags[name + '.transformer_blocks.0:attn2'] = View(t2)
+                state.update(h=o, h16=None)
+            elif kind == 'down':
+                a16 = need_f16()
+                nd = (dm[0], dm[1] // 2, dm[2] // 2)
+                o = b.buf(O * V_(nd), state['C'])
+                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_DOWN_HW, out_f32=o)
+                state.update(h=o, dims=nd, h16=None)
+            elif kind == 'up':
+                a16 = need_f16()
+                nd = (dm[0], dm[1] * 2, dm[2] * 2)
+                o = b.buf(O * V_(nd), state['C'])
+                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_UP_HW, out_f32=o)
+                state.update(h=o, dims=nd, h16=None)
+            b.tags[name] = View(state['h'])
+
+    inp, mid, out = w.topo
+    hs = []
+    for i, blk in enumerate(inp):
+        run_block(f'input_blocks.{i}', blk)
+        hs.append((state['h'], state['C']))
+    run_block('middle_block', mid)
+    for i, blk in enumerate(out):
+        run_block(f'output_blocks.{i}', blk, skip=hs.pop())
+    dm = state['dims']
+    yo = b.buf(O * V_(dm), state['C'], dtype=f16)
+    b.groupnorm(state['h'], state['C'], None, 0, O, V_(dm), w.out_gn[0], w.out_gn[1], 1e-5, True, yo)
+    b.conv(yo, w.out_conv, O, dm, out_f32=eps_out, ncdhw=True)
+    return objbuf
+
+
+for _n in ('_push', 'conv', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
+    setattr(Builder, _n, getattr(VolBuilderMixin, _n))

@@ -1,0 +1,166 @@
+"""Loop owners on the host side: thin objects that own packed weights + per-graph plans and call
+the native sampling loop.  They mirror ``EchoToLayout`` / ``EchoToShape`` of the reference
+(model/networks/diffusion_layout/echo2layout.py, diffusion_shape/echo2shape.py)."""
+import torch
+
+from . import hip
+from .plan import (Builder, GraphIndex, View, GCNWeights, UNet1DWeights, emit_gcn, emit_unet1d_step)
+from .plan_vol import UNet3DWeights, emit_unet3d_step
+from .schedules import LayoutSchedule, ShapeSchedule, timestep_embedding_table
+
+
+def _cpu_sd(module):
+    return {k: v.detach().cpu() for k, v in module.state_dict().items()}
+
+
+def gcn_forward(sd, prefix, obj, pred, triples, device=None, weights=None):
+    """GraphTripleConvNet.forward on the HIP path (setup GCNs and unit tests).
+    obj f32[O,Dobj], pred f32[T,Dp] (any device), triples int64[T,3] -> (obj_out, pred_out) on device."""
+    device = device or torch.device('cuda')
+    gw = weights or GCNWeights(sd, prefix, device)
+    g = GraphIndex(triples, obj.shape[0], device)
+    b = Builder(device)
+    o = b.dev(obj)
+    p = b.dev(pred)
+    oo, po = emit_gcn(b, gw, g, View(o), obj.shape[1], View(p), pred.shape[1], want_pred=True)
+    plan = b.finish()
+    plan.run()
+    torch.cuda.synchronize()
+    out_p = po.t if po.col == 0 and po.ld == po.t.shape[1] else po.t[:, po.col:po.col + po.width].contiguous()
+    return oo.t, out_p
+
+
+class LayoutDenoiser:
+    """UNet1DModel + GaussianDiffusion sampling on the HIP path (loop A of SURVEY.md section 3.1)."""
+
+    def __init__(self, net, diffusion_kwargs, device=None):
+        self.device = device or torch.device('cuda')
+        self.net = net
+        self.w = UNet1DWeights(_cpu_sd(net), net, self.device)
+        dk = dict(diffusion_kwargs)
+        if dk.get('model_mean_type', 'eps') != 'eps' or dk.get('model_var_type', 'fixedsmall') != 'fixedsmall':
+            raise NotImplementedError('only eps-prediction / fixedsmall is on the sampling path')
+        self.sched = LayoutSchedule(dk.get('time_num', 1000), dk.get('beta_start', 1e-4), dk.get('beta_end', 0.02),
+                                    dk.get('schedule_type', 'linear'))
+        self.T = self.sched.time_num
+        self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
+        self.coef = self.sched.coef.to(self.device)
+        self._plans = {}
+
+    def _plan_for(self, obj_embed, triples):
+        O = obj_embed.shape[0]
+        key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
+        st = self._plans.get(key)
+        if st is None:
+            g = GraphIndex(triples, O, self.device)
+            b = Builder(self.device)
+            D = self.net.in_channels
+            x = b.buf(O, D)
+            eps = b.buf(O, self.net.out_channels)
+            step = b.buf(1, dtype=torch.int32, zero=True)
+            noise = b.buf(self.T + 1, O, D)
+            oe = b.dev(obj_embed)
+            objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, eps)
+            n_eps_ops = len(b.ops)
+            b.update(hip.OP_DDPM, x, eps, self.coef, step, noise=View(noise[1:].reshape(self.T, O * D), ld=O * D),
+                     noise_stride=O * D, inc_step=True)
+            plan = b.finish()
+            # eps-only plan (same ops minus the update) for step-level parity tests
+            b2 = Builder(self.device)
+            b2.ops = b.ops[:n_eps_ops]
+            b2.keep = b.keep
+            b2.tags = b.tags
+            st = dict(plan=plan, eps_plan=b2.finish(), x=x, eps=eps, step=step, noise=noise, objbuf=objbuf,
+                      oe_w=oe.shape[1])
+            self._plans = {key: st}          # keep one graph resident (scenes are sampled one at a time)
+        st['objbuf'][:, :st['oe_w']].copy_(obj_embed.to(self.device))
+        return st
+
+    @property
+    def weight_bytes_per_step(self):
+        st = next(iter(self._plans.values()))
+        return st['plan'].weight_bytes
+
+    def eps(self, x, obj_embed, triples, iteration):
+        """One UNet1DModel.forward at loop iteration ``iteration`` (t = T-1-iteration)."""
+        st = self._plan_for(obj_embed, triples)
+        st['x'].copy_(x.to(self.device))
+        st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
+        return st['eps'].clone()
+
+    def sample(self, obj_embed, triples, noise=None, n_steps=None, use_graph=True):
+        """p_sample_loop_sg: returns x_0 [O, 8].  ``noise`` f32[T+1, O, 8] (row 0 = x_T, row 1+i = draw of
+        iteration i) makes the run reproducible against the CPU oracle; None draws it on the device."""
+        st = self._plan_for(obj_embed, triples)
+        O, D = st['x'].shape
+        n_steps = self.T if n_steps is None else n_steps
+        if noise is None:
+            st['noise'].normal_()
+        else:
+            st['noise'][:noise.shape[0]].copy_(noise.to(self.device))
+        st['x'].copy_(st['noise'][0])
+        st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
+        return st['x'].clone()
+
+
+class ShapeDenoiser:
+    """UNet3DModel + DDIM sampling on the HIP path (loop B of SURVEY.md section 3.1):
+    ``EchoToShape.rel2shape`` without the VQ-VAE decode (echo2shape.py:484-521)."""
+
+    def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16)):
+        """df: DiffusionUNet holder; model_params: df_conf.model.params (linear_start/end, timesteps)."""
+        self.device = device or torch.device('cuda')
+        self.df = df
+        net = df.diffusion_net
+        self.net = net
+        sd = {k[len('diffusion_net.'):]: v for k, v in _cpu_sd(df).items()}
+        self.w = UNet3DWeights(sd, net, self.device)
+        mp = dict(model_params or {})
+        self.sched = ShapeSchedule(ddim_steps, mp.get('timesteps', 1000), mp.get('linear_start', 0.00085),
+                                   mp.get('linear_end', 0.012))
+        self.S = len(self.sched.timesteps)
+        self.z_shape = tuple(z_shape)
+        self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
+        self.coef = self.sched.coef.to(self.device)
+        self._plans = {}
+
+    def _plan_for(self, uc, triples):
+        uc = uc.reshape(uc.shape[0], -1)
+        O = uc.shape[0]
+        key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
+        st = self._plans.get(key)
+        if st is None:
+            g = GraphIndex(triples, O, self.device)
+            b = Builder(self.device)
+            x = b.buf(O, *self.z_shape)
+            eps = b.buf(O, *self.z_shape)
+            step = b.buf(1, dtype=torch.int32, zero=True)
+            ucd = b.dev(uc)
+            objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:])
+            n_eps_ops = len(b.ops)
+            b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
+            plan = b.finish()
+            b2 = Builder(self.device)
+            b2.ops, b2.keep, b2.tags = b.ops[:n_eps_ops], b.keep, b.tags
+            st = dict(plan=plan, eps_plan=b2.finish(), x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1])
+            self._plans = {key: st}
+        st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
+        return st
+
+    def eps(self, x, uc, triples, iteration):
+        st = self._plan_for(uc, triples)
+        st['x'].copy_(x.to(self.device))
+        st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
+        return st['eps'].clone()
+
+    def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True):
+        """DDIM loop; ``noise1`` f32[1,C,D,H,W] is shared by all objects as in the reference
+        (echo2shape.py:507-510); None draws it on the device.  Returns latents [O,C,D,H,W]."""
+        st = self._plan_for(uc, triples)
+        O = st['x'].shape[0]
+        n_steps = self.S if n_steps is None else n_steps
+        if noise1 is None:
+            noise1 = torch.randn((1,) + self.z_shape, device=self.device)
+        st['x'].copy_(noise1.to(self.device).expand(O, *self.z_shape))
+        st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
+        return st['x'].clone()

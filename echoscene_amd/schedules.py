@@ -1,0 +1,78 @@
+"""Host-side diffusion schedules and per-step coefficient tables (tiny, computed once).
+
+These are the numbers the reference keeps in ``GaussianDiffusion`` / ``DDIMSampler``; they are
+prepared on the host in the reference's own precision order and uploaded as small device tables
+that the step plans index with the on-device step counter.
+
+  * layout: ``get_betas('linear')`` + ``GaussianDiffusion.__init__``
+    (model/networks/diffusion_layout/diffusion_ddpm.py:38-41, 133-162)
+  * shape : ``make_beta_schedule('linear')``, ``make_ddim_timesteps('uniform')``,
+    ``make_ddim_sampling_parameters`` (diffusion_shape/ldm_diffusion_util.py:43-96) and
+    ``DDIMSampler.make_schedule`` (samplers/ddim.py:28-57), eta = 0
+  * ``timestep_embedding`` (ldm_diffusion_util.py:174-194): a sinusoid table, one row per loop
+    iteration.  It is computed on the host because an ulp in the frequency is amplified by t<=999
+    (phase error ~6e-5 rad); a table is bit-identical to the reference's CPU value.
+"""
+import math
+import numpy as np
+import torch
+
+
+def timestep_embedding_table(timesteps, dim, max_period=10000):
+    t = torch.as_tensor(np.asarray(timesteps), dtype=torch.float32)
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None] * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb.contiguous()
+
+
+class LayoutSchedule:
+    """Per-iteration coefficients of the ancestral DDPM loop, iteration i <-> t = T-1-i."""
+
+    def __init__(self, time_num=1000, beta_start=1e-4, beta_end=0.02, schedule_type='linear'):
+        if schedule_type != 'linear':
+            raise NotImplementedError('layout schedule %r (shipped configs use linear)' % schedule_type)
+        self.time_num = time_num
+        betas64 = np.linspace(beta_start, beta_end, time_num).astype(np.float64)
+        alphas64 = 1.0 - betas64
+        ac = torch.from_numpy(np.cumprod(alphas64, axis=0)).float()        # cast to fp32 FIRST
+        ac_prev = torch.from_numpy(np.append(1.0, ac[:-1])).float()
+        betas = torch.from_numpy(betas64).float()
+        alphas = torch.from_numpy(alphas64).float()
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        logvar = torch.log(torch.max(post_var, 1e-20 * torch.ones_like(post_var)))
+        srac = torch.sqrt(1.0 / ac)
+        srm1 = torch.sqrt(1.0 / ac - 1)
+        c1 = betas * torch.sqrt(ac_prev) / (1.0 - ac)
+        c2 = (1.0 - ac_prev) * torch.sqrt(alphas) / (1.0 - ac)
+        sigma = torch.exp(0.5 * logvar)
+        sigma[0] = 0.0                                                       # no noise when t == 0
+        tab = torch.stack([srac, srm1, c1, c2, sigma], dim=1)               # indexed by t
+        self.timesteps = np.arange(time_num - 1, -1, -1)                     # iteration order
+        self.coef = tab[torch.from_numpy(self.timesteps.copy())].contiguous()   # [T, 5] by iteration
+
+
+class ShapeSchedule:
+    """DDIM (eta=0) coefficients, iteration i <-> index = S-1-i, timestep ts[index]."""
+
+    def __init__(self, ddim_steps=100, timesteps=1000, linear_start=0.00085, linear_end=0.012):
+        betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps,
+                                dtype=torch.float64) ** 2).numpy()
+        ac = torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)
+        c = timesteps // ddim_steps
+        ts = np.asarray(list(range(0, timesteps, c))) + 1
+        if ts.max() >= timesteps:
+            # same failure the reference hits (IndexError in make_ddim_sampling_parameters)
+            raise IndexError('ddim_steps=%d yields timestep %d >= %d' % (ddim_steps, ts.max(), timesteps))
+        a = ac[ts]
+        a_prev = torch.tensor([ac[0].item()] + ac[ts[:-1]].tolist(), dtype=torch.float32)
+        s1m = torch.sqrt(1.0 - a)
+        tab = torch.stack([s1m, a.sqrt(), a_prev.sqrt(), (1.0 - a_prev - 0.0 ** 2).sqrt()], dim=1)
+        order = np.arange(len(ts) - 1, -1, -1)
+        self.ddim_timesteps = ts
+        self.timesteps = ts[order]
+        self.coef = tab[torch.from_numpy(order.copy())].contiguous()        # [S, 4] by iteration
+        self.alphas_cumprod = ac

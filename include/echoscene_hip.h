@@ -3,7 +3,7 @@
  * The reference (ymxlzgy/echoscene) has no FFI: its hot path is Python calling ATen ops
  * (SURVEY.md section 1).  This header is therefore the boundary the *build* defines
  * (last row): the host-side mirror of model/SGDiff.py
- * (echoscene_amd/model/*.py) calls these entry points through ctypes; each entry point
+ * (echoscene_amd/model/ *.py) calls these entry points through ctypes; each entry point
  * cites the reference function(s) whose arithmetic it replaces.
  *
  * Conventions
@@ -75,6 +75,8 @@ typedef struct es_linear_args {
     int32_t act;              /* ES_ACT_*                                                      */
     const float* res;         /* residual [M, N] added AFTER the activation, or NULL           */
     int32_t res_ld;
+    const float* res2;        /* optional second residual (cross-attention-with-one-key vector) */
+    int32_t res2_ld;
     float* out;               /* [M, N]                                                        */
     int32_t out_ld;
 } es_linear_args;
@@ -132,12 +134,14 @@ typedef struct es_conv_args {
        ResBlock whose channel count changes (out = conv2(h) + skip(x), :294-314) */
     const void* a2; const void* w2; int32_t Cin2;
     const float* bias;        /* [N] (sum of both biases when a2 is used) or NULL                */
-    const float* rowvec;      /* [O, N] per-object vector broadcast over voxels (emb_layers output /
+    const float* rowvec;      /* [O, rowvec_ld] per-object vector broadcast over voxels (emb_layers output /
                                  cross-attention-with-one-key output), or NULL                   */
+    int32_t rowvec_ld;
     const float* res;         /* fp32 residual [M, N] or NULL                                    */
     float* out_f32;           /* [M, N] or NULL                                                  */
     void* out_f16;            /* [M, N] or NULL                                                  */
-    int32_t out_ld;           /* leading dimension of both outputs (>= N)                        */
+    int32_t out_ld;           /* leading dimension of both outputs and of res (>= N);
+                                 out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
 } es_conv_args;
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
 /* host helper: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16
@@ -173,11 +177,11 @@ typedef struct es_attn_args {
 } es_attn_args;
 int es_attention_f16(const es_attn_args* args, es_stream stream);       /* CrossAttention.forward self-attn, attention.py:172-219 */
 
-typedef struct es_geglu_args { const void* h_f16; int32_t M, C4; void* out_f16; } es_geglu_args;
+typedef struct es_geglu_args { const float* h_f32; int32_t M, C4; void* out_f16; } es_geglu_args;  /* h: [M, 2*C4] value|gate */
 int es_geglu_f16(const es_geglu_args* args, es_stream stream);          /* GEGLU: x * gelu(gate), attention.py:39-46 */
 
 /* NCDHW fp32 latent <-> channels-last helpers, the 3->32->64 conv-pool stem of
- * shape_messsage_passing (openai_model_3d.py:757-764) and the final 224->3 conv. */
+ * shape_messsage_passing (openai_model_3d.py:757-764). */
 int es_latent_to_cl_f16(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f16, es_stream s);
 typedef struct es_stem_args {
     const float* x;        /* [O,3,16,16,16] fp32 NCDHW                                          */
@@ -188,13 +192,7 @@ typedef struct es_stem_args {
     int32_t O;
 } es_stem_args;
 int es_shape_stem(const es_stem_args* args, es_stream stream);
-typedef struct es_convout_args {
-    const void* a_f16;     /* [O,D,H,W,Cin] f16 (already GN+SiLU)                                */
-    const float* w;        /* [Cout, 27, Cin] fp32                                               */
-    const float* bias; int32_t O, D, H, W, Cin, Cout;
-    float* out_ncdhw;      /* [O,Cout,D,H,W] fp32                                                */
-} es_convout_args;
-int es_conv_out_small(const es_convout_args* args, es_stream stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Plans: an ordered op list enqueued by the native runtime (no Python between kernels), and
@@ -202,7 +200,7 @@ int es_conv_out_small(const es_convout_args* args, es_stream stream);
  * ---------------------------------------------------------------------------------------- */
 enum {
     ES_OP_LINEAR = 1, ES_OP_DDPM = 2, ES_OP_DDIM = 3, ES_OP_COPY = 4, ES_OP_CONV = 5, ES_OP_GN = 6,
-    ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_CONVOUT = 12,
+    ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11,
     ES_OP_FORK = 13, ES_OP_JOIN = 14
 };
 typedef struct es_copy_args { void* dst; const void* src; size_t bytes; } es_copy_args;
@@ -213,7 +211,7 @@ typedef struct es_op {
     union {
         es_linear_args linear; es_update_args update; es_copy_args copy; es_conv_args conv;
         es_gn_args gn; es_ln_args ln; es_attn_args attn; es_geglu_args geglu; es_tocl_args tocl;
-        es_stem_args stem; es_convout_args convout;
+        es_stem_args stem;
     } u;
 } es_op;
 
@@ -224,6 +222,8 @@ int es_plan_num_ops(const es_plan* plan);
 int es_plan_run(es_plan* plan, es_stream stream);
 /* capture es_plan_run into a hipGraph (idempotent) */
 int es_plan_capture(es_plan* plan, es_stream stream);
+/* library-wide one-off device allocations (zero page); call once outside stream capture */
+int es_init(void);
 /* The sampling loops.  `step` is the device scalar the plan's ops read; it is set to first_step,
  * then the (captured) plan is launched n_steps times -- the plan's last update op increments it.
  *   layout: GaussianDiffusion.p_sample_loop_sg  (diffusion_ddpm.py:330-345), 1000 iterations

@@ -176,35 +176,44 @@ def cross_attention(sd, p, x, context, heads, nm=EXACT, trunk=False):
     return _linear(sd, p + '.to_out.0', out, nm, trunk)
 
 
-def transformer_block(sd, p, x, context, heads, nm=EXACT, trunk=False):
+def transformer_block(sd, p, x, context, heads, nm=EXACT, trunk=False, trace=None):
     """attention.py:237-245: self-attn, cross-attn, GEGLU feed-forward, all pre-LN residual."""
     C = x.shape[-1]
 
     def ln(i, t):
         return F.layer_norm(t, (C,), sd[f'{p}.norm{i}.weight'], sd[f'{p}.norm{i}.bias'], 1e-5)
 
+    if trace is not None:
+        trace[p + ':in'] = x
     x = cross_attention(sd, p + '.attn1', ln(1, x), None, heads, nm, trunk) + x
+    if trace is not None:
+        trace[p + ':attn1'] = x
     x = cross_attention(sd, p + '.attn2', ln(2, x), context, heads, nm, trunk) + x
+    if trace is not None:
+        trace[p + ':attn2'] = x
     h = _linear(sd, p + '.ff.net.0.proj', ln(3, x), nm, trunk)
     a, gate = h.chunk(2, dim=-1)                                   # attention.py:44-46
     h = a * F.gelu(gate)
-    return _linear(sd, p + '.ff.net.2', h, nm, trunk) + x
+    x = _linear(sd, p + '.ff.net.2', h, nm, trunk) + x
+    if trace is not None:
+        trace[p + ':ff'] = x
+    return x
 
 
-def spatial_transformer(sd, p, x, context, heads, nm=EXACT, trunk=False):
+def spatial_transformer(sd, p, x, context, heads, nm=EXACT, trunk=False, trace=None):
     """attention.py:335-351 (3-D) / :385-396 (1-D).  GroupNorm eps is 1e-6 here."""
     shp = x.shape
     h = F.group_norm(x, 32, sd[p + '.norm.weight'], sd[p + '.norm.bias'], 1e-6)
     h = _conv(sd, p + '.proj_in', h, nm, trunk, padding=0)
     B, C = h.shape[:2]
     h = h.reshape(B, C, -1).permute(0, 2, 1)
-    h = transformer_block(sd, p + '.transformer_blocks.0', h, context, heads, nm, trunk)
+    h = transformer_block(sd, p + '.transformer_blocks.0', h, context, heads, nm, trunk, trace)
     h = h.permute(0, 2, 1).reshape(B, C, *shp[2:])
     h = _conv(sd, p + '.proj_out', h, nm, trunk, padding=0)
     return h + x
 
 
-def _run_block(sd, p, h, emb, context, heads, nm, trunk):
+def _run_block(sd, p, h, emb, context, heads, nm, trunk, trace=None):
     """One TimestepEmbedSequential; sub-module kinds inferred from the keys."""
     j = 0
     while any(k.startswith(f'{p}.{j}.') for k in sd):
@@ -212,7 +221,7 @@ def _run_block(sd, p, h, emb, context, heads, nm, trunk):
         if (q + '.in_layers.0.weight') in sd:
             h = res_block(sd, q, h, emb, nm, trunk)
         elif (q + '.transformer_blocks.0.norm1.weight') in sd:
-            h = spatial_transformer(sd, q, h, context, heads, nm, trunk)
+            h = spatial_transformer(sd, q, h, context, heads, nm, trunk, trace)
         elif (q + '.op.weight') in sd:     # Downsample: stride 2 (1-D) or (1,2,2) (3-D)
             stride = 2 if sd[q + '.op.weight'].dim() == 3 else (1, 2, 2)
             h = _conv(sd, q + '.op', h, nm, trunk, stride=stride)
@@ -226,21 +235,23 @@ def _run_block(sd, p, h, emb, context, heads, nm, trunk):
             h = _conv(sd, q, h, nm, trunk)
         else:
             raise KeyError('cannot classify ' + q)
+        if trace is not None:
+            trace[q] = h
         j += 1
     return h
 
 
-def _unet_trunk(sd, h, emb, context, heads, nm, trunk):
+def _unet_trunk(sd, h, emb, context, heads, nm, trunk, trace=None):
     hs = []
     n_in = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('input_blocks.'))
     n_out = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('output_blocks.'))
     for i in range(n_in):
-        h = _run_block(sd, f'input_blocks.{i}', h, emb, context, heads, nm, trunk)
+        h = _run_block(sd, f'input_blocks.{i}', h, emb, context, heads, nm, trunk, trace)
         hs.append(h)
-    h = _run_block(sd, 'middle_block', h, emb, context, heads, nm, trunk)
+    h = _run_block(sd, 'middle_block', h, emb, context, heads, nm, trunk, trace)
     for i in range(n_out):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_block(sd, f'output_blocks.{i}', h, emb, context, heads, nm, trunk)
+        h = _run_block(sd, f'output_blocks.{i}', h, emb, context, heads, nm, trunk, trace)
     h = F.silu(F.group_norm(h, 32, sd['out.0.weight'], sd['out.0.bias'], 1e-5))
     return _conv(sd, 'out.2', h, nm, trunk)
 
@@ -248,7 +259,7 @@ def _unet_trunk(sd, h, emb, context, heads, nm, trunk):
 # --------------------------------------------------------------------------------------
 # a4/a5  UNet1DModel.forward (+ box_messsage_passing)   denoise_net.py:758-806
 # --------------------------------------------------------------------------------------
-def unet1d_forward(sd, box_t, obj_embed, triples, timesteps, heads=8, enable_t_emb=True):
+def unet1d_forward(sd, box_t, obj_embed, triples, timesteps, heads=8, enable_t_emb=True, trace=None):
     mc = sd['time_embed.0.weight'].shape[1]
     t_emb = timestep_embedding(timesteps, mc)
     emb = _linear(sd, 'time_embed.2', F.silu(_linear(sd, 'time_embed.0', t_emb)))
@@ -261,7 +272,9 @@ def unet1d_forward(sd, box_t, obj_embed, triples, timesteps, heads=8, enable_t_e
     ctx, _ = gcn_net(sd, 'box_graph_cov', obj, pred_embed, edges)
     context = ctx.unsqueeze(1)           # overwrites the caller's context (denoise_net.py:791-792)
     h = box_t.unsqueeze(1).permute(0, 2, 1)          # [O, 8, 1]
-    out = _unet_trunk(sd, h, emb, context, heads, EXACT, False)
+    if trace is not None:
+        trace.update(emb=emb, ctx=ctx, gcn_in=obj)
+    out = _unet_trunk(sd, h, emb, context, heads, EXACT, False, trace)
     return out.squeeze(-1)
 
 
@@ -278,7 +291,7 @@ def shape_stem(sd, x):
 
 
 def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
-                   enable_t_emb=True, nm=EXACT):
+                   enable_t_emb=True, nm=EXACT, trace=None):
     """sd: keys of UNet3DModel (i.e. without the 'diffusion_net.' prefix)."""
     mc = sd['time_embed.0.weight'].shape[1]
     t_emb = timestep_embedding(timesteps, mc)
@@ -291,7 +304,9 @@ def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
             obj = torch.cat([obj, _linear(sd, 'shape_time_emb', emb)], dim=1)
         ctx, _ = gcn_net(sd, 'shape_code_graph_cov', obj, sd['pred_embeddings.weight'][p], edges)
         context = ctx.unsqueeze(1)       # "we dont use the previous context" (:843-844)
-    return _unet_trunk(sd, x, emb, context, heads, nm, True)
+        if trace is not None:
+            trace.update(emb=emb, ctx=ctx, code=code)
+    return _unet_trunk(sd, x, emb, context, heads, nm, True, trace)
 
 
 # --------------------------------------------------------------------------------------

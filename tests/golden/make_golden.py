@@ -130,7 +130,7 @@ def _unet1d(model_channels, ctx_dim, time_num=1000):
 
 
 def case_unet1d_tiny():
-    net, kw = _unet1d(64, 128)
+    net, kw = _unet1d(128, 128)
     fill(net, 'unet1d_tiny.')
     objs, triples = synth.synthetic_graph(8, seed=2)
     box = rnd((8, 8), 21)
@@ -179,7 +179,7 @@ def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise):
 
 def case_layout_loop_tiny():
     """BASELINE.json configs[0]: box-only diffusion, 8-node graph, 100 DDPM steps (tiny width)."""
-    net, kw = _unet1d(64, 128)
+    net, kw = _unet1d(128, 128)
     fill(net, 'unet1d_tiny.')
     noise = synth.layout_noise(8, 8, 100, seed=7)
     oe, triples, x, _, tabs = _layout_loop(net, kw, 8, 3, 100, 100, noise)
@@ -323,7 +323,7 @@ def case_scene_e2e():
     torch.save(vq.state_dict(), vq_path)
     opt = escfg.default_diff_opt(device='cpu', time_num=100, logs_dir=tmp)
     opt.hyper.isTrain = False
-    opt.layout_branch.denoiser_kwargs = escfg.layout_denoiser_kwargs(64)
+    opt.layout_branch.denoiser_kwargs = escfg.layout_denoiser_kwargs(128)
     opt.layout_branch.denoiser_kwargs.concat_dim = 128
     opt.layout_branch.denoiser_kwargs.crossattn_dim = 128
     df = escfg.shape_df_conf(32)

@@ -1,0 +1,248 @@
+"""GPU parity tests of the "rows" path (GCN + layout denoiser), all through the C ABI.
+
+ * unit level: es_linear_rows_f32 against a plain PyTorch fp32 CPU evaluation of the same fused op
+   (tolerance 2e-5 * scale: same fp32 arithmetic, different summation order);
+ * network level: HIP vs the reference-generated golden vectors and vs the CPU oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, seeded_state_dict
+from echoscene_amd import synth, config as escfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    return torch.device('cuda')
+
+
+def _close(a, b, atol, rtol=1e-5):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert torch.isfinite(a).all()
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), 'max abs err %.3e (ref scale %.3e)' % (err, b.abs().max().item())
+
+
+def _run_linear(dev, segs_cpu, W, b, M, prologue=0, gamma=None, beta=None, eps=0.0, act=0, res=None, res2=None):
+    """segs_cpu: list of dicts(src=tensor, mode, idx, ent_row, ent_off, width, col)."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg
+    bld = Builder(dev)
+    pl = PackedLinear(W, b, dev)
+    segs = []
+    for s in segs_cpu:
+        t = bld.dev(s['src'])
+        v = View(t, col=s.get('col', 0), ld=s.get('ld', None), width=s['width'])
+        mk = lambda a: None if a is None else bld.dev(a, torch.int32)
+        segs.append(seg(v, s.get('mode', 0), idx=mk(s.get('idx')), ent_row=mk(s.get('ent_row')),
+                        ent_off=mk(s.get('ent_off'))))
+    out = bld.buf(M, pl.N, zero=True)
+    g = None if gamma is None else bld.dev(gamma)
+    be = None if beta is None else bld.dev(beta)
+    r1 = None if res is None else View(bld.dev(res))
+    r2 = None if res2 is None else View(bld.dev(res2))
+    bld.linear(segs, pl, M, View(out), prologue=prologue, gamma=g, beta=be, eps=eps, act=act, res=r1, res2=r2)
+    plan = bld.finish()
+    plan.run()
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize('M,K,N', [(5, 8, 8), (32, 512, 512), (32, 2048, 96), (124, 1664, 256), (33, 640, 24)])
+def test_linear_plain(dev, M, K, N):
+    rs = np.random.RandomState(M * 7 + N)
+    X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32))
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(N).astype(np.float32))
+    R = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32))
+    out = _run_linear(dev, [dict(src=X, width=K)], W, b, M, act=1, res=R)
+    _close(out, F.relu(F.linear(X, W, b)) + R, 2e-5)
+
+
+def test_linear_prologues(dev):
+    from echoscene_amd import hip
+    rs = np.random.RandomState(3)
+    M, K, N = 32, 512, 64
+    X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)) * 1.7 + 0.3
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(N).astype(np.float32))
+    ga = torch.from_numpy(1 + 0.1 * rs.standard_normal(K).astype(np.float32))
+    be = torch.from_numpy(0.1 * rs.standard_normal(K).astype(np.float32))
+    gn = lambda eps: F.group_norm(X.unsqueeze(-1), 32, ga, be, eps).squeeze(-1)
+    _close(_run_linear(dev, [dict(src=X, width=K)], W, b, M, hip.PRO_GN_SILU, ga, be, 1e-5),
+           F.linear(F.silu(gn(1e-5)), W, b), 2e-5)
+    _close(_run_linear(dev, [dict(src=X, width=K)], W, b, M, hip.PRO_GN, ga, be, 1e-6, act=hip.ACT_SILU),
+           F.silu(F.linear(gn(1e-6), W, b)), 2e-5)
+    _close(_run_linear(dev, [dict(src=X, width=K)], W, b, M, hip.PRO_LN, ga, be, 1e-5),
+           F.linear(F.layer_norm(X, (K,), ga, be, 1e-5), W, b), 2e-5)
+    _close(_run_linear(dev, [dict(src=X, width=K)], W, b, M, hip.PRO_SILU), F.linear(F.silu(X), W, b), 2e-5)
+    # GEGLU: source holds [value | gate]
+    X2 = torch.from_numpy(rs.standard_normal((M, 2 * K)).astype(np.float32))
+    a, g = X2.chunk(2, dim=-1)
+    R2 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32))
+    _close(_run_linear(dev, [dict(src=X2, width=K, ld=2 * K)], W, b, M, hip.PRO_GEGLU, res=R2, res2=R2),
+           F.linear(a * F.gelu(g), W, b) + 2 * R2, 2e-5)
+    # concat of two sources under one GroupNorm (skip connections of the output blocks)
+    Xa, Xb = X[:, :256].contiguous(), X[:, 256:].contiguous()
+    _close(_run_linear(dev, [dict(src=Xa, width=256), dict(src=Xb, width=256)], W, b, M, hip.PRO_GN_SILU, ga, be, 1e-5),
+           F.linear(F.silu(gn(1e-5)), W, b), 2e-5)
+
+
+def test_linear_gather_and_csr_mean(dev):
+    from echoscene_amd import hip
+    rs = np.random.RandomState(5)
+    O, T, D, Dp, H = 9, 31, 48, 16, 32
+    obj = torch.from_numpy(rs.standard_normal((O, D)).astype(np.float32))
+    pred = torch.from_numpy(rs.standard_normal((T, Dp)).astype(np.float32))
+    s = torch.from_numpy(rs.randint(0, O - 1, T)).long()          # node O-1 appears in no triple
+    o = torch.from_numpy(rs.randint(0, O - 1, T)).long()
+    K = 2 * D + Dp
+    W = torch.from_numpy((rs.standard_normal((H, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.zeros(H)
+    out = _run_linear(dev, [dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=s), dict(src=pred, width=Dp),
+                            dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=o)], W, b, T)
+    _close(out, F.linear(torch.cat([obj[s], pred, obj[o]], 1), W, b), 2e-5)
+    # CSR mean == scatter_add/avg of graph.py:172-199
+    msg = torch.from_numpy(rs.standard_normal((T, 2 * H + Dp)).astype(np.float32))
+    pooled = torch.zeros(O, H).index_add_(0, s, msg[:, :H]).index_add_(0, o, msg[:, H + Dp:])
+    cnt = torch.zeros(O).index_add_(0, s, torch.ones(T)).index_add_(0, o, torch.ones(T)).clamp(min=1)
+    pooled = pooled / cnt[:, None]
+    rows, offs, ptr = [], [], [0]
+    for n in range(O):
+        ts, to = (s == n).nonzero().flatten().tolist(), (o == n).nonzero().flatten().tolist()
+        rows += ts + to
+        offs += [0] * len(ts) + [H + Dp] * len(to)
+        ptr.append(len(rows))
+    W2 = torch.from_numpy((rs.standard_normal((24, H)) / np.sqrt(H)).astype(np.float32))
+    out = _run_linear(dev, [dict(src=msg, width=H, ld=2 * H + Dp, mode=hip.SEG_CSRMEAN, idx=torch.tensor(ptr),
+                                 ent_row=torch.tensor(rows), ent_off=torch.tensor(offs))], W2, None, O)
+    _close(out, F.linear(pooled, W2), 2e-5)
+    assert out[O - 1].abs().max() == 0          # isolated node pools to exactly zero
+
+
+def test_bad_args_raise(dev):
+    from echoscene_amd import hip
+    X = torch.zeros(4, 6)
+    with pytest.raises(RuntimeError, match='multiples of 4'):
+        _run_linear(dev, [dict(src=X, width=6)], torch.zeros(8, 6), None, 4)
+
+
+@pytest.mark.parametrize('tag', ['res_bn', 'plain'])
+def test_gcn_vs_reference_golden(dev, tag):
+    from echoscene_amd.model.graph import GraphTripleConvNet
+    from echoscene_amd.samplers import gcn_forward
+    g = load_golden('gcn_' + tag)
+    din, dp, nl, H, res, bn, dout = [int(v) for v in g['cfg']]
+    net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res),
+                             mlp_normalization='batch' if bn else 'none', output_dim=dout)
+    sd = {'n.' + k: v for k, v in seeded_state_dict(net, 'gcn_%s.' % tag).items()}
+    o, p = gcn_forward(sd, 'n', g['obj'], g['pred'], g['triples'], dev)
+    _close(o, g['out_obj'], 3e-5)
+    _close(p, g['out_pred'], 3e-5)
+
+
+def _layout(dev, mc, ctx, prefix, time_num):
+    from echoscene_amd.model.unet import UNet1DModel
+    from echoscene_amd.samplers import LayoutDenoiser
+    kw = dict(escfg.layout_denoiser_kwargs(mc))
+    kw['concat_dim'] = kw['crossattn_dim'] = ctx
+    net = UNet1DModel(**kw)
+    synth.seeded_fill_(net, prefix=prefix)
+    return LayoutDenoiser(net, escfg.layout_diffusion_kwargs(time_num), dev)
+
+
+def test_unet1d_tiny_eps_vs_reference_golden(dev):
+    g = load_golden('unet1d_tiny')
+    den = _layout(dev, 128, 128, 'unet1d_tiny.', 1000)
+    t = int(g['t'][0])
+    eps = den.eps(g['box'], g['obj_embed'], g['triples'], iteration=999 - t)
+    _close(eps, g['eps'], 5e-5)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_layout_loop_tiny_100_steps_vs_reference_golden(dev, use_graph):
+    """BASELINE.json configs[0] on the HIP path: 8 nodes, 100 DDPM steps, injected noise."""
+    g = load_golden('layout_loop_tiny')
+    den = _layout(dev, 128, 128, 'unet1d_tiny.', 100)
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    x = den.sample(g['obj_embed'], g['triples'], noise, use_graph=use_graph)
+    _close(x, g['x_final'], 2e-4)
+    x2 = den.sample(g['obj_embed'], g['triples'], noise, use_graph=use_graph)
+    assert torch.equal(x, x2), 'sampling must be deterministic for fixed noise'
+
+
+def test_unet1d_full_vs_reference_golden(dev):
+    """Full-width layout denoiser (config/full_mp.yaml) at O=8 and O=32 (BASELINE configs[1] size)."""
+    g = load_golden('unet1d_full')
+    den = _layout(dev, 512, 1280, 'unet1d_full.', 1000)
+    for O in (8, 32):
+        eps = den.eps(g['box%d' % O], g['obj_embed%d' % O], g['triples%d' % O], iteration=999 - 617)
+        _close(eps, g['eps%d' % O], 1e-4)
+    noise = synth.layout_noise(8, 8, 1000, seed=7)[:11]
+    x = den.sample(g['loop_obj_embed'], g['loop_triples'], noise, n_steps=10)
+    _close(x, g['loop_x10'], 2e-4)
+
+
+def test_unet1d_tiny_blockwise_vs_oracle(dev):
+    """Every intermediate of the tiny layout denoiser (time MLP, GCN context, each ResBlock /
+    transformer / resample output) against the CPU oracle -- localises any mismatch."""
+    from oracle import echoscene_oracle as orc
+    g = load_golden('unet1d_tiny')
+    den = _layout(dev, 128, 128, 'unet1d_tiny.', 1000)
+    t = int(g['t'][0])
+    den.eps(g['box'], g['obj_embed'], g['triples'], iteration=999 - t)
+    st = next(iter(den._plans.values()))
+    trace = {}
+    sd = {k: v.detach().cpu() for k, v in den.net.state_dict().items()}
+    orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'], trace=trace)
+    bad = []
+    for name, v in st['eps_plan'].tags.items():
+        ref = trace[name]
+        ref = ref.reshape(ref.shape[0], -1)
+        got = v.t[:, v.col:v.col + v.width].cpu()
+        err = (got - ref).abs().max().item()
+        if not err < 1e-4 * max(1.0, ref.abs().max().item()):
+            bad.append((name, '%.2e' % err, 'rows', (got - ref).abs().max(1).values.gt(1e-4).nonzero().flatten().tolist()))
+    assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize('K,pro', [(64, 'gn'), (128, 'gn'), (64, 'ln'), (96, 'ln'), (1024, 'gn')])
+def test_linear_narrow_norms(dev, K, pro):
+    from echoscene_amd import hip
+    rs = np.random.RandomState(K)
+    M, N = 8, 40
+    X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)) * 2 - 0.5
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    ga = torch.from_numpy(1 + 0.1 * rs.standard_normal(K).astype(np.float32))
+    be = torch.from_numpy(0.1 * rs.standard_normal(K).astype(np.float32))
+    if pro == 'gn':
+        ref = F.linear(F.silu(F.group_norm(X.unsqueeze(-1), 32, ga, be, 1e-5).squeeze(-1)), W)
+        out = _run_linear(dev, [dict(src=X, width=K)], W, None, M, hip.PRO_GN_SILU, ga, be, 1e-5)
+    else:
+        ref = F.linear(F.layer_norm(X, (K,), ga, be, 1e-5), W)
+        out = _run_linear(dev, [dict(src=X, width=K)], W, None, M, hip.PRO_LN, ga, be, 1e-5)
+    _close(out, ref, 2e-5)
+
+
+def test_linear_multisegment_multichunk(dev):
+    """gather | direct | gather with K > 1024 (the GCN's first layer at full width: K = 1664)."""
+    from echoscene_amd import hip
+    rs = np.random.RandomState(9)
+    O, T, D, Dp, H = 8, 29, 768, 128, 256
+    obj = torch.from_numpy(rs.standard_normal((O, D)).astype(np.float32))
+    pred = torch.from_numpy(rs.standard_normal((T, Dp)).astype(np.float32))
+    s = torch.from_numpy(rs.randint(0, O, T)).long()
+    o = torch.from_numpy(rs.randint(0, O, T)).long()
+    K = 2 * D + Dp
+    W = torch.from_numpy((rs.standard_normal((H, K)) / np.sqrt(K)).astype(np.float32))
+    out = _run_linear(dev, [dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=s), dict(src=pred, width=Dp),
+                            dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=o)], W, None, T, act=hip.ACT_RELU)
+    _close(out, F.relu(F.linear(torch.cat([obj[s], pred, obj[o]], 1), W)), 2e-5)

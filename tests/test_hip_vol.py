@@ -1,0 +1,252 @@
+"""GPU parity tests of the "volume" path (3-D latent-SDF denoiser), all through the C ABI.
+
+Numerics contract of the path: fp16 MFMA operands, fp32 accumulation, fp32 residual
+stream and statistics.  Two references are used:
+  * an fp16-operand emulation (PyTorch CPU fp32 ops on operands rounded to fp16, or the oracle with
+    ``Numerics(torch.float16)``) -- differs from the kernels only in summation order / online softmax
+    -> tight tolerance (1e-3 relative to the tensor scale);
+  * the exact fp32 oracle / the reference-generated golden vectors -> the stated precision of the
+    fp16 path: 2e-2 relative to the tensor scale (measured values are printed with -s).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, seeded_state_dict
+from echoscene_amd import synth, config as escfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda')
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-6)).item()
+
+
+def _rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _cl(x):          # NCDHW -> [O*V, C]
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _ncdhw(y, O, D, H, W):
+    return y.reshape(O, D, H, W, -1).permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize('mode,N,Cin,dims', [('same', 40, 32, (4, 8, 8)), ('same', 224, 64, (4, 8, 8)),
+                                              ('same', 250, 96, (2, 4, 4)), ('down', 48, 64, (4, 4, 4)),
+                                              ('up', 48, 32, (4, 8, 8)), ('lin', 300, 64, (4, 4, 4))])
+def test_conv_mfma(dev, mode, N, Cin, dims):
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    O = 3
+    D, H, W = dims
+    taps = 1 if mode == 'lin' else 27
+    idims = dict(same=dims, lin=dims, down=(D, 2 * H, 2 * W), up=(D, H // 2, W // 2))[mode]
+    x = _rnd((O, Cin) + idims, 1).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3) if taps == 27 else (N, Cin), 2) / np.sqrt(Cin * taps)).half().float()
+    bias = _rnd((N,), 3)
+    rowv = _rnd((O, N), 4)
+    res = _rnd((O * D * H * W, N), 5)
+    if mode == 'same':
+        ref = F.conv3d(x, wt, bias, padding=1)
+    elif mode == 'down':
+        ref = F.conv3d(x, wt, bias, stride=(1, 2, 2), padding=1)
+    elif mode == 'up':
+        ref = F.conv3d(F.interpolate(x, (D, H, W), mode='nearest'), wt, bias, padding=1)
+    else:
+        ref = F.conv3d(x, wt[:, :, None, None, None], bias)
+    ref = _cl(ref) + rowv.repeat_interleave(D * H * W, 0) + res
+    b = Builder(dev)
+    pc = PackedConv(wt, bias, dev)
+    a16 = b.dev(_cl(x), torch.float16)
+    out = b.buf(O * D * H * W, N, zero=True)
+    out16 = b.buf(O * D * H * W, N, dtype=torch.float16, zero=True)
+    b.conv(a16, pc, O, dims, mode=dict(same=0, lin=0, down=1, up=2)[mode], rowvec=View(b.dev(rowv)),
+           res=b.dev(res), out_f32=out, out_f16=out16)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-4
+    assert _rel(out16, ref) < 2e-3
+
+
+def test_conv_fused_skip_and_ncdhw(dev):
+    from echoscene_amd.plan import Builder
+    from echoscene_amd.plan_vol import PackedConv
+    O, dims, Cin, Cs, N = 2, (4, 4, 4), 64, 96, 72
+    D, H, W = dims
+    x = _rnd((O, Cin) + dims, 1).half().float()
+    xs = _rnd((O, Cs) + dims, 2).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3), 3) / np.sqrt(Cin * 27)).half().float()
+    ws = (_rnd((N, Cs), 4) / np.sqrt(Cs)).half().float()
+    bias = _rnd((N,), 5)
+    ref = _cl(F.conv3d(x, wt, bias, padding=1) + F.conv3d(xs, ws[:, :, None, None, None]))
+    b = Builder(dev)
+    out = b.buf(O * D * H * W, N, zero=True)
+    b.conv(b.dev(_cl(x), torch.float16), PackedConv(wt, bias, dev), O, dims,
+           skip=(b.dev(_cl(xs), torch.float16), PackedConv(ws, None, dev)), out_f32=out)
+    # final-conv form: 3 output channels written as NCDHW
+    w3 = (_rnd((3, Cin, 3, 3, 3), 6) / np.sqrt(Cin * 27)).half().float()
+    out3 = b.buf(O, 3, D, H, W, zero=True)
+    b.conv(b.dev(_cl(x), torch.float16), PackedConv(w3, None, dev), O, dims, out_f32=out3, ncdhw=True)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-4
+    assert _rel(out3, F.conv3d(x, w3, None, padding=1)) < 1e-4
+
+
+def test_groupnorm_layernorm_geglu_tocl(dev):
+    from echoscene_amd.plan import Builder
+    O, C1, C2, dims = 3, 64, 32, (4, 4, 8)
+    V = dims[0] * dims[1] * dims[2]
+    x1, x2 = _rnd((O, C1) + dims, 1) * 2 + 0.5, _rnd((O, C2) + dims, 2)
+    ga, be = 1 + 0.1 * _rnd((C1 + C2,), 3), 0.1 * _rnd((C1 + C2,), 4)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), 32, ga, be, 1e-5))
+    b = Builder(dev)
+    y = b.buf(O * V, C1 + C2, dtype=torch.float16, zero=True)
+    raw = b.buf(O * V, C1 + C2, dtype=torch.float16, zero=True)
+    b.groupnorm(b.dev(_cl(x1)), C1, b.dev(_cl(x2)), C2, O, V, b.dev(ga), b.dev(be), 1e-5, True, y, raw)
+    y1 = b.buf(O * V, C1, dtype=torch.float16, zero=True)
+    b.groupnorm(b.dev(_cl(x1)), C1, None, 0, O, V, b.dev(ga[:C1]), b.dev(be[:C1]), 1e-6, False, y1)
+    M, Cc = 50, 96
+    t = _rnd((M, Cc), 5) * 3 - 1
+    yl = b.buf(M, Cc, dtype=torch.float16, zero=True)
+    b.layernorm(b.dev(t), M, Cc, b.dev(ga), b.dev(be), yl)
+    hg = _rnd((M, 2 * 64), 6)
+    yg = b.buf(M, 64, dtype=torch.float16, zero=True)
+    b.geglu(b.dev(hg), M, 64, yg)
+    xin = _rnd((O, 3) + dims, 7)
+    xcl = b.buf(O * V, 32, dtype=torch.float16)
+    b.to_cl(b.dev(xin), O, 3, V, 32, xcl)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(y, _cl(ref)) < 2e-3
+    assert _rel(raw, _cl(torch.cat([x1, x2], 1))) < 1e-3
+    assert _rel(y1, _cl(F.group_norm(x1, 32, ga[:C1], be[:C1], 1e-6))) < 2e-3
+    assert _rel(yl, F.layer_norm(t, (Cc,), ga, be, 1e-5)) < 2e-3
+    a_, g_ = hg.chunk(2, -1)
+    assert _rel(yg, a_ * F.gelu(g_)) < 2e-3
+    assert _rel(xcl[:, :3], _cl(xin)) < 1e-3 and xcl[:, 3:].abs().max() == 0
+
+
+@pytest.mark.parametrize('Ntok,heads,dh', [(256, 8, 12), (1024, 2, 56), (256, 2, 84), (100, 3, 8)])
+def test_attention(dev, Ntok, heads, dh):
+    from echoscene_amd.plan import Builder
+    B, Cc = 2, heads * dh
+    qkv = (_rnd((B, Ntok, 3 * Cc), 1) * 1.5).half()
+    q, k, v = qkv.float().chunk(3, -1)
+    sp = lambda t: t.reshape(B, Ntok, heads, dh).permute(0, 2, 1, 3)
+    att = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * dh ** -0.5, -1) @ sp(v)
+    ref = att.permute(0, 2, 1, 3).reshape(B * Ntok, Cc)
+    b = Builder(dev)
+    out = b.buf(B * Ntok, Cc, dtype=torch.float16, zero=True)
+    b.attention(b.dev(qkv.reshape(B * Ntok, 3 * Cc), torch.float16), B, Ntok, heads, dh, out)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 3e-3
+
+
+def test_shape_stem(dev):
+    from echoscene_amd.plan import Builder
+    from oracle import echoscene_oracle as orc
+    O = 3
+    x = _rnd((O, 3, 16, 16, 16), 1)
+    sd = {'shape_embeddings.0.weight': _rnd((32, 3, 3, 3, 3), 2) / 9, 'shape_embeddings.0.bias': _rnd((32,), 3),
+          'shape_embeddings.2.weight': _rnd((64, 32, 3, 3, 3), 4) / 29, 'shape_embeddings.2.bias': _rnd((64,), 5),
+          'shape_embeddings.5.weight': torch.eye(512), 'shape_embeddings.5.bias': torch.zeros(512)}
+    ref = orc.shape_stem(sd, x)
+    b = Builder(dev)
+    out = b.buf(O, 512, zero=True)
+    b.stem(b.dev(x), [b.dev(sd['shape_embeddings.%d.%s' % (i, n)]) for i in (0, 2) for n in ('weight', 'bias')],
+           b.buf(O, 32 * 512), out, O)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-5
+
+
+def _shape(dev, mc, ctx, prefix, S):
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    p = escfg.shape_unet_params(mc)
+    p['context_dim'] = ctx
+    df = DiffusionUNet(p)
+    synth.seeded_fill_(df, prefix=prefix)
+    return ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=S, device=dev)
+
+
+def _unet3d_sd(den):
+    return {k[len('diffusion_net.'):]: v.detach().cpu() for k, v in den.df.state_dict().items()}
+
+
+def test_unet3d_tiny_blockwise_vs_oracle(dev):
+    """Every block output of the tiny 3-D denoiser against the fp16-operand oracle."""
+    from oracle import echoscene_oracle as orc
+    g = load_golden('unet3d_tiny')
+    den = _shape(dev, 32, 64, 'unet3d_tiny.', 100)
+    t = int(g['t'][0])
+    it = int(np.nonzero(den.sched.timesteps == t)[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it)
+    st = next(iter(den._plans.values()))
+    trace = {}
+    ref = orc.unet3d_forward(_unet3d_sd(den), g['x'], g['uc_s'], g['triples'], g['t'],
+                             nm=orc.Numerics(torch.float16), trace=trace)
+    bad = []
+    for name, v in st['eps_plan'].tags.items():
+        if name not in trace:
+            continue
+        r = trace[name]
+        if r.dim() == 5:
+            r = r.permute(0, 2, 3, 4, 1).reshape(-1, r.shape[1])
+        elif r.dim() == 3:
+            r = r.reshape(-1, r.shape[-1])
+        got = v.t.reshape(-1, v.t.shape[-1])[:, v.col:v.col + v.width]
+        e = _rel(got, r)
+        if not e < 2e-3:
+            bad.append((name, '%.2e' % e))
+    assert not bad, bad[:8]
+    assert _rel(eps, ref) < 2e-3
+
+
+def test_unet3d_tiny_eps_vs_reference_golden(dev):
+    g = load_golden('unet3d_tiny')
+    den = _shape(dev, 32, 64, 'unet3d_tiny.', 100)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it)
+    e = _rel(eps, g['eps'])
+    print('unet3d tiny: fp16-MFMA eps vs fp32 reference golden: rel err %.3e' % e)
+    assert e < 2e-2
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_ddim_tiny_loop_vs_reference_golden(dev, use_graph):
+    g = load_golden('ddim_tiny')
+    den = _shape(dev, 32, 64, 'unet3d_tiny.', 4)
+    z = den.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), use_graph=use_graph)
+    e = _rel(z, g['z_final'])
+    print('ddim tiny (4 steps): latent vs fp32 reference golden: rel err %.3e' % e)
+    assert e < 2e-2
+    z2 = den.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), use_graph=use_graph)
+    assert torch.equal(z, z2)
+
+
+def test_unet3d_full_eps_vs_reference_golden(dev):
+    """Full-width shape denoiser (config/sdfusion-txt2shape_mp.yaml), O=2."""
+    g = load_golden('unet3d_full')
+    den = _shape(dev, 224, 1280, 'unet3d_full.', 100)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it)
+    e = _rel(eps, g['eps'])
+    print('unet3d full: fp16-MFMA eps vs fp32 reference golden: rel err %.3e' % e)
+    assert e < 2e-2

@@ -46,7 +46,7 @@ def _unet1d_sd(mc, ctx, prefix):
 
 def test_unet1d_tiny():
     g = load_golden('unet1d_tiny')
-    sd = _unet1d_sd(64, 128, 'unet1d_tiny.')
+    sd = _unet1d_sd(128, 128, 'unet1d_tiny.')
     eps = orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'])
     _close(eps, g['eps'], 2e-5)
 
@@ -65,7 +65,7 @@ def test_ddpm_tables_bit_exact():
 def test_layout_loop_tiny_100_steps():
     """BASELINE.json configs[0]: 8-node graph, 100 DDPM steps, injected noise."""
     g = load_golden('layout_loop_tiny')
-    sd = _unet1d_sd(64, 128, 'unet1d_tiny.')
+    sd = _unet1d_sd(128, 128, 'unet1d_tiny.')
     noise = synth.layout_noise(8, 8, 100, seed=7)
     x = orc.layout_sample_loop(sd, g['obj_embed'], g['triples'], noise, time_num=100)
     _close(x, g['x_final'], 1e-4)
