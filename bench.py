@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 
 
 def build_layout(dev, O, seed):
@@ -37,6 +38,30 @@ def build_layout(dev, O, seed):
     rs = torch.Generator().manual_seed(seed)
     obj_embed = torch.randn(O, 640, generator=rs)
     return net, den, obj_embed, triples
+
+
+def build_shape(dev, O, seed, triples):
+    from echoscene_amd import synth, config as escfg
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    conf = escfg.shape_df_conf(224)
+    df = DiffusionUNet(conf.unet.params, conditioning_key='crossattn')
+    synth.seeded_fill_(df, prefix='bench.shape.')
+    den = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev)
+    uc = torch.randn(O, 1, 1280, generator=torch.Generator().manual_seed(seed + 1))
+    return df, den, uc
+
+
+def cpu_baseline_shape(df, uc, triples, O_sample):
+    """One DDIM step of the CPU oracle on the first O_sample objects (cost is linear in objects)."""
+    from oracle import echoscene_oracle as orc
+    from echoscene_amd import synth
+    sd = {k[len('diffusion_net.'):]: v.detach() for k, v in df.state_dict().items()}
+    keep = (triples[:, 0] < O_sample) & (triples[:, 2] < O_sample)
+    tri = triples[keep]
+    t0 = time.perf_counter()
+    orc.shape_sample_loop(sd, uc[:O_sample], tri, synth.shape_noise(seed=7), S=100, n_steps=1)
+    return time.perf_counter() - t0
 
 
 def cpu_baseline_layout(net, obj_embed, triples, O, budget_s=15.0):
@@ -60,10 +85,10 @@ def cpu_baseline_layout(net, obj_embed, triples, O, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1000)
-    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--nodes', type=int, default=32)
-    ap.add_argument('--workload', default='layout', choices=['layout'])
+    ap.add_argument('--workload', default='full', choices=['full', 'layout'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     a = ap.parse_args()
@@ -79,62 +104,106 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     O = a.nodes
+    full = a.workload == 'full'
     net, den, obj_embed, triples = build_layout(dev, O, seed=100 + rank)
     use_graph = not a.no_graph
-    # untimed warm-up (also builds the plan and captures the graph)
+    # untimed warm-up (also builds the plans and captures the graphs)
     den.sample(obj_embed, triples, noise=None, n_steps=max(a.warmup, 1), use_graph=use_graph)
     st = next(iter(den._plans.values()))
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
+    if full:
+        df, sden, uc = build_shape(dev, O, 100 + rank, triples)
+        sden.sample(uc, triples, noise1=None, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
+        ss = next(iter(sden._plans.values()))
+        ss['x'].normal_()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t0 = time.perf_counter()
-    ev0.record()
+    ev[0].record()
     done = 0
-    while done < a.steps:                       # the loop is 1000 iterations long; K may exceed it
+    while done < a.steps:                       # the layout loop is 1000 iterations long; K may exceed it
         n = min(a.steps - done, den.T)
         st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
         done += n
-    ev1.record()
+    ev[1].record()
+    done = 0
+    while full and done < a.steps:              # the DDIM loop is 100 iterations long
+        n = min(a.steps - done, sden.S)
+        ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
+        done += n
+    ev[2].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    lay_ms, shp_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
     tmax = torch.tensor([wall], device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     assert torch.isfinite(st['x']).all(), 'non-finite layout state'
+    if full:
+        assert torch.isfinite(ss['x']).all(), 'non-finite shape latent'
 
     if rank == 0:
         ms_per_step = wall * 1e3 / a.steps
         value = world * a.steps / wall
-        n_launch = st['plan'].n_ops
-        wbytes = st['plan'].weight_bytes
-        ach = wbytes / (dev_ms * 1e-3 / a.steps) / 1e9
-        out = {
-            'metric': 'denoising steps/sec (layout box-denoiser loop, 32-node scene graph, 1000-step DDPM)',
-            'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: EchoLayout box diffusion, %d-node synthetic graph (T=%d triples), '
-                                   '1000-step DDPM, HIP denoiser + graph conv' % (O, triples.shape[0]),
-                       'scenes_per_gpu': 1, 'hip_graph': use_graph, 'kernels_per_step': n_launch},
-            'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'kernel': 'k_linear_rows', 'algorithmic_bytes_per_step': wbytes,
-                         'launches_per_step': n_launch,
-                         'avg_launch_us_incl_gaps': round(dev_ms * 1e3 / a.steps / n_launch, 3)},
-        }
+        T = int(triples.shape[0])
+        lay = {'steps_per_s': round(a.steps / (lay_ms * 1e-3), 2), 'ms_per_step': round(lay_ms / a.steps, 4),
+               'kernels_per_step': st['plan'].n_ops, 'weight_bytes_per_step': st['plan'].weight_bytes,
+               'hbm_GBps_algorithmic': round(st['plan'].weight_bytes / (lay_ms * 1e-3 / a.steps) / 1e9, 1)}
+        if full:
+            flops = ss['plan'].flops
+            ach = flops / (shp_ms * 1e-3 / a.steps) / 1e12
+            out = {
+                'metric': 'denoising steps/sec (layout+SDF) for 32-node scene-graph, 64^3 SDF (3x16^3 latent), '
+                          'full step = one DDPM layout step + one DDIM shape step over all objects',
+                'value': round(value, 4), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f16 MFMA operands / f32 accumulate (shape UNet); f32 (layout, GCN)',
+                'data': 'synthetic',
+                'config': {'workload': 'EchoScene full (layout+SDF) %d-node synthetic graph (T=%d), 3x16^3 latent -> '
+                                       '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules, 1 scene per GPU'
+                                       % (O, T), 'hip_graph': use_graph, 'layout': lay,
+                           'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
+                                     'ms_per_step': round(shp_ms / a.steps, 3),
+                                     'kernels_per_step': ss['plan'].n_ops,
+                                     'algorithmic_TFLOP_per_step': round(flops / 1e12, 3)}},
+                'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'k_conv_mfma',
+                             'note': 'algorithmic FLOPs of one shape step / measured shape-step time (all kernels)'},
+            }
+        else:
+            ach = lay['hbm_GBps_algorithmic']
+            out = {
+                'metric': 'denoising steps/sec (layout box-denoiser loop, 32-node scene graph, 1000-step DDPM)',
+                'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'configs[1]: EchoLayout box diffusion, %d-node synthetic graph (T=%d triples), '
+                                       '1000-step DDPM, HIP denoiser + graph conv' % (O, T),
+                           'scenes_per_gpu': 1, 'hip_graph': use_graph, 'layout': lay},
+                'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'k_linear_rows'},
+            }
         if world == 1 and not a.no_cpu_baseline:
-            v, n = cpu_baseline_layout(net, obj_embed, triples, O)
-            out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
-                                   'kind': 'port', 'sample': '%d layout denoising steps of the same %d-node graph '
-                                   '(torch-CPU oracle, fp32)' % (n, O)}
+            v, n = cpu_baseline_layout(net, obj_embed, triples, O, budget_s=8.0 if full else 15.0)
+            if full:
+                Os = 4
+                ts = cpu_baseline_shape(df, uc, triples, Os)
+                t_full = 1.0 / v + ts * (O / Os)
+                out['cpu_baseline'] = {'value': round(1.0 / t_full, 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                                       'kind': 'port', 'sample': '%d layout steps at O=%d (%.1f steps/s) + 1 DDIM shape step on '
+                                       '%d of the %d objects (%.2f s, scaled x%d: cost is linear in objects); torch-CPU oracle fp32'
+                                       % (n, O, v, Os, O, ts, O // Os)}
+            else:
+                out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                                       'kind': 'port', 'sample': '%d layout denoising steps of the same %d-node graph '
+                                       '(torch-CPU oracle, fp32)' % (n, O)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

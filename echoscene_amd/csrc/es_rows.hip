@@ -33,50 +33,81 @@ __device__ __forceinline__ const float* seg_base(const es_seg& s) {
     return p;
 }
 
-// raw load of 4 consecutive virtual columns [k, k+4) of row m of the concatenated A operand
-// (v = value, g = GEGLU gate).  Kept free of arithmetic so that the staging loop can keep several
-// of these loads in flight before the first use.
-__device__ __forceinline__ void load_a4_raw(const es_linear_args& a, int m, int k, f4& v, f4& g) {
-    v = f4{0.f, 0.f, 0.f, 0.f};
-    g = v;
-    if (m >= a.M || k >= a.K) return;
-    int c = k;
-    int si = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if (si == s && s + 1 < a.nseg && c >= a.seg[s].width) { c -= a.seg[s].width; si = s + 1; }
-    }
-    const es_seg& sg = a.seg[si];
-    const float* base = seg_base(sg);
-    if (sg.mode == ES_SEG_DIRECT) {
-        const float* p = base + (long)m * sg.ld + c;
-        v = *(const f4*)p;
-        if (a.prologue == ES_PRO_GEGLU) g = *(const f4*)(p + a.K);
-    } else if (sg.mode == ES_SEG_GATHER) {
-        v = *(const f4*)(base + (long)sg.idx[m] * sg.ld + c);
-    } else {  // CSR mean: sum entries in stored order (== scatter_add order of the reference), / max(cnt,1)
-        const int e0 = sg.idx[m], e1 = sg.idx[m + 1];
-        for (int e = e0; e < e1; ++e) {
-            f4 t = *(const f4*)(base + (long)sg.ent_row[e] * sg.ld + sg.ent_off[e] + c);
-            v += t;
-        }
-        const float cnt = (float)max(e1 - e0, 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] / cnt;
-    }
-}
-
-__device__ __forceinline__ f4 post_a4(const es_linear_args& a, f4 v, f4 g) {
-    if (a.prologue == ES_PRO_GEGLU) {
+// Staging of one K chunk of the (virtually concatenated) A operand into LDS.
+// Thread mapping: row r = tid >> 4 (32 rows), column lane cl = tid & 15; a thread walks its row in
+// steps of 16 float4 -> 16 consecutive lanes read 256 contiguous bytes, no integer division, and the
+// segment loop / mode switch are wave-uniform (scalar branches only).  Loads are unconditional
+// (row index clamped, result masked) so that 8 of them are in flight per thread before first use.
+template <int PRO>
+__device__ __forceinline__ f4 post_a4(f4 v, f4 g) {
+    if (PRO == ES_PRO_GEGLU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * es_gelu(g[e]);
-    } else if (a.prologue == ES_PRO_SILU) {
+    } else if (PRO == ES_PRO_SILU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = es_silu(v[e]);
     }
     return v;
 }
 
+template <int PRO>
+__device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, int m0, int kc0, int kc, int tid) {
+    const int r = tid >> 4, cl = tid & 15;
+    const int m = m0 + r;
+    const bool row_ok = m < a.M;
+    const int mc = row_ok ? m : a.M - 1;
+    int koff = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const es_seg& sg = a.seg[s];
+        const int lo = max(kc0, koff), hi = min(min(kc0 + kc, koff + sg.width), a.K);
+        if (lo < hi) {
+            const int w4 = (hi - lo) >> 2;
+            const float* base = seg_base(sg) + (lo - koff);
+            float* dst = &sm.x[r][lo - kc0];
+            if (sg.mode == ES_SEG_CSRMEAN) {
+                const int e0 = sg.idx[mc], e1 = sg.idx[mc + 1];
+                const float inv = 1.0f / (float)max(e1 - e0, 1);
+                for (int c4 = cl; c4 < w4; c4 += 16) {
+                    f4 v = {0.f, 0.f, 0.f, 0.f};
+                    for (int e = e0; e < e1; ++e)        // stored order == scatter_add order of the reference
+                        v += *(const f4*)(base + (long)sg.ent_row[e] * sg.ld + sg.ent_off[e] + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = row_ok ? v[e] / (float)max(e1 - e0, 1) : 0.f;
+                    (void)inv;
+                    *(f4*)(dst + 4 * c4) = v;
+                }
+            } else {
+                const long rowoff = (long)(sg.mode == ES_SEG_GATHER ? sg.idx[mc] : mc) * sg.ld;
+                const float* src = base + rowoff;
+                for (int u0 = 0; u0 * 16 < w4; u0 += 8) {
+                    f4 v[8], gt[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c4 = min(cl + 16 * (u0 + u), w4 - 1);
+                        v[u] = *(const f4*)(src + 4 * c4);
+                        if (PRO == ES_PRO_GEGLU) gt[u] = *(const f4*)(src + a.K + 4 * c4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c4 = cl + 16 * (u0 + u);
+                        if (c4 < w4) {
+                            f4 y = post_a4<PRO>(v[u], gt[u]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = row_ok ? y[e] : 0.f;
+                            *(f4*)(dst + 4 * c4) = y;
+                        }
+                    }
+                }
+            }
+        }
+        koff += sg.width;
+    }
+    // zero the K padding (K not a multiple of 16)
+    const int kend = min(kc0 + kc, a.K) - kc0;
+    for (int c = kend + cl; c < kc; c += 16) sm.x[r][c] = 0.f;
+}
+
+template <int PRO>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a) {
     __shared__ Smem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,37 +126,18 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
         f4 bf[MAXJ];
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int kb = wave + j * NWAVE;
-            if (kb < nkb) bf[j] = __builtin_nontemporal_load(&wp[(size_t)((kc0 >> 4) + kb) * 64 + lane]);
+            const int kb = min(wave + j * NWAVE, nkb - 1);
+            bf[j] = __builtin_nontemporal_load(&wp[(size_t)((kc0 >> 4) + kb) * 64 + lane]);
         }
         // (2) stage the activation chunk (prologue elementwise part applied on the fly)
         if (kc0 > 0) __syncthreads();
-        const int c4n = kc >> 2, total = MT * c4n;
-        for (int base0 = 0; base0 < total; base0 += NTHREAD * 8) {
-            f4 v[8], gt[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {                 // 8 independent loads in flight per thread
-                const int idx = base0 + u * NTHREAD + tid;
-                if (idx < total) {
-                    const int r = idx / c4n, c4 = idx - r * c4n;
-                    load_a4_raw(a, m0 + r, kc0 + 4 * c4, v[u], gt[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base0 + u * NTHREAD + tid;
-                if (idx < total) {
-                    const int r = idx / c4n, c4 = idx - r * c4n;
-                    *(f4*)&sm.x[r][4 * c4] = post_a4(a, v[u], gt[u]);
-                }
-            }
-        }
+        stage_chunk<PRO>(a, sm, m0, kc0, kc, tid);
         __syncthreads();
         // (3) norm prologues (host guarantees K <= KC for these)
-        if (a.prologue == ES_PRO_GN || a.prologue == ES_PRO_GN_SILU || a.prologue == ES_PRO_LN) {
+        if (PRO == ES_PRO_GN || PRO == ES_PRO_GN_SILU || PRO == ES_PRO_LN) {
             const int r = tid >> 4, sub = tid & 15;     // 16 lanes per row
             const int K = a.K;
-            if (a.prologue == ES_PRO_LN) {
+            if (PRO == ES_PRO_LN) {
                 float s = 0.f;
                 for (int k = sub; k < K; k += 16) s += sm.x[r][k];
 #pragma unroll
@@ -153,41 +165,42 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
                         for (int k = 0; k < gs; ++k) {
                             const int kk = g * gs + k;
                             float y = (sm.x[r][kk] - mean) * rstd * a.gamma[kk] + a.beta[kk];
-                            if (a.prologue == ES_PRO_GN_SILU) y = es_silu(y);
+                            if (PRO == ES_PRO_GN_SILU) y = es_silu(y);
                             sm.x[r][kk] = y;
                         }
                     }
-                } else
+                } else {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int g = sub + 16 * h;
-                    f4 v[8];
-                    float s = 0.f;
+                    for (int h = 0; h < 2; ++h) {
+                        const int g = sub + 16 * h;
+                        f4 v[8];
+                        float s = 0.f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < gs4) { v[u] = *(const f4*)&sm.x[r][g * gs + 4 * u]; s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]); }
-                    const float mean = s / (float)gs;
-                    float var = 0.f;
+                        for (int u = 0; u < 8; ++u)
+                            if (u < gs4) { v[u] = *(const f4*)&sm.x[r][g * gs + 4 * u]; s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]); }
+                        const float mean = s / (float)gs;
+                        float var = 0.f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < gs4) {
+                        for (int u = 0; u < 8; ++u)
+                            if (u < gs4) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var += d * d; }
-                        }
-                    const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < gs4) {
-                            const int kk = g * gs + 4 * u;
-                            const f4 ga = *(const f4*)&a.gamma[kk], be = *(const f4*)&a.beta[kk];
-                            f4 y;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                y[e] = (v[u][e] - mean) * rstd * ga[e] + be[e];
-                                if (a.prologue == ES_PRO_GN_SILU) y[e] = es_silu(y[e]);
+                                for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var += d * d; }
                             }
-                            *(f4*)&sm.x[r][kk] = y;
-                        }
+                        const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (u < gs4) {
+                                const int kk = g * gs + 4 * u;
+                                const f4 ga = *(const f4*)&a.gamma[kk], be = *(const f4*)&a.beta[kk];
+                                f4 y;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    y[e] = (v[u][e] - mean) * rstd * ga[e] + be[e];
+                                    if (PRO == ES_PRO_GN_SILU) y[e] = es_silu(y[e]);
+                                }
+                                *(f4*)&sm.x[r][kk] = y;
+                            }
+                    }
                 }
             }
             __syncthreads();
@@ -301,7 +314,16 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
     if (a->prologue == ES_PRO_GEGLU)
         ES_REQUIRE(a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
     dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT);
-    hipLaunchKernelGGL(k_linear_rows, grid, dim3(NTHREAD), 0, (hipStream_t)stream, *a);
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->prologue) {
+        case ES_PRO_NONE: hipLaunchKernelGGL(k_linear_rows<ES_PRO_NONE>, grid, dim3(NTHREAD), 0, st, *a); break;
+        case ES_PRO_SILU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_SILU>, grid, dim3(NTHREAD), 0, st, *a); break;
+        case ES_PRO_GN: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GN>, grid, dim3(NTHREAD), 0, st, *a); break;
+        case ES_PRO_GN_SILU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GN_SILU>, grid, dim3(NTHREAD), 0, st, *a); break;
+        case ES_PRO_LN: hipLaunchKernelGGL(k_linear_rows<ES_PRO_LN>, grid, dim3(NTHREAD), 0, st, *a); break;
+        case ES_PRO_GEGLU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GEGLU>, grid, dim3(NTHREAD), 0, st, *a); break;
+        default: ES_REQUIRE(false, "es_linear_rows_f32: unknown prologue %d", a->prologue);
+    }
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

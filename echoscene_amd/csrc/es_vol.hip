@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
 //   N = 224 / 448 / 672 (and 3*C, 8*C) are all multiples of 224 at full width; ragged N / M are
 //   handled by zero-page rows and masked stores (narrow test configs).
 // ---------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 224, BK = 32;
-constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;   // 8192 + 14336
+constexpr int BN = 224, BK = 32, BNP = 256;     // BNP: B tile rows padded so that every thread issues 4 B loads
+constexpr int NSTAGE = 3;                        // LDS ring depth (tiles ks, ks+1, ks+2)
 
 struct ConvGeom {
     int O, D, H, W;          // output grid
@@ -220,25 +220,29 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// BM_ = 128 (wave tile 64 x 112) or 64 (wave tile 32 x 112); 4 waves as 2(M) x 2(N).
+template <int BM_>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw) {
+    constexpr int MI = BM_ / 32;                 // 16-row MFMA tiles per wave in M
+    constexpr int NA = BM_ / 64;                 // A glds per thread per stage
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NLOAD = NA + 4;                // glds per thread per stage (uniform across waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.O * g.D * g.H * g.W;
-    const long m0 = (long)blockIdx.x * BM;
+    const long m0 = (long)blockIdx.x * BM_;
     const int n0 = blockIdx.y * BN;
 
     // ---- per-lane staging roles (fixed for the whole K loop) ----
-    // A: 512 16-B slots (128 rows x 4 chunks): slot p = tid + 256*j, j = 0,1
-    int a_row[2], a_lc[2];
-    int a_o[2], a_d[2], a_h[2], a_w[2];
-    bool a_ok[2];
+    int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
+    bool a_ok[NA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = tid + 256 * j;
-        a_row[j] = p >> 2;
-        a_lc[j] = (p & 3) ^ f_swz(a_row[j]);
-        const long m = m0 + a_row[j];
+    for (int j = 0; j < NA; ++j) {
+        const int p = tid + 256 * j;             // 16-B slot: row = p >> 2, physical chunk = p & 3
+        const int row = p >> 2;
+        a_lc[j] = (p & 3) ^ f_swz(row);
+        const long m = m0 + row;
         a_ok[j] = m < M;
         const long mm = a_ok[j] ? m : 0;
         a_w[j] = (int)(mm & (g.W - 1));
@@ -246,47 +250,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
         a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
         a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
     }
-    // B: 896 slots (224 rows x 4 chunks): slot p = tid + 256*j, j = 0..3 (j = 3 only for tid < 128)
-    int b_row[4], b_lc[4];
+    int b_lc[4], b_row[4];
     bool b_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = tid + 256 * j;
         b_row[j] = p >> 2;
         b_lc[j] = (p & 3) ^ f_swz(b_row[j]);
-        b_ok[j] = (p < BN * 4) && (n0 + b_row[j] < a.N);
+        b_ok[j] = (b_row[j] < BN) && (n0 + b_row[j] < a.N);
     }
 
-    f4 acc[4][7];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    // K steps: phase 0 = taps x (Cin/32) of the main contraction, phase 1 = Cin2/32 steps of the
-    // optional fused 1x1 skip connection (accumulated into the same tile).
+    // ---- K-step generator state (for the tile being STAGED, which runs 2 steps ahead of compute) ----
     const int kch0 = a.Cin >> 5;
     const int nks0 = a.taps * kch0;
     const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
-
-    auto stage = [&](int ks, int b) {
-        char* As = smem + b * STAGE_BYTES;
-        char* Bs = As + A_BYTES;
-        const bool p1 = ks >= nks0;
-        const _Float16* Ag = (const _Float16*)(p1 ? a.a2 : a.a);
-        const _Float16* Wg = (const _Float16*)(p1 ? a.w2 : a.w);
-        const int Cin = p1 ? a.Cin2 : a.Cin;
-        const int taps = p1 ? 1 : a.taps;
-        const int mode = p1 ? (int)ES_CONV_SAME : a.mode;
-        const int Hi = p1 ? g.H : g.Hi, Wi = p1 ? g.W : g.Wi;
-        const int kk = p1 ? ks - nks0 : ks;
-        const int kch = p1 ? (a.Cin2 >> 5) : kch0;
-        const int tap = kk / kch, c0 = (kk - tap * kch) << 5;
-        int kd = 0, kh = 0, kw = 0;
-        if (taps == 27) { kd = tap / 9 - 1; kh = (tap / 3) % 3 - 1; kw = tap % 3 - 1; }
+    int st_phase = 0, st_tap = 0, st_c = 0;
+    const _Float16* a_src[NA];                   // source row start for the current (phase, tap); zero page if outside
+    bool a_in[NA];
+    const _Float16* b_src[4];                    // weight row start for the current phase
+    auto set_phase = [&]() {
+        const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
+        const long rowlen = st_phase ? (long)a.Cin2 : (long)a.taps * a.Cin;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const _Float16* src = zero_page;
+        for (int j = 0; j < 4; ++j) b_src[j] = b_ok[j] ? Wg + (long)(n0 + b_row[j]) * rowlen + b_lc[j] * 8 : zero_page;
+    };
+    auto set_tap = [&]() {
+        const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
+        const int Cin = st_phase ? a.Cin2 : a.Cin;
+        const int mode = st_phase ? (int)ES_CONV_SAME : a.mode;
+        const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+        int kd = 0, kh = 0, kw = 0;
+        if (!st_phase && a.taps == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
             const int id = a_d[j] + kd;
             int ih, iw;
             bool ok = a_ok[j] && id >= 0 && id < g.D;
@@ -298,32 +294,60 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
                 ok = ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
                 if (mode == ES_CONV_UP_HW) { ih >>= 1; iw >>= 1; }
             }
-            if (ok) src = Ag + ((((long)a_o[j] * g.D + id) * Hi + ih) * Wi + iw) * Cin + c0 + a_lc[j] * 8;
-            glds16(src, As + (wave * 64 + 256 * j) * 16);
+            a_in[j] = ok;
+            a_src[j] = ok ? Ag + ((((long)a_o[j] * g.D + id) * Hi + ih) * Wi + iw) * Cin + a_lc[j] * 8 : zero_page;
         }
+    };
+    set_phase();
+    set_tap();
+
+    auto stage = [&](int b) {                    // issue the glds of the next K step into ring slot b, then advance
+        char* As = smem + b * STAGE_BYTES;
+        char* Bs = As + A_BYTES;
+        const int boff = st_phase ? st_c : st_tap * a.Cin + st_c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < 3 || wave < 2) {
-                const _Float16* src = zero_page;
-                if (b_ok[j]) src = Wg + ((long)(n0 + b_row[j]) * taps + tap) * Cin + c0 + b_lc[j] * 8;
-                glds16(src, Bs + (wave * 64 + 256 * j) * 16);
+        for (int j = 0; j < NA; ++j)
+            glds16(a_in[j] ? a_src[j] + st_c : zero_page, As + (wave * 64 + 256 * j) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            glds16(b_ok[j] ? b_src[j] + boff : zero_page, Bs + (wave * 64 + 256 * j) * 16);
+        st_c += BK;
+        if (st_c == (st_phase ? a.Cin2 : a.Cin)) {
+            st_c = 0;
+            ++st_tap;
+            if (!st_phase && st_tap == a.taps) {
+                if (a.a2) { st_phase = 1; st_tap = 0; set_phase(); set_tap(); }
+            } else if (!st_phase) {
+                set_tap();
             }
         }
     };
 
-    const int i16 = lane & 15, q = lane >> 4;
-    int buf = 0;
-    stage(0, 0);
-    for (int ks = 0; ks < nks; ++ks) {
-        __syncthreads();       // tile ks has landed (the barrier release waits vmcnt(0)) and every wave is
-                               // done reading the other buffer, which is refilled next
-        if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
-        const char* As = smem + buf * STAGE_BYTES;
-        const char* Bs = As + A_BYTES;
-        h8 af[4], bfr[7];
+    f4 acc[MI][7];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + i16;
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int i16 = lane & 15, q = lane >> 4;
+    stage(0);
+    if (nks > 1) stage(1);
+    for (int ks = 0; ks < nks; ++ks) {
+        // tile ks must have landed; tile ks+1 (NLOAD loads per thread) may stay in flight across the barrier
+        if (ks + 1 < nks) {
+            if (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();            // also: every wave finished reading ring slot (ks+2)%3 == (ks-1)%3
+        if (ks + 2 < nks) stage((ks + 2) % NSTAGE);
+        const char* As = smem + (ks % NSTAGE) * STAGE_BYTES;
+        const char* Bs = As + A_BYTES;
+        h8 af[MI], bfr[7];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * (BM_ / 2) + i * 16 + i16;
             af[i] = *(const h8*)(As + row * 64 + ((q ^ f_swz(row)) << 4));
         }
 #pragma unroll
@@ -332,26 +356,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
             bfr[j] = *(const h8*)(Bs + row * 64 + ((q ^ f_swz(row)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 7; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        buf ^= 1;
     }
 
     // ---- epilogue: D[row=(lane>>4)*4+r][col=lane&15] ----
-    const int col16 = i16, rq = q;
     const int V = g.D * g.H * g.W;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * 64 + i * 16 + rq * 4 + r;
+            const long m = m0 + wm * (BM_ / 2) + i * 16 + q * 4 + r;
             if (m >= M) continue;
             const long o = m / V;
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const int n = n0 + wn * 112 + j * 16 + col16;
+                const int n = n0 + wn * 112 + j * 16 + i16;
                 if (n >= a.N) continue;
                 float v = acc[i][j][r];
                 if (a.bias) v += a.bias[n];
@@ -546,13 +568,23 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
     if (!g_zero_page) if (int rc = es_vol_init()) return rc;
     const long M = (long)a->O * a->D * a->H * a->W;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (a->N + BN - 1) / BN);
+    const int ntn = (a->N + BN - 1) / BN;
+    // small-M layers (16x4x4 level): 64-row tiles double the number of workgroups (>= 1 per CU)
+    const bool small = ((M + 127) / 128) * ntn < 512;
     static bool attr_set = false;
+    constexpr int LDS128 = NSTAGE * (128 * BK * 2 + BNP * BK * 2), LDS64 = NSTAGE * (64 * BK * 2 + BNP * BK * 2);
     if (!attr_set) {
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_mfma, grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+    if (small) {
+        dim3 grid((unsigned)((M + 63) / 64), ntn);
+        hipLaunchKernelGGL(k_conv_mfma<64>, grid, dim3(256), LDS64, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+    } else {
+        dim3 grid((unsigned)((M + 127) / 128), ntn);
+        hipLaunchKernelGGL(k_conv_mfma<128>, grid, dim3(256), LDS128, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+    }
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
