@@ -122,3 +122,20 @@ def resolve_nested(cfg_or_path):
     if isinstance(cfg_or_path, (str, os.PathLike)):
         return load_yaml(cfg_or_path)
     return to_plain(cfg_or_path)
+
+
+def tiny_diff_opt(device='cuda', logs_dir=None, vq_ckpt=None):
+    """Narrow end-to-end test configuration (same topology as full_mp.yaml, widths 128 / 32 / 32,
+    100 layout steps, 64-entry codebook).  Used by tests/golden/make_golden.py (on the reference) and
+    by the parity tests (on this build)."""
+    opt = default_diff_opt(device=device, time_num=100, logs_dir=logs_dir)
+    opt.hyper.isTrain = False
+    opt.layout_branch.denoiser_kwargs = layout_denoiser_kwargs(128)
+    opt.layout_branch.denoiser_kwargs.concat_dim = 128
+    opt.layout_branch.denoiser_kwargs.crossattn_dim = 128
+    opt.shape_branch.df_cfg = shape_df_conf(32)
+    vqc = vqvae_conf(32)
+    vqc.model.params.n_embed = 64
+    opt.shape_branch.vq_cfg = vqc
+    opt.shape_branch.vq_ckpt = vq_ckpt
+    return opt

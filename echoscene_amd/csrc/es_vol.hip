@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / gs;
             float t = (x[e] - smean[g]) * srstd[g] * a.gamma[c + e] + a.beta[c + e];
-            if (a.silu) t = es_silu_fast(t);
+            if (a.silu == 1) t = es_silu_fast(t);
+            else if (a.silu == 2) t = es_gelu(t);
             y[e] = (_Float16)t;
             r[e] = (_Float16)x[e];
         }
@@ -279,23 +280,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
         const int Cin = st_phase ? a.Cin2 : a.Cin;
         const int mode = st_phase ? (int)ES_CONV_SAME : a.mode;
         const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+        const int Di = (mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
         int kd = 0, kh = 0, kw = 0;
         if (!st_phase && a.taps == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int id = a_d[j] + kd;
+            int id = a_d[j] + kd;
             int ih, iw;
             bool ok = a_ok[j] && id >= 0 && id < g.D;
+            if (mode == ES_CONV_UP_DHW) id >>= 1;
             if (mode == ES_CONV_DOWN_HW) {
                 ih = 2 * a_h[j] + kh; iw = 2 * a_w[j] + kw;
                 ok = ok && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
             } else {
                 ih = a_h[j] + kh; iw = a_w[j] + kw;
                 ok = ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                if (mode == ES_CONV_UP_HW) { ih >>= 1; iw >>= 1; }
+                if (mode == ES_CONV_UP_HW || mode == ES_CONV_UP_DHW) { ih >>= 1; iw >>= 1; }
             }
             a_in[j] = ok;
-            a_src[j] = ok ? Ag + ((((long)a_o[j] * g.D + id) * Hi + ih) * Wi + iw) * Cin + a_lc[j] * 8 : zero_page;
+            a_src[j] = ok ? Ag + ((((long)a_o[j] * Di + id) * Hi + ih) * Wi + iw) * Cin + a_lc[j] * 8 : zero_page;
         }
     };
     set_phase();
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_Q = 64, AT_K = 64;
 
-template <int DP>   // padded head dim: 32, 64 or 96
+template <int DP>   // padded head dim: 32, 64, 96 or 256 (VQ-VAE AttnBlock: one head of 256)
 __global__ __launch_bounds__(256) void k_attention(const es_attn_args a) {
     constexpr int KLD = DP + 8;              // halfs; +8 keeps 16-B alignment and skews banks
     constexpr int VLD = AT_K + 8;
@@ -512,6 +515,81 @@ __global__ __launch_bounds__(256) void k_attention(const es_attn_args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Direct 3x3x3 conv for N <= 4 output channels (final eps conv 224->3, VQ-VAE conv_out 64->1):
+// an MFMA tile would be >98 % padding.  One thread per voxel, weights [N][27][Cin] f16 in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_small_n(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* wl = (_Float16*)smem;                                  // [N][27][Cin]
+    const int wn = a.N * 27 * a.Cin;
+    for (int i = threadIdx.x * 8; i < wn; i += 256 * 8) *(h8*)(wl + i) = *(const h8*)((const _Float16*)a.w + i);
+    __syncthreads();
+    const long M = (long)g.O * g.D * g.H * g.W;
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int w_ = (int)(m & (g.W - 1)), h_ = (int)((m >> g.lw) & (g.H - 1)), d_ = (int)((m >> (g.lw + g.lh)) & (g.D - 1));
+    const long o = m >> (g.lw + g.lh + g.ld);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const _Float16* A = (const _Float16*)a.a;
+    for (int tap = 0; tap < 27; ++tap) {
+        const int id = d_ + tap / 9 - 1, ih = h_ + (tap / 3) % 3 - 1, iw = w_ + tap % 3 - 1;
+        if (id < 0 || id >= g.D || ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) continue;
+        const _Float16* src = A + (((o * g.D + id) * g.H + ih) * g.W + iw) * a.Cin;
+        for (int c = 0; c < a.Cin; c += 8) {
+            const h8 x = *(const h8*)(src + c);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n < a.N) {
+                    const h8 wv = *(const h8*)(wl + (n * 27 + tap) * a.Cin + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[n] += (float)x[e] * (float)wv[e];
+                }
+            }
+        }
+    }
+    const long V = (long)g.D * g.H * g.W;
+    for (int n = 0; n < a.N; ++n) {
+        float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
+        if (ncdhw) a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
+        else a.out_f32[m * a.out_ld + n] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// VQ nearest-codebook lookup (quantizer.py:68-119): d_j = |z|^2 + |e_j|^2 - 2 z.e_j, argmin_j
+// (first minimum), output = lut[argmin] written as channels-last f16 padded to Cpad.  lut is the
+// codebook already passed through post_quant_conv (a 1x1x1 conv, folded on the host).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vq_lookup(const es_vq_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* E = (float*)smem;                     // [n_embed][4]: e0,e1,e2,|e|^2
+    for (int j = threadIdx.x; j < a.n_embed; j += 256) {
+        const float e0 = a.codebook[j * 3], e1 = a.codebook[j * 3 + 1], e2 = a.codebook[j * 3 + 2];
+        E[j * 4] = e0; E[j * 4 + 1] = e1; E[j * 4 + 2] = e2;
+        E[j * 4 + 3] = e0 * e0 + e1 * e1 + e2 * e2;          // torch.sum(E**2, dim=1)
+    }
+    __syncthreads();
+    const long M = (long)a.O * a.V;
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const long o = m / a.V, v = m - o * a.V;
+    const float z0 = a.z[(o * 3 + 0) * a.V + v], z1 = a.z[(o * 3 + 1) * a.V + v], z2 = a.z[(o * 3 + 2) * a.V + v];
+    const float zz = z0 * z0 + z1 * z1 + z2 * z2;
+    float best = INFINITY;
+    int bi = 0;
+    for (int j = 0; j < a.n_embed; ++j) {
+        const f4 e = *(const f4*)&E[j * 4];
+        const float dot = fmaf(z2, e[2], fmaf(z1, e[1], z0 * e[0]));
+        const float d = (zz + e[3]) - 2.0f * dot;
+        if (d < best) { best = d; bi = j; }
+    }
+    if (a.idx_out) a.idx_out[m] = bi;
+    _Float16* out = (_Float16*)a.out_f16 + m * a.Cpad;
+    for (int c = 0; c < a.Cpad; ++c) out[c] = c < 3 ? (_Float16)a.lut[bi * 3 + c] : (_Float16)0.f;
+}
+
 _Float16* g_zero_page = nullptr;
 
 int ilog2_exact(int v) {
@@ -561,13 +639,20 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     g.O = a->O; g.D = a->D; g.H = a->H; g.W = a->W;
     g.Hi = a->H; g.Wi = a->W;
     if (a->mode == ES_CONV_DOWN_HW) { g.Hi = 2 * a->H; g.Wi = 2 * a->W; }
-    if (a->mode == ES_CONV_UP_HW) { g.Hi = a->H / 2; g.Wi = a->W / 2; }
+    if (a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW) { g.Hi = a->H / 2; g.Wi = a->W / 2; }
     g.lw = ilog2_exact(a->W); g.lh = ilog2_exact(a->H); g.ld = ilog2_exact(a->D);
     ES_REQUIRE(g.lw >= 0 && g.lh >= 0 && g.ld >= 0, "es_conv_mfma_f16: D,H,W must be powers of two (%d,%d,%d)", a->D, a->H, a->W);
     const int ncdhw = a->out_ld < 0 ? 1 : 0;      // out_ld < 0 selects NCDHW fp32 output [O,N,V]
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
     if (!g_zero_page) if (int rc = es_vol_init()) return rc;
     const long M = (long)a->O * a->D * a->H * a->W;
+    if (a->N <= 4 && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16 &&
+        (size_t)a->N * 27 * a->Cin * 2 <= 60000) {
+        hipLaunchKernelGGL(k_conv_small_n, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->N * 27 * a->Cin * 2,
+                           (hipStream_t)stream, *a, g, ncdhw);
+        ES_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int ntn = (a->N + BN - 1) / BN;
     // small-M layers (16x4x4 level): 64-row tiles double the number of workgroups (>= 1 per CU)
     const bool small = ((M + 127) / 128) * ntn < 512;
@@ -611,11 +696,12 @@ extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
 }
 
 extern "C" int es_attention_f16(const es_attn_args* a, es_stream stream) {
-    ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 96 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 96)", a->dhead);
+    ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 256 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 256)", a->dhead);
     dim3 grid((a->Ntok + AT_Q - 1) / AT_Q, a->B * a->heads);
     if (a->dhead <= 32) hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->dhead <= 64) hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->dhead <= 96) hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(k_attention<256>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -641,6 +727,20 @@ extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
     const long n1 = (long)a->O * 32 * 512, n2 = (long)a->O * 512;
     hipLaunchKernelGGL(k_stem1, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_vq_lookup(const es_vq_args* a, es_stream stream) {
+    ES_REQUIRE(a->n_embed > 0 && a->n_embed * 16 <= 160 * 1024 - 1024, "es_vq_lookup: n_embed=%d too large for LDS", a->n_embed);
+    ES_REQUIRE(a->Cpad >= 3, "es_vq_lookup: Cpad=%d", a->Cpad);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_vq_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set = true;
+    }
+    const long M = (long)a->O * a->V;
+    hipLaunchKernelGGL(k_vq_lookup, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->n_embed * 16, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

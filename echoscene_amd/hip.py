@@ -16,8 +16,9 @@ c_i32p = C.c_void_p
 SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-CONV_SAME, CONV_DOWN_HW, CONV_UP_HW = 0, 1, 2
+CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW = 0, 1, 2, 3
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
+OP_VQ = 12
 OP_FORK, OP_JOIN = 13, 14
 
 
@@ -84,10 +85,15 @@ class StemArgs(C.Structure):
                 ('scratch', C.c_void_p), ('out', C.c_void_p), ('O', C.c_int32)]
 
 
+class VQArgs(C.Structure):
+    _fields_ = [('z', C.c_void_p), ('codebook', C.c_void_p), ('lut', C.c_void_p), ('O', C.c_int32), ('V', C.c_int32),
+                ('n_embed', C.c_int32), ('Cpad', C.c_int32), ('idx_out', C.c_void_p), ('out_f16', C.c_void_p)]
+
+
 class _OpU(C.Union):
     _fields_ = [('linear', LinearArgs), ('update', UpdateArgs), ('copy', CopyArgs), ('conv', ConvArgs),
                 ('gn', GNArgs), ('ln', LNArgs), ('attn', AttnArgs), ('geglu', GegluArgs), ('tocl', ToClArgs),
-                ('stem', StemArgs)]
+                ('stem', StemArgs), ('vq', VQArgs)]
 
 
 class Op(C.Structure):
@@ -112,6 +118,7 @@ EXPORTS = {
     'es_geglu_f16': (C.c_int, [C.POINTER(GegluArgs), C.c_void_p]),
     'es_latent_to_cl_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_shape_stem': (C.c_int, [C.POINTER(StemArgs), C.c_void_p]),
+    'es_vq_lookup': (C.c_int, [C.POINTER(VQArgs), C.c_void_p]),
     'es_init': (C.c_int, []),
     'es_plan_create': (C.c_void_p, [C.POINTER(Op), C.c_int]),
     'es_plan_destroy': (None, [C.c_void_p]),

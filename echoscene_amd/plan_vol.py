@@ -141,14 +141,14 @@ class VolBuilderMixin:
         self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
         return self._push(hip.OP_CONV, 'conv', a)
 
-    def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None):
+    def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None, groups=32):
         a = GNArgs()
         a.x1, a.C1 = x1.data_ptr(), C1
         a.x2, a.C2 = (x2.data_ptr(), C2) if x2 is not None else (None, 0)
-        a.O, a.V, a.groups, a.eps = O, V, 32, eps
-        a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0
+        a.O, a.V, a.groups, a.eps = O, V, groups, eps
+        a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), int(silu)
         ntiles = (V + 63) // 64
-        a.stats = self.buf(O * ntiles * 32 * 2).data_ptr()
+        a.stats = self.buf(O * ntiles * groups * 2).data_ptr()
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
         self.keep += [gamma, beta]
@@ -330,3 +330,133 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16))
 
 for _n in ('_push', 'conv', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
     setattr(Builder, _n, getattr(VolBuilderMixin, _n))
+
+
+# ------------------------------------------------------------------------------------------------
+# VQ-VAE decode epilogue: VQVAE.decode_no_quant (vqvae_networks/network.py:95-103) ->
+# VectorQuantizer nearest-code lookup (quantizer.py:68-119) -> post_quant_conv -> Decoder3D.forward
+# (vqvae_modules.py:376-409; ResnetBlock :67-126, AttnBlock :128-176, Upsample :24-39)
+# ------------------------------------------------------------------------------------------------
+def _vq_groups(C):
+    return C // 4 if C <= 32 else (32 if C % 32 == 0 else 30)          # Normalize(), vqvae_modules.py:13-21
+
+
+class VQWeights:
+    def __init__(self, sd, device):
+        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        PC = lambda w, b: PackedConv(sd[w], sd[b] if b else None, device)
+        E = sd['quantize.embedding.weight'].detach().double()
+        Wp = sd['post_quant_conv.weight'].detach().double().flatten(1)          # [3,3]
+        self.codebook = E.float().contiguous().to(device)
+        self.lut = (E @ Wp.t() + sd['post_quant_conv.bias'].double()).float().contiguous().to(device)
+        self.n_embed = E.shape[0]
+        if E.shape[1] != 3:
+            raise NotImplementedError('embed_dim != 3')
+        d = {k[len('decoder.'):]: v for k, v in sd.items() if k.startswith('decoder.')}
+        self.d = d
+        self.conv_in = PackedConv(d['conv_in.weight'], d['conv_in.bias'], device)
+
+        def res(p):
+            r = dict(gn1=(d[p + '.norm1.weight'].float().to(device), d[p + '.norm1.bias'].float().to(device)),
+                     conv1=PackedConv(d[p + '.conv1.weight'], d[p + '.conv1.bias'], device),
+                     gn2=(d[p + '.norm2.weight'].float().to(device), d[p + '.norm2.bias'].float().to(device)),
+                     conv2=PackedConv(d[p + '.conv2.weight'], d[p + '.conv2.bias'], device))
+            r['cin'], r['cout'] = d[p + '.conv1.weight'].shape[1], d[p + '.conv1.weight'].shape[0]
+            if (p + '.nin_shortcut.weight') in d:
+                r['skip'] = PackedConv(d[p + '.nin_shortcut.weight'].flatten(1), None, device)
+                r['bias2'] = (d[p + '.conv2.bias'].float() + d[p + '.nin_shortcut.bias'].float()).contiguous().to(device)
+            return r
+
+        self.mid1, self.mid2 = res('mid.block_1'), res('mid.block_2')
+        p = 'mid.attn_1'
+        Cc = d[p + '.q.weight'].shape[0]
+        self.attn = dict(
+            C=Cc, gn=(d[p + '.norm.weight'].float().to(device), d[p + '.norm.bias'].float().to(device)),
+            qkv=PackedConv(torch.cat([d[p + '.q.weight'].flatten(1), d[p + '.k.weight'].flatten(1),
+                                      d[p + '.v.weight'].flatten(1)], 0),
+                           torch.cat([d[p + '.q.bias'], d[p + '.k.bias'], d[p + '.v.bias']], 0), device),
+            proj=PackedConv(d[p + '.proj_out.weight'].flatten(1), d[p + '.proj_out.bias'], device))
+        n_lvl = 1 + max(int(k.split('.')[1]) for k in d if k.startswith('up.'))
+        self.levels = []
+        for lvl in reversed(range(n_lvl)):
+            blocks, bi = [], 0
+            while f'up.{lvl}.block.{bi}.norm1.weight' in d:
+                blocks.append(res(f'up.{lvl}.block.{bi}'))
+                bi += 1
+            up = None
+            if (f'up.{lvl}.upsample.conv.weight') in d:
+                up = PackedConv(d[f'up.{lvl}.upsample.conv.weight'], d[f'up.{lvl}.upsample.conv.bias'], device)
+            self.levels.append((blocks, up))
+        self.out_gn = (d['norm_out.weight'].float().to(device), d['norm_out.bias'].float().to(device))
+        self.conv_out = PackedConv(d['conv_out.weight'], d['conv_out.bias'], device)
+
+
+def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
+    """z f32 [Oc,3,16,16,16] -> sdf_out f32 [Oc,1,64,64,64] (one chunk of objects)."""
+    from .hip import VQArgs
+    f16 = torch.float16
+    st = dict(h=None, C=0, dims=tuple(zdims), last=None, h16=None)
+    V_ = lambda dm: dm[0] * dm[1] * dm[2]
+    V0 = V_(zdims)
+    zq = b.buf(Oc * V0, 32, dtype=f16)
+    a = VQArgs()
+    a.z, a.codebook, a.lut = z.data_ptr(), w.codebook.data_ptr(), w.lut.data_ptr()
+    a.O, a.V, a.n_embed, a.Cpad = Oc, V0, w.n_embed, 32
+    a.idx_out = None
+    a.out_f16 = zq.data_ptr()
+    b._push(hip.OP_VQ, 'vq', a)
+    b.keep.append(w)
+    o = b.buf(Oc * V0, w.conv_in.N)
+    st['last'] = b.conv(zq, w.conv_in, Oc, zdims, out_f32=o)
+    st.update(h=o, C=w.conv_in.N)
+
+    def gn(x, Cc, ga, be, act, y, raw=None):
+        b.groupnorm(x, Cc, None, 0, Oc, V_(st['dims']), ga, be, 1e-6, act, y, raw, groups=_vq_groups(Cc))
+
+    def res(r):
+        dm, M = st['dims'], Oc * V_(st['dims'])
+        x, cin, cout = st['h'], r['cin'], r['cout']
+        y1 = b.buf(M, cin, dtype=f16)
+        raw = b.buf(M, cin, dtype=f16) if 'skip' in r else None
+        gn(x, cin, r['gn1'][0], r['gn1'][1], 1, y1, raw)
+        h1 = b.buf(M, cout)
+        b.conv(y1, r['conv1'], Oc, dm, out_f32=h1)
+        y2 = b.buf(M, cout, dtype=f16)
+        gn(h1, cout, r['gn2'][0], r['gn2'][1], 1, y2)
+        o = b.buf(M, cout)
+        if 'skip' in r:
+            st['last'] = b.conv(y2, r['conv2'], Oc, dm, bias=r['bias2'], skip=(raw, r['skip']), out_f32=o)
+        else:
+            st['last'] = b.conv(y2, r['conv2'], Oc, dm, res=x, out_f32=o)
+        st.update(h=o, C=cout, h16=None)
+
+    res(w.mid1)
+    # AttnBlock: single head of C channels over all voxels
+    dm, M, Cc = st['dims'], Oc * V_(st['dims']), w.attn['C']
+    x = st['h']
+    yn = b.buf(M, Cc, dtype=f16)
+    gn(x, Cc, w.attn['gn'][0], w.attn['gn'][1], 0, yn)
+    qkv = b.buf(M, 3 * Cc, dtype=f16)
+    b.conv(yn, w.attn['qkv'], Oc, dm, out_f16=qkv)
+    at = b.buf(M, Cc, dtype=f16)
+    b.attention(qkv, Oc, V_(dm), 1, Cc, at)
+    o = b.buf(M, Cc)
+    st['last'] = b.conv(at, w.attn['proj'], Oc, dm, res=x, out_f32=o)
+    st.update(h=o, h16=None)
+    res(w.mid2)
+    for blocks, up in w.levels:
+        for r in blocks:
+            res(r)
+        if up is not None:
+            dm = st['dims']
+            t = b.buf(Oc * V_(dm), st['C'], dtype=f16)           # f16 copy of the current activation
+            b.ops[st['last']].u.conv.out_f16 = t.data_ptr()
+            nd = (dm[0] * 2, dm[1] * 2, dm[2] * 2)
+            o = b.buf(Oc * V_(nd), st['C'])
+            st['last'] = b.conv(t, up, Oc, nd, mode=hip.CONV_UP_DHW, out_f32=o)
+            st.update(h=o, dims=nd, h16=None)
+    dm = st['dims']
+    yo = b.buf(Oc * V_(dm), st['C'], dtype=f16)
+    gn(st['h'], st['C'], w.out_gn[0], w.out_gn[1], 2, yo)        # norm_out -> GELU
+    b.conv(yo, w.conv_out, Oc, dm, out_f32=sdf_out, ncdhw=True)
+    return dm

@@ -5,7 +5,7 @@ import torch
 
 from . import hip
 from .plan import (Builder, GraphIndex, View, GCNWeights, UNet1DWeights, emit_gcn, emit_unet1d_step)
-from .plan_vol import UNet3DWeights, emit_unet3d_step
+from .plan_vol import UNet3DWeights, emit_unet3d_step, VQWeights, emit_vq_decode
 from .schedules import LayoutSchedule, ShapeSchedule, timestep_embedding_table
 
 
@@ -164,3 +164,42 @@ class ShapeDenoiser:
         st['x'].copy_(noise1.to(self.device).expand(O, *self.z_shape))
         st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
         return st['x'].clone()
+
+
+class VQDecoder:
+    """VQVAE.decode_no_quant on the HIP path: latents [O,3,16,16,16] -> SDF [O,1,64,64,64]
+    (the once-per-sample epilogue of rel2shape, echo2shape.py:522).  Objects are decoded in chunks so
+    that the 64^3-resolution activations stay bounded."""
+
+    def __init__(self, vqvae, device=None, chunk=8):
+        self.device = device or torch.device('cuda')
+        self.w = VQWeights(_cpu_sd(vqvae), self.device)
+        self.chunk = chunk
+        self._plans = {}
+
+    def _plan(self, Oc, zdims):
+        key = (Oc, zdims)
+        if key not in self._plans:
+            b = Builder(self.device)
+            z = b.buf(Oc, 3, *zdims)
+            od = tuple(4 * d for d in zdims)         # placeholder; real dims come from the emitter
+            sdf = b.buf(Oc, 1, *od)
+            dm = emit_vq_decode(b, self.w, z, sdf, Oc, zdims)
+            assert tuple(dm) == od, (dm, od)
+            self._plans = {key: dict(plan=b.finish(), z=z, sdf=sdf)}
+        return self._plans[key]
+
+    def decode_no_quant(self, z):
+        z = z.to(self.device).float().contiguous()
+        O = z.shape[0]
+        zdims = tuple(z.shape[2:])
+        n_up = len([1 for _, up in self.w.levels if up is not None])
+        out = torch.empty(O, 1, *[d * 2 ** n_up for d in zdims], device=self.device)
+        for i in range(0, O, self.chunk):
+            n = min(self.chunk, O - i)
+            st = self._plan(n, zdims)
+            st['z'].copy_(z[i:i + n])
+            st['plan'].run()
+            out[i:i + n].copy_(st['sdf'])
+        torch.cuda.synchronize()
+        return out

@@ -120,7 +120,7 @@ int es_ddim_update(const es_update_args* args, es_stream stream);
  * channels-last [O, D, H, W, C]; the residual stream is fp32, every contraction reads fp16
  * operands and accumulates in fp32 on MFMA (v_mfma_f32_16x16x32_f16).
  * ---------------------------------------------------------------------------------------- */
-enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2 };
+enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW = 3 };
 
 typedef struct es_conv_args {
     const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
@@ -129,7 +129,8 @@ typedef struct es_conv_args {
     int32_t Cin, N;           /* N = true number of output channels                              */
     int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
     int32_t mode;             /* ES_CONV_*: SAME; DOWN_HW = stride (1,2,2) (Downsample, :188);
-                                 UP_HW = nearest x2 on H,W folded into addressing (Upsample, :150-153) */
+                                 UP_HW = nearest x2 on H,W folded into addressing (Upsample, :150-153);
+                                 UP_DHW = nearest x2 on D,H,W (VQ-VAE Upsample, vqvae_modules.py:24-39) */
     /* optional second contraction accumulated into the same tile: the 1x1 skip_connection of a
        ResBlock whose channel count changes (out = conv2(h) + skip(x), :294-314) */
     const void* a2; const void* w2; int32_t Cin2;
@@ -155,7 +156,7 @@ typedef struct es_gn_args {
     int32_t O, V;                    /* objects, voxels per object                              */
     int32_t groups; float eps;
     const float* gamma; const float* beta;   /* [C1+C2]                                         */
-    int32_t silu;
+    int32_t silu;                    /* 0 none, 1 SiLU, 2 GELU (VQ-VAE norm_out, vqvae_modules.py:404-406) */
     float* stats;                    /* scratch [O, groups, 2]                                  */
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
@@ -180,6 +181,18 @@ int es_attention_f16(const es_attn_args* args, es_stream stream);       /* Cross
 typedef struct es_geglu_args { const float* h_f32; int32_t M, C4; void* out_f16; } es_geglu_args;  /* h: [M, 2*C4] value|gate */
 int es_geglu_f16(const es_geglu_args* args, es_stream stream);          /* GEGLU: x * gelu(gate), attention.py:39-46 */
 
+/* VQVAE.decode_no_quant front end (vqvae_networks/network.py:95-103, quantizer.py:68-119): nearest
+ * codebook entry per latent voxel; `lut` = codebook already mapped through post_quant_conv. */
+typedef struct es_vq_args {
+    const float* z;          /* [O,3,V] fp32 NCDHW latents                                       */
+    const float* codebook;   /* [n_embed,3]                                                      */
+    const float* lut;        /* [n_embed,3]                                                      */
+    int32_t O, V, n_embed, Cpad;
+    int32_t* idx_out;        /* optional [O*V] chosen indices                                    */
+    void* out_f16;           /* [O*V, Cpad] channels-last f16                                    */
+} es_vq_args;
+int es_vq_lookup(const es_vq_args* args, es_stream stream);
+
 /* NCDHW fp32 latent <-> channels-last helpers, the 3->32->64 conv-pool stem of
  * shape_messsage_passing (openai_model_3d.py:757-764). */
 int es_latent_to_cl_f16(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f16, es_stream s);
@@ -200,7 +213,7 @@ int es_shape_stem(const es_stem_args* args, es_stream stream);
  * ---------------------------------------------------------------------------------------- */
 enum {
     ES_OP_LINEAR = 1, ES_OP_DDPM = 2, ES_OP_DDIM = 3, ES_OP_COPY = 4, ES_OP_CONV = 5, ES_OP_GN = 6,
-    ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11,
+    ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_VQ = 12,
     ES_OP_FORK = 13, ES_OP_JOIN = 14
 };
 typedef struct es_copy_args { void* dst; const void* src; size_t bytes; } es_copy_args;
@@ -211,7 +224,7 @@ typedef struct es_op {
     union {
         es_linear_args linear; es_update_args update; es_copy_args copy; es_conv_args conv;
         es_gn_args gn; es_ln_args ln; es_attn_args attn; es_geglu_args geglu; es_tocl_args tocl;
-        es_stem_args stem;
+        es_stem_args stem; es_vq_args vq;
     } u;
 } es_op;
 

@@ -299,7 +299,7 @@ def _vqvae(ch, n_embed):
 
 
 def case_vqvae():
-    for tag, ch, ne, B in (('tiny', 16, 64, 2), ('full', 64, 8192, 1)):
+    for tag, ch, ne, B in (('tiny', 32, 64, 2), ('full', 64, 8192, 1)):
         vq = _vqvae(ch, ne)
         fill(vq, 'vqvae_%s.' % tag)
         z = rnd((B, 3, 16, 16, 16), 71, 0.6)
@@ -317,21 +317,11 @@ def case_scene_e2e():
     import random
     tmp = tempfile.mkdtemp(prefix='golden_e2e_')
     # tiny VQ-VAE checkpoint file required at construction (model/model_utils.py:21)
-    vq = _vqvae(16, 64)
+    vq = _vqvae(32, 64)
     fill(vq, 'e2e.vqvae.')
     vq_path = os.path.join(tmp, 'vq.pth')
     torch.save(vq.state_dict(), vq_path)
-    opt = escfg.default_diff_opt(device='cpu', time_num=100, logs_dir=tmp)
-    opt.hyper.isTrain = False
-    opt.layout_branch.denoiser_kwargs = escfg.layout_denoiser_kwargs(128)
-    opt.layout_branch.denoiser_kwargs.concat_dim = 128
-    opt.layout_branch.denoiser_kwargs.crossattn_dim = 128
-    df = escfg.shape_df_conf(32)
-    opt.shape_branch.df_cfg = df
-    vqc = escfg.vqvae_conf(16)
-    vqc.model.params.n_embed = 64
-    opt.shape_branch.vq_cfg = vqc
-    opt.shape_branch.vq_ckpt = vq_path
+    opt = escfg.tiny_diff_opt(device='cpu', logs_dir=tmp, vq_ckpt=vq_path)
     opt.misc.debug = 0
     import model.networks.diffusion_shape.echo2shape as e2s
     e2s.init_mesh_renderer = lambda **k: None
@@ -342,7 +332,7 @@ def case_scene_e2e():
     for typ in ('echoscene', 'echolayout'):
         m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
                    gconv_pooling='avg', with_angles=True, clip=True, separated=False)
-        fill(m.diff, 'e2e.diff.')
+        synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), seed=0, prefix='e2e.diff.')
         if typ == 'echoscene':
             fill(m.diff.ShapeDiff.df, 'e2e.shape_df.')
             m.diff.ShapeDiff.ddim_steps = 4
@@ -354,18 +344,27 @@ def case_scene_e2e():
         noise1 = synth.shape_noise(seed=7)
         calls = {'n': 0}
 
-        # inject both loops' noise through torch.randn (p_sample_loop_sg's default noise_fn and
-        # rel2shape's single shared latent noise)
+        # inject both loops' noise: the layout loop's ``noise_fn=torch.randn`` default is bound at import time,
+        # so it is overridden on the reference's own DiffusionPoint.gen_samples_sg; rel2shape's single shared
+        # latent noise is drawn through the global torch.randn at call time.
+        import model.networks.diffusion_layout.diffusion_ddpm as dd
+        _orig_gen = dd.DiffusionPoint.gen_samples_sg
+
+        def noise_fn(size, dtype, device):
+            i = calls['n']
+            calls['n'] += 1
+            return noise[i].clone()
+
+        def gen(self, shape, device, obj_embed, triples=None, condition=None, noise_fn_=None, clip_denoised=True,
+                keep_running=False, **kw):
+            return _orig_gen(self, shape, device, obj_embed, triples, condition=condition, noise_fn=noise_fn,
+                             clip_denoised=clip_denoised, keep_running=keep_running)
+        dd.DiffusionPoint.gen_samples_sg = gen
         _randn = torch.randn
 
         def randn(*a, **k):
             size = k.get('size', a[0] if len(a) == 1 and not isinstance(a[0], int) else a)
-            size = tuple(size)
-            if size == (O, 8):
-                i = calls['n']
-                calls['n'] += 1
-                return noise[i].clone()
-            if size == (1, 3, 16, 16, 16):
+            if tuple(size) == (1, 3, 16, 16, 16):
                 return noise1.clone()
             return _randn(*a, **k)
         torch.randn = randn
@@ -374,6 +373,8 @@ def case_scene_e2e():
                 d = m.sample_box_and_shape(objs, triples, tf, rf, gen_shape=(typ == 'echoscene'))
         finally:
             torch.randn = _randn
+            dd.DiffusionPoint.gen_samples_sg = _orig_gen
+        assert calls['n'] == 101, calls
         for k, v in d.items():
             if v is None:
                 continue

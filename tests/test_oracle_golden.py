@@ -140,3 +140,31 @@ def test_vqvae_decode(tag):
     assert tuple(sdf.shape[2:]) == (64, 64, 64)
     _close(sdf[:, :, ::4, ::4, ::4], g['sdf_sub'], 1e-4)
     assert abs(sdf.double().abs().sum().item() - g['sdf_abs'].item()) < 1e-4 * g['sdf_abs'].item()
+
+
+def test_scene_e2e_tiny_oracle_vs_reference_api():
+    """Whole boundary on the CPU oracle vs the reference's own ``SGDiff.sample_box_and_shape`` (tiny widths):
+    setup GCNs -> 100-step layout loop -> rel_s_mlp -> 4-step DDIM -> VQ-VAE decode."""
+    from echoscene_amd.model.scene import SGDiff
+    g = load_golden('scene_e2e_tiny')
+    objs, triples = g['objs'], g['triples']
+    O = objs.shape[0]
+    tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
+    for typ in ('echoscene', 'echolayout'):
+        m = SGDiff(typ, escfg.tiny_diff_opt('cpu'), synth.VOCAB, residual=True, with_angles=True)
+        sd = seeded_state_dict(m.diff, 'e2e.diff.')
+        oe, latent_m, _ = orc.scene_setup(sd, objs, triples, tf, rf, model_type=typ)
+        lsd = {k[len('LayoutDiff.df.model.'):]: v for k, v in sd.items() if k.startswith('LayoutDiff.df.model.')}
+        x = orc.layout_sample_loop(lsd, oe, triples, synth.layout_noise(O, 8, 100, seed=7), time_num=100)
+        _close(x[:, 0:3], g[typ + '_sizes'], 2e-4)
+        _close(x[:, 3:6], g[typ + '_translations'], 2e-4)
+        _close(x[:, 6:8], g[typ + '_angles'], 2e-4)
+        if typ == 'echoscene':
+            uc = orc.rel_s(sd, oe)
+            dsd = seeded_state_dict(m.diff.ShapeDiff.df, 'e2e.shape_df.')
+            dsd = {k[len('diffusion_net.'):]: v for k, v in dsd.items()}
+            z = orc.shape_sample_loop(dsd, uc, triples, synth.shape_noise(seed=7), S=4)
+            vsd = seeded_state_dict(m.diff.ShapeDiff.vqvae, 'e2e.vqvae.')
+            sdf = orc.vqvae_decode_no_quant(vsd, z)
+            assert tuple(sdf.shape) == (O, 1, 64, 64, 64)
+            _close(sdf[:, :, ::4, ::4, ::4], g['echoscene_shapes'], 2e-3)
