@@ -8,9 +8,10 @@ box loop (BASELINE configs[1]); with ``--workload full`` one layout step + one D
 over the same O objects (the metric's "layout+SDF" step; needs the volume path).
 Inputs (weights, graph, noise tables) are resident in HBM before the timed region starts.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank samples its own
-scene (the path shards over scenes/objects with no data-path collective -> weak scaling);
-value = total steps of all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI): ONE scene whose objects are
+block-partitioned over the ranks (the per-object shape UNet is 99.98 % of the step FLOPs); each DDIM step
+exchanges the 64-d conv-pool codes with one all-gather ("echo" message passing), the layout branch is
+replicated.  Strong scaling: value = steps of that one scene / max-over-ranks time.
 """
 import argparse
 import json
@@ -40,14 +41,14 @@ def build_layout(dev, O, seed):
     return net, den, obj_embed, triples
 
 
-def build_shape(dev, O, seed, triples):
+def build_shape(dev, O, seed, triples, rank=0, world=1):
     from echoscene_amd import synth, config as escfg
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     conf = escfg.shape_df_conf(224)
     df = DiffusionUNet(conf.unet.params, conditioning_key='crossattn')
     synth.seeded_fill_(df, prefix='bench.shape.')
-    den = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev)
+    den = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev, rank=rank, world=world)
     uc = torch.randn(O, 1, 1280, generator=torch.Generator().manual_seed(seed + 1))
     return df, den, uc
 
@@ -105,7 +106,9 @@ def main():
 
     O = a.nodes
     full = a.workload == 'full'
-    net, den, obj_embed, triples = build_layout(dev, O, seed=100 + rank)
+    # N > 1: ONE scene, its objects block-partitioned over the ranks (strong scaling);
+    # the layout branch (1 % of the work, couples all nodes every step) is replicated on every rank.
+    net, den, obj_embed, triples = build_layout(dev, O, seed=100)
     use_graph = not a.no_graph
     # untimed warm-up (also builds the plans and captures the graphs)
     den.sample(obj_embed, triples, noise=None, n_steps=max(a.warmup, 1), use_graph=use_graph)
@@ -113,8 +116,9 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O, 100 + rank, triples)
-        sden.sample(uc, triples, noise1=None, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
+        df, sden, uc = build_shape(dev, O, 100, triples, rank, world)
+        noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+        sden.sample(uc, triples, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
         ss['x'].normal_()
     torch.cuda.synchronize()
@@ -133,7 +137,12 @@ def main():
     done = 0
     while full and done < a.steps:              # the DDIM loop is 100 iterations long
         n = min(a.steps - done, sden.S)
-        ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
+        if world == 1:
+            ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
+        else:                                   # per-step echo all-gather over RCCL (parallel.sharded_ddim_loop)
+            from echoscene_amd.parallel import sharded_ddim_loop
+            sden._cur, sden._use_graph = ss, use_graph
+            sharded_ddim_loop(sden, O, n, world)
         done += n
     ev[2].record()
     torch.cuda.synchronize()
@@ -151,24 +160,24 @@ def main():
 
     if rank == 0:
         ms_per_step = wall * 1e3 / a.steps
-        value = world * a.steps / wall
+        value = a.steps / wall
         T = int(triples.shape[0])
         lay = {'steps_per_s': round(a.steps / (lay_ms * 1e-3), 2), 'ms_per_step': round(lay_ms / a.steps, 4),
                'kernels_per_step': st['plan'].n_ops, 'weight_bytes_per_step': st['plan'].weight_bytes,
                'hbm_GBps_algorithmic': round(st['plan'].weight_bytes / (lay_ms * 1e-3 / a.steps) / 1e9, 1)}
         if full:
-            flops = ss['plan'].flops
+            flops = ss['plan'].flops          # this rank's share of the step
             ach = flops / (shp_ms * 1e-3 / a.steps) / 1e12
             out = {
                 'metric': 'denoising steps/sec (layout+SDF) for 32-node scene-graph, 64^3 SDF (3x16^3 latent), '
                           'full step = one DDPM layout step + one DDIM shape step over all objects',
                 'value': round(value, 4), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
                 'vs_baseline': None, 'dtype': 'f16 MFMA operands / f32 accumulate (shape UNet); f32 (layout, GCN)',
                 'data': 'synthetic',
                 'config': {'workload': 'EchoScene full (layout+SDF) %d-node synthetic graph (T=%d), 3x16^3 latent -> '
-                                       '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules, 1 scene per GPU'
-                                       % (O, T), 'hip_graph': use_graph, 'layout': lay,
+                                       '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules; 1 scene, objects sharded over %d GPU(s)'
+                                       % (O, T, world), 'hip_graph': use_graph, 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
                                      'kernels_per_step': ss['plan'].n_ops,
@@ -182,7 +191,7 @@ def main():
             out = {
                 'metric': 'denoising steps/sec (layout box-denoiser loop, 32-node scene graph, 1000-step DDPM)',
                 'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-                'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'weak',
+                'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'strong',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'configs[1]: EchoLayout box diffusion, %d-node synthetic graph (T=%d triples), '
                                        '1000-step DDPM, HIP denoiser + graph conv' % (O, T),

@@ -1,0 +1,49 @@
+"""Multi-GPU sharding of the shape branch: one process per GPU (torch.distributed; backend "nccl"
+is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference has no multi-GPU sampling path; this is new design
+(SURVEY.md section 8(e)): objects of one scene are block-partitioned over the ranks.  Each object's
+UNet3D forward depends on the other objects only through the 64-d conv-pool code of their current
+latents that feeds the shape GCN ("echo" message passing, openai_model_3d.py:800-814), so the only
+per-step exchange is an all-gather of [O_local, 64] floats (8 KB per step at O=32), after which
+every rank runs the tiny GCN redundantly on the full graph.  At the end the latents (or decoded
+SDFs) are all-gathered.  Results are identical to the single-GPU run because every kernel treats
+objects independently and the GCN is computed on the full graph on every rank.
+"""
+import torch
+
+
+def partition(num_objects, world, rank):
+    """Contiguous block partition with equal padded block size.  Returns (lo, hi, block)."""
+    block = (num_objects + world - 1) // world
+    lo = min(rank * block, num_objects)
+    hi = min(lo + block, num_objects)
+    return lo, hi, block
+
+
+def all_gather_rows(local, num_rows, world, group=None):
+    """All-gather row blocks of a [rows_local, C] tensor into [num_rows, C] (blocks padded to equal size)."""
+    import torch.distributed as dist
+    block = (num_rows + world - 1) // world
+    C = local.shape[1:]
+    pad = torch.zeros((block,) + tuple(C), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * block,) + tuple(C), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:num_rows]
+
+
+def sharded_ddim_loop(backend, num_objects, n_steps, world, group=None):
+    """The DDIM loop with the per-step echo exchange.
+
+    ``backend`` provides (HIP: samplers.ShapeDenoiser shard; tests: an oracle-based shard):
+        codes_local(i)        -> [O_local, 64] conv-pool codes of this rank's current latents
+        step(i, codes_all)    -> advance this rank's latents by DDIM iteration i given all objects' codes
+        latents_local()       -> [O_local, C, D, H, W]
+    Returns the full latents [O, C, D, H, W] on every rank."""
+    for i in range(n_steps):
+        cl = backend.codes_local(i)
+        ca = all_gather_rows(cl, num_objects, world, group) if world > 1 else cl
+        backend.step(i, ca)
+    zl = backend.latents_local()
+    return all_gather_rows(zl, num_objects, world, group) if world > 1 else zl

@@ -17,15 +17,16 @@ from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, Op
 class View:
     """Pointer + leading dimension into a device matrix (column slices without copies)."""
 
-    def __init__(self, t, col=0, ld=None, width=None):
+    def __init__(self, t, col=0, ld=None, width=None, row=0):
         self.t = t
         self.col = col
+        self.row = row
         self.ld = (t.shape[-1] if t.dim() > 1 else 0) if ld is None else ld
         self.width = (t.shape[-1] - col) if width is None else width
 
     @property
     def ptr(self):
-        return self.t.data_ptr() + 4 * self.col
+        return self.t.data_ptr() + 4 * (self.col + self.row * self.ld)
 
 
 def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=None, step_stride=0, width=None):

@@ -188,9 +188,18 @@ class VolBuilderMixin:
         return self._push(hip.OP_STEM, 'stem', a)
 
 
-def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16)):
-    """One UNet3DModel.forward: x f32 [O,3,D,H,W] (NCDHW) -> eps_out f32 [O,3,D,H,W]."""
-    O, mc, E, gdim = g.O, w.mc, 4 * w.mc, 64
+def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None):
+    """One UNet3DModel.forward: x f32 [Ol,3,D,H,W] (NCDHW) -> eps_out f32 [Ol,3,D,H,W].
+
+    Object sharding (multi-GPU): this rank owns objects [lo, hi) of the O-node graph; x / eps_out hold only
+    those.  The per-object vector ops (time MLP, GCN over the FULL graph, projections) are computed for all O
+    rows on every rank -- they are ~0.1 % of the FLOPs -- while every voxel op runs on the local objects only.
+    The one cross-rank dependency is the conv-pool stem code of the other ranks' objects (the "echo"): the ops
+    up to ``b.split`` produce this rank's codes, the caller all-gathers them into ``objbuf`` and runs the rest."""
+    Ofull, mc, E, gdim = g.O, w.mc, 4 * w.mc, 64
+    hi = Ofull if hi is None else hi
+    Ol = hi - lo
+    O = Ofull
     D0, H0, W0 = dims
     V0 = D0 * H0 * W0
     f16 = torch.float16
@@ -203,9 +212,16 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16))
     Dobj = ucw + gdim + (gdim if w.enable_t_emb else 0)
     objbuf = b.buf(O, Dobj)
     objbuf[:, :ucw].copy_(uc_dev)
-    code512 = b.buf(O, 512)
-    b.stem(x, w.stem, b.buf(O, 32 * 512), code512, O)
-    b.linear([seg(View(code512))], w.stem_lin, O, View(objbuf, col=ucw, ld=Dobj, width=gdim))
+    code512 = b.buf(Ol, 512)
+    b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
+    if Ol == Ofull:
+        b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
+        b.codes_local = None
+    else:
+        b.codes_local = b.buf(Ol, gdim)
+        b.linear([seg(View(code512))], w.stem_lin, Ol, View(b.codes_local))
+    b.split = len(b.ops)                       # <- all-gather point of the multi-GPU loop
+    b.code_cols = (ucw, gdim)
     if w.enable_t_emb:
         b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
     pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
@@ -224,6 +240,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16))
 
     # ---- volume path ----
     state = dict(h=None, C=0, dims=dims, last_op=None, h16=None)
+    O = Ol                                     # ---- from here on: local objects only ----
 
     def V_(dm):
         return dm[0] * dm[1] * dm[2]
@@ -259,7 +276,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16))
                 raw = b.buf(M, cin, dtype=f16) if 'skip' in d else None
                 b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
                 h1 = b.buf(M, cout)
-                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), out_f32=h1)
+                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=w.emb_all.N, width=cout, row=lo), out_f32=h1)
                 y2 = b.buf(M, cout, dtype=f16)
                 b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
                 o = b.buf(M, cout)
@@ -285,7 +302,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16))
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
                 t2 = b.buf(M, Cc)
-                b.conv(at, d['o1'], O, dm, rowvec=cavo[name], res=t0, out_f32=t2)
+                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, row=lo), res=t0, out_f32=t2)
                 l3 = b.buf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
                 gl = b.buf(M, 8 * Cc)

@@ -105,10 +105,13 @@ class LayoutDenoiser:
 
 class ShapeDenoiser:
     """UNet3DModel + DDIM sampling on the HIP path (loop B of SURVEY.md section 3.1):
-    ``EchoToShape.rel2shape`` without the VQ-VAE decode (echo2shape.py:484-521)."""
+    ``EchoToShape.rel2shape`` without the VQ-VAE decode (echo2shape.py:484-521).
 
-    def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16)):
-        """df: DiffusionUNet holder; model_params: df_conf.model.params (linear_start/end, timesteps)."""
+    ``rank`` / ``world``: object sharding over GPUs (echoscene_amd/parallel.py).  world == 1 runs the whole
+    step as one hipGraph; world > 1 splits each step at the echo all-gather."""
+
+    def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
+                 group=None):
         self.device = device or torch.device('cuda')
         self.df = df
         net = df.diffusion_net
@@ -122,32 +125,60 @@ class ShapeDenoiser:
         self.z_shape = tuple(z_shape)
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
+        self.rank, self.world, self.group = rank, world, group
         self._plans = {}
 
     def _plan_for(self, uc, triples):
+        from .parallel import partition
         uc = uc.reshape(uc.shape[0], -1)
         O = uc.shape[0]
         key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
         st = self._plans.get(key)
         if st is None:
+            lo, hi, _ = partition(O, self.world, self.rank)
             g = GraphIndex(triples, O, self.device)
             b = Builder(self.device)
-            x = b.buf(O, *self.z_shape)
-            eps = b.buf(O, *self.z_shape)
+            x = b.buf(hi - lo, *self.z_shape)
+            eps = b.buf(hi - lo, *self.z_shape)
             step = b.buf(1, dtype=torch.int32, zero=True)
             ucd = b.dev(uc)
-            objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:])
+            objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
-            plan = b.finish()
-            b2 = Builder(self.device)
-            b2.ops, b2.keep, b2.tags = b.ops[:n_eps_ops], b.keep, b.tags
-            st = dict(plan=plan, eps_plan=b2.finish(), x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1])
+            st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
+                      codes_local=b.codes_local, code_cols=b.code_cols)
+
+            def sub(ops):
+                b2 = Builder(self.device)
+                b2.ops, b2.keep, b2.tags = ops, b.keep, b.tags
+                b2.weight_bytes, b2.flops = b.weight_bytes, b.flops
+                return b2.finish()
+            st['plan'] = b.finish()
+            st['eps_plan'] = sub(b.ops[:n_eps_ops])
+            if self.world > 1:
+                st['stem_plan'] = sub(b.ops[:b.split])
+                st['main_plan'] = sub(b.ops[b.split:])
             self._plans = {key: st}
         st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
         return st
 
+    # -- shard backend protocol of parallel.sharded_ddim_loop ------------------------------------------------
+    def codes_local(self, i):
+        st = self._cur
+        st['stem_plan'].run()
+        return st['codes_local']
+
+    def step(self, i, codes_all):
+        st = self._cur
+        c0, cw = st['code_cols']
+        st['objbuf'][:, c0:c0 + cw].copy_(codes_all)
+        st['main_plan'].sample(st['step'], int(i), 1, use_graph=self._use_graph)
+
+    def latents_local(self):
+        return self._cur['x']
+
     def eps(self, x, uc, triples, iteration):
+        assert self.world == 1
         st = self._plan_for(uc, triples)
         st['x'].copy_(x.to(self.device))
         st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
@@ -155,15 +186,19 @@ class ShapeDenoiser:
 
     def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True):
         """DDIM loop; ``noise1`` f32[1,C,D,H,W] is shared by all objects as in the reference
-        (echo2shape.py:507-510); None draws it on the device.  Returns latents [O,C,D,H,W]."""
+        (echo2shape.py:507-510); None draws it on the device (world > 1: pass it, or every rank draws its own).
+        Returns the latents of ALL objects [O,C,D,H,W] (all-gathered when sharded)."""
+        from .parallel import sharded_ddim_loop
         st = self._plan_for(uc, triples)
-        O = st['x'].shape[0]
         n_steps = self.S if n_steps is None else n_steps
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
-        st['x'].copy_(noise1.to(self.device).expand(O, *self.z_shape))
-        st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
-        return st['x'].clone()
+        st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
+        if self.world == 1:
+            st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
+            return st['x'].clone()
+        self._cur, self._use_graph = st, use_graph
+        return sharded_ddim_loop(self, st['O'], n_steps, self.world, self.group).clone()
 
 
 class VQDecoder:

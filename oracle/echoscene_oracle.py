@@ -291,18 +291,27 @@ def shape_stem(sd, x):
 
 
 def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
-                   enable_t_emb=True, nm=EXACT, trace=None):
-    """sd: keys of UNet3DModel (i.e. without the 'diffusion_net.' prefix)."""
+                   enable_t_emb=True, nm=EXACT, trace=None, code_all=None, rows=None):
+    """sd: keys of UNet3DModel (i.e. without the 'diffusion_net.' prefix).
+
+    ``code_all`` / ``rows`` (test support for the multi-GPU sharding, echoscene_amd/parallel.py): x holds only
+    the objects ``rows`` of the graph; the conv-pool codes of ALL objects are supplied (all-gathered) so the
+    GCN runs on the full graph, and the context rows of the local objects are kept."""
     mc = sd['time_embed.0.weight'].shape[1]
     t_emb = timestep_embedding(timesteps, mc)
     emb = _linear(sd, 'time_embed.2', F.silu(_linear(sd, 'time_embed.0', t_emb)))
     if 'shape_code_graph_cov.gconvs.0.net1.0.weight' in sd:           # messsage_passing
         edges, p = _edges(triples)
-        code = shape_stem(sd, x)
+        code = shape_stem(sd, x) if code_all is None else code_all
         obj = torch.cat([obj_embed.squeeze(1), code], dim=1)
+        emb_full = emb
+        if rows is not None:             # time embedding rows for every object of the graph (all share t)
+            emb_full = emb[:1].expand(obj.shape[0], -1)
         if enable_t_emb:
-            obj = torch.cat([obj, _linear(sd, 'shape_time_emb', emb)], dim=1)
+            obj = torch.cat([obj, _linear(sd, 'shape_time_emb', emb_full)], dim=1)
         ctx, _ = gcn_net(sd, 'shape_code_graph_cov', obj, sd['pred_embeddings.weight'][p], edges)
+        if rows is not None:
+            ctx = ctx[rows]
         context = ctx.unsqueeze(1)       # "we dont use the previous context" (:843-844)
         if trace is not None:
             trace.update(emb=emb, ctx=ctx, code=code)
