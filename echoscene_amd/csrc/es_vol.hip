@@ -13,6 +13,7 @@
 //     operand of the next contraction; bias / time-embedding / residual adds are fused into the
 //     contraction epilogue.
 #include "es_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -23,19 +24,32 @@ __device__ __forceinline__ int f_swz(int row) { return (0x1320 >> (((row >> 2) &
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_VT = 64;
 
+// 4 channels per thread (16-B loads), 64 voxels per workgroup, then channel -> group reduction in LDS.
 __global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* part) {
     // part: [O][ntiles][groups][2]
-    __shared__ float ssum[2048], ssq[2048];
+    __shared__ float ssum4[4][2048], ssq4[4][2048];       // per voxel-row lane partials (fixed-order combine: deterministic)
+    float* ssum = ssum4[0];
+    float* ssq = ssq4[0];
     const int o = blockIdx.y, tile = blockIdx.x, C = a.C1 + a.C2;
     const int v0 = tile * GN_VT;
     const int nv = min(GN_VT, a.V - v0);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    const int c4n = C >> 2;
+    const int CX = 64;                                   // 64 lanes span 256 channels per pass
+    const int cx = threadIdx.x & (CX - 1), vy = threadIdx.x >> 6;        // 4 voxel rows in flight
+    for (int c4 = cx; c4 < c4n; c4 += CX) {
+        const int c = c4 * 4;
         const float* src; int ld, cc;
         if (c < a.C1) { src = a.x1; ld = a.C1; cc = c; } else { src = a.x2; ld = a.C2; cc = c - a.C1; }
         const float* p = src + ((long)o * a.V + v0) * ld + cc;
-        float s = 0.f, q = 0.f;
-        for (int v = 0; v < nv; ++v) { const float x = p[(long)v * ld]; s += x; q += x * x; }
-        ssum[c] = s; ssq[c] = q;
+        f4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+        for (int v = vy; v < nv; v += 4) { const f4 x = *(const f4*)(p + (long)v * ld); s += x; q += x * x; }
+        *(f4*)&ssum4[vy][c] = s;
+        *(f4*)&ssq4[vy][c] = q;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        ssum[c] = (ssum4[0][c] + ssum4[1][c]) + (ssum4[2][c] + ssum4[3][c]);
+        ssq[c] = (ssq4[0][c] + ssq4[1][c]) + (ssq4[2][c] + ssq4[3][c]);
     }
     __syncthreads();
     const int gs = C / a.groups;
@@ -47,9 +61,12 @@ __global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* p
     }
 }
 
-// Pass 2: finalize statistics (fixed order, double) and apply; 8 channels per thread -> 16-B f16 stores.
+// Pass 2: finalize statistics (fixed order, double), fold them with the affine into per-channel scale/shift in LDS,
+// then y = x*scale + shift (+SiLU/GELU) -> fp16.  Thread (tx, ty): 8 channels at 8*(tx + 32k), voxels ty + 8k:
+// no integer divisions in the streaming loop, 32-B reads / 16-B writes per thread.
 __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const float* part, int ntiles, int vox_per_block) {
     __shared__ float smean[64], srstd[64];
+    __shared__ float ssc[2048], ssh[2048];
     const int o = blockIdx.y, C = a.C1 + a.C2, gs = C / a.groups;
     if (threadIdx.x < a.groups) {
         double s = 0.0, q = 0.0;
@@ -65,32 +82,40 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
         srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
     __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / gs;
+        const float sc = srstd[g] * a.gamma[c];
+        ssc[c] = sc;
+        ssh[c] = a.beta[c] - smean[g] * sc;
+    }
+    __syncthreads();
     const int c8n = C >> 3;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int v0 = blockIdx.x * vox_per_block;
-    const int total = vox_per_block * c8n;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int vl = idx / c8n, c8 = idx - vl * c8n;
-        const int v = v0 + vl;
-        if (v >= a.V) break;
+    for (int c8 = tx; c8 < c8n; c8 += 32) {
         const int c = c8 * 8;
         const float* src; int ld, cc;
         if (c < a.C1) { src = a.x1; ld = a.C1; cc = c; } else { src = a.x2; ld = a.C2; cc = c - a.C1; }
-        const float* p = src + ((long)o * a.V + v) * ld + cc;
-        const f4 x0 = *(const f4*)p, x1 = *(const f4*)(p + 4);
-        float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        h8 y, r;
+        const f4 sc0 = *(const f4*)&ssc[c], sc1 = *(const f4*)&ssc[c + 4], sh0 = *(const f4*)&ssh[c], sh1 = *(const f4*)&ssh[c + 4];
+        for (int vl = ty; vl < vox_per_block; vl += 8) {
+            const int v = v0 + vl;
+            if (v >= a.V) break;
+            const float* p = src + ((long)o * a.V + v) * ld + cc;
+            const f4 x0 = *(const f4*)p, x1 = *(const f4*)(p + 4);
+            f4 y0 = x0 * sc0 + sh0, y1 = x1 * sc1 + sh1;
+            h8 y, r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / gs;
-            float t = (x[e] - smean[g]) * srstd[g] * a.gamma[c + e] + a.beta[c + e];
-            if (a.silu == 1) t = es_silu_fast(t);
-            else if (a.silu == 2) t = es_gelu(t);
-            y[e] = (_Float16)t;
-            r[e] = (_Float16)x[e];
+            for (int e = 0; e < 4; ++e) {
+                float t0 = y0[e], t1 = y1[e];
+                if (a.silu == 1) { t0 = es_silu_fast(t0); t1 = es_silu_fast(t1); }
+                else if (a.silu == 2) { t0 = es_gelu(t0); t1 = es_gelu(t1); }
+                y[e] = (_Float16)t0; y[4 + e] = (_Float16)t1;
+                r[e] = (_Float16)x0[e]; r[4 + e] = (_Float16)x1[e];
+            }
+            const long off = ((long)o * a.V + v) * C + c;
+            *(h8*)((_Float16*)a.y_f16 + off) = y;
+            if (a.raw_f16) *(h8*)((_Float16*)a.raw_f16 + off) = r;
         }
-        const long off = ((long)o * a.V + v) * C + c;
-        *(h8*)((_Float16*)a.y_f16 + off) = y;
-        if (a.raw_f16) *(h8*)((_Float16*)a.raw_f16 + off) = r;
     }
 }
 
@@ -178,26 +203,39 @@ __global__ __launch_bounds__(256) void k_stem1(const es_stem_args a) {
 }
 
 __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
-    // one thread per output [o][c=64][2][2][2]; pooling windows start at 0 and 4 (kernel 2, stride 4)
+    // 8 lanes per output [o][c=64][2][2][2] (each lane 4 of the 32 input channels, all 8 window positions);
+    // pooling windows start at 0 and 4 (kernel 2, stride 4)
     const long n = (long)a.O * 512;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gi = ((long)blockIdx.x * 256 + threadIdx.x);
+    const long i = gi >> 3;
+    const int sl = (int)(gi & 7);
     if (i >= n) return;
     const int pw = i & 1, ph = (i >> 1) & 1, pd = (i >> 2) & 1, c = (i >> 3) & 63;
     const long o = i >> 9;
     const float* x = a.scratch + o * 32 * 512;
     const float* w = a.w1 + c * 32 * 27;
-    float best = -INFINITY;
-    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
-        const int d = 4 * pd + dz, h = 4 * ph + dy, ww = 4 * pw + dx;
-        float s = a.b1[c];
-        for (int ci = 0; ci < 32; ++ci)
-            for (int kd = 0; kd < 3; ++kd) { const int id = d + kd - 1; if (id < 0 || id > 7) continue;
-                for (int kh = 0; kh < 3; ++kh) { const int ih = h + kh - 1; if (ih < 0 || ih > 7) continue;
-                    for (int kw = 0; kw < 3; ++kw) { const int iw = ww + kw - 1; if (iw < 0 || iw > 7) continue;
-                        s += x[ci * 512 + id * 64 + ih * 8 + iw] * w[ci * 27 + kd * 9 + kh * 3 + kw]; } } }
-        best = fmaxf(best, s);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int cj = 0; cj < 4; ++cj) {
+        const int ci = sl * 4 + cj;
+        for (int kd = 0; kd < 3; ++kd) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) {
+            const float wv = w[ci * 27 + kd * 9 + kh * 3 + kw];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int id = 4 * pd + (k >> 2) + kd - 1, ih = 4 * ph + ((k >> 1) & 1) + kh - 1, iw = 4 * pw + (k & 1) + kw - 1;
+                if (id >= 0 && id < 8 && ih >= 0 && ih < 8 && iw >= 0 && iw < 8) s[k] += x[ci * 512 + id * 64 + ih * 8 + iw] * wv;
+            }
+        }
     }
-    a.out[i] = best;       // i = o*512 + c*8 + pd*4 + ph*2 + pw  == nn.Flatten order of [O,64,2,2,2]
+    float best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = s[k];
+        v += __shfl_xor(v, 1, 8); v += __shfl_xor(v, 2, 8); v += __shfl_xor(v, 4, 8);
+        best = fmaxf(best, v + a.b1[c]);
+    }
+    if (sl == 0) a.out[i] = best;       // i = o*512 + c*8 + pd*4 + ph*2 + pw  == nn.Flatten order of [O,64,2,2,2]
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,14 +259,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// BM_ = 128 (wave tile 64 x 112) or 64 (wave tile 32 x 112); 4 waves as 2(M) x 2(N).
-template <int BM_>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw) {
-    constexpr int MI = BM_ / 32;                 // 16-row MFMA tiles per wave in M
-    constexpr int NA = BM_ / 64;                 // A glds per thread per stage
+// Workgroup = NW_ waves as (NW_/2)(M) x 2(N); tile BM_ x 224:
+//   <256, 8> wave tile 64 x 112 (16^3 and 16x8x8 levels: A+B bytes per flop -32 % vs <128,4>)
+//   <128, 4> wave tile 64 x 112
+//   < 64, 4> wave tile 32 x 112 (16x4x4 level: enough workgroups to cover the 256 CUs)
+template <int BM_, int NW_>
+__global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw_) {
+    int ncdhw = ncdhw_;
+    constexpr int NT = 64 * NW_;                 // threads
+    constexpr int WROWS = BM_ / (NW_ / 2);       // rows per wave
+    constexpr int MI = WROWS / 16;               // 16-row MFMA tiles per wave in M
+    constexpr int NA = BM_ * 4 / NT;             // A glds per thread per stage
+    constexpr int NB = BNP * 4 / NT;             // B glds per thread per stage
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NLOAD = NA + 4;                // glds per thread per stage (uniform across waves)
+    constexpr int NLOAD = NA + NB;               // glds per thread per stage (uniform across waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = ncdhw >> 8;                  // ablation switches (ES_CONV_DEBUG, tools/microbench_conv.py)
+    ncdhw &= 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.O * g.D * g.H * g.W;
@@ -240,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
     bool a_ok[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int p = tid + 256 * j;             // 16-B slot: row = p >> 2, physical chunk = p & 3
+        const int p = tid + NT * j;              // 16-B slot: row = p >> 2, physical chunk = p & 3
         const int row = p >> 2;
         a_lc[j] = (p & 3) ^ f_swz(row);
         const long m = m0 + row;
@@ -251,78 +298,93 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
         a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
         a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
     }
-    int b_lc[4], b_row[4];
-    bool b_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = tid + 256 * j;
-        b_row[j] = p >> 2;
-        b_lc[j] = (p & 3) ^ f_swz(b_row[j]);
-        b_ok[j] = (b_row[j] < BN) && (n0 + b_row[j] < a.N);
-    }
+    // B (weights) is pre-tiled on the host in exactly the LDS image order: one K step of one 224-column tile is a
+    // contiguous 16 KiB block, so every wave-level load is 1 KiB contiguous (8 full cache lines, no per-row addressing).
 
-    // ---- K-step generator state (for the tile being STAGED, which runs 2 steps ahead of compute) ----
+    // ---- K-step generator (for the tile being STAGED, which runs 2-3 steps ahead of compute) ----
+    // Order: channel chunk OUTER, 3x3x3 tap INNER.  Consecutive K steps then read the same 64-B channel chunk of
+    // voxels shifted by one tap, so the A operand is re-used out of L2 up to 27x (with taps outer the re-use distance
+    // is the whole channel sweep of all co-resident workgroups, > the 4 MiB L2, and every tap re-fetches from MALL).
     const int kch0 = a.Cin >> 5;
     const int nks0 = a.taps * kch0;
     const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
-    int st_phase = 0, st_tap = 0, st_c = 0;
-    const _Float16* a_src[NA];                   // source row start for the current (phase, tap); zero page if outside
-    bool a_in[NA];
-    const _Float16* b_src[4];                    // weight row start for the current phase
-    auto set_phase = [&]() {
+    // split-K: this workgroup handles K steps [ks_begin, ks_end) of the nks steps
+    const int S = gridDim.z;
+    const int ks_begin = (int)((long)nks * blockIdx.z / S), ks_end = (int)((long)nks * (blockIdx.z + 1) / S);
+    const int nloc = ks_end - ks_begin;
+    int st_phase = ks_begin >= nks0 ? 1 : 0;
+    int st_tap = st_phase ? 0 : ks_begin % a.taps;
+    int st_c = st_phase ? (ks_begin - nks0) * BK : (ks_begin / a.taps) * BK;
+    // per-row: pointer to the centre tap (+ this lane's 16-B chunk) and a 27-bit validity mask of the taps
+    const _Float16* a_ctr[NA];
+    unsigned a_msk[NA];
+    const _Float16* b_base;
+    const bool uniform_delta = (a.mode == ES_CONV_SAME || a.mode == ES_CONV_DOWN_HW);
+    auto set_phase = [&]() __attribute__((always_inline)) {
         const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
-        const long rowlen = st_phase ? (long)a.Cin2 : (long)a.taps * a.Cin;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b_src[j] = b_ok[j] ? Wg + (long)(n0 + b_row[j]) * rowlen + b_lc[j] * 8 : zero_page;
-    };
-    auto set_tap = [&]() {
+        const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
+        b_base = Wg + ((long)blockIdx.y * nks_ph) * (BNP * BK) + tid * 8;
         const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
         const int Cin = st_phase ? a.Cin2 : a.Cin;
         const int mode = st_phase ? (int)ES_CONV_SAME : a.mode;
         const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
-        const int Di = (mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
-        int kd = 0, kh = 0, kw = 0;
-        if (!st_phase && a.taps == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
+        const int ntap = st_phase ? 1 : a.taps;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int id = a_d[j] + kd;
-            int ih, iw;
-            bool ok = a_ok[j] && id >= 0 && id < g.D;
-            if (mode == ES_CONV_UP_DHW) id >>= 1;
-            if (mode == ES_CONV_DOWN_HW) {
-                ih = 2 * a_h[j] + kh; iw = 2 * a_w[j] + kw;
-                ok = ok && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+            const int ch = mode == ES_CONV_DOWN_HW ? 2 * a_h[j] : a_h[j];
+            const int cw = mode == ES_CONV_DOWN_HW ? 2 * a_w[j] : a_w[j];
+            a_ctr[j] = Ag + ((((long)a_o[j] * g.D + a_d[j]) * Hi + ch) * Wi + cw) * Cin + a_lc[j] * 8;
+            unsigned m = 0;
+            if (ntap == 1) {
+                m = a_ok[j] ? 1u : 0u;
             } else {
-                ih = a_h[j] + kh; iw = a_w[j] + kw;
-                ok = ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                if (mode == ES_CONV_UP_HW || mode == ES_CONV_UP_DHW) { ih >>= 1; iw >>= 1; }
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const int id = a_d[j] + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
+                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+                    m |= (ok ? 1u : 0u) << t;
+                }
             }
-            a_in[j] = ok;
-            a_src[j] = ok ? Ag + ((((long)a_o[j] * Di + id) * Hi + ih) * Wi + iw) * Cin + a_lc[j] * 8 : zero_page;
+            a_msk[j] = m;
         }
     };
     set_phase();
-    set_tap();
 
-    auto stage = [&](int b) {                    // issue the glds of the next K step into ring slot b, then advance
+    auto stage = [&](int b) __attribute__((always_inline)) {   // issue the glds of the next K step into ring slot b, then advance
         char* As = smem + b * STAGE_BYTES;
         char* Bs = As + A_BYTES;
-        const int boff = st_phase ? st_c : st_tap * a.Cin + st_c;
+        const int Cin = st_phase ? a.Cin2 : a.Cin;
+        const int ntap = st_phase ? 1 : a.taps;
+        const long boff = (long)((st_c >> 5) * ntap + st_tap) * (BNP * BK);
+        if (st_phase || uniform_delta) {
+            int kd = 0, kh = 0, kw = 0;
+            if (ntap == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
+            const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+            const long delta = ((long)(kd * Hi + kh) * Wi + kw) * Cin + st_c;          // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
-            glds16(a_in[j] ? a_src[j] + st_c : zero_page, As + (wave * 64 + 256 * j) * 16);
+            for (int j = 0; j < NA; ++j)
+                glds16((((a_msk[j] >> st_tap) & 1u) && !(dbg & 16)) ? a_ctr[j] + delta : zero_page, As + (wave * 64 + NT * j) * 16);
+        } else {                                 // nearest-upsample modes: source index is not a uniform shift
+            const _Float16* Ag = (const _Float16*)a.a;
+            const int kd = st_tap / 9 - 1, kh = (st_tap / 3) % 3 - 1, kw = st_tap % 3 - 1;
+            const int Di = (a.mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            glds16(b_ok[j] ? b_src[j] + boff : zero_page, Bs + (wave * 64 + 256 * j) * 16);
-        st_c += BK;
-        if (st_c == (st_phase ? a.Cin2 : a.Cin)) {
-            st_c = 0;
-            ++st_tap;
-            if (!st_phase && st_tap == a.taps) {
-                if (a.a2) { st_phase = 1; st_tap = 0; set_phase(); set_tap(); }
-            } else if (!st_phase) {
-                set_tap();
+            for (int j = 0; j < NA; ++j) {
+                int id = a_d[j] + kd, ih = a_h[j] + kh, iw = a_w[j] + kw;
+                const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                if (a.mode == ES_CONV_UP_DHW) id >>= 1;
+                ih >>= 1; iw >>= 1;
+                glds16(ok ? Ag + ((((long)a_o[j] * Di + id) * g.Hi + ih) * g.Wi + iw) * Cin + a_lc[j] * 8 + st_c : zero_page,
+                       As + (wave * 64 + NT * j) * 16);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            glds16(b_base + ((dbg & 32) ? 0 : boff) + NT * 8 * j, Bs + (wave * 64 + NT * j) * 16);
+        if (++st_tap == ntap) {
+            st_tap = 0;
+            st_c += BK;
+            if (st_c == Cin && !st_phase && a.a2) { st_phase = 1; st_c = 0; set_phase(); }
         }
     };
 
@@ -333,24 +395,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
         for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int i16 = lane & 15, q = lane >> 4;
-    stage(0);
-    if (nks > 1) stage(1);
-    for (int ks = 0; ks < nks; ++ks) {
-        // tile ks must have landed; tile ks+1 (NLOAD loads per thread) may stay in flight across the barrier
-        if (ks + 1 < nks) {
-            if (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();            // also: every wave finished reading ring slot (ks+2)%3 == (ks-1)%3
-        if (ks + 2 < nks) stage((ks + 2) % NSTAGE);
-        const char* As = smem + (ks % NSTAGE) * STAGE_BYTES;
+    // Software pipeline: while the MFMAs of K step ks run, the fragments of step ks+1 are read from LDS into
+    // a second register set and tiles ks+2, ks+3 are in flight from HBM/L2 (3-slot LDS ring).
+    auto load_frags = [&](int slot, h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline)) {
+        const char* As = smem + slot * STAGE_BYTES;
         const char* Bs = As + A_BYTES;
-        h8 af[MI], bfr[7];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row = wm * (BM_ / 2) + i * 16 + i16;
+            const int row = wm * WROWS + i * 16 + i16;
             af[i] = *(const h8*)(As + row * 64 + ((q ^ f_swz(row)) << 4));
         }
 #pragma unroll
@@ -358,35 +410,95 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const es_conv_args a, cons
             const int row = wn * 112 + j * 16 + i16;
             bfr[j] = *(const h8*)(Bs + row * 64 + ((q ^ f_swz(row)) << 4));
         }
+    };
+    auto mma = [&](h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 7; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    };
+    // tiles ks+1 and ks+2 are in flight while tile ks is consumed (an additional register-level double buffer of the
+    // fragments was measured slower: LDS latency is not what this loop waits for)
+    {
+        h8 af[MI], bfr[7];
+        stage(0);
+        if (nloc > 1) stage(1);
+        for (int ks = 0; ks < nloc; ++ks) {
+            if (ks + 1 < nloc) {
+                if (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (NLOAD == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();        // also: every wave finished reading ring slot (ks+2)%3 == (ks-1)%3
+            if (ks + 2 < nloc && !(dbg & 1)) stage((ks + 2) % NSTAGE);
+            if (!(dbg & 8)) load_frags(ks % NSTAGE, af, bfr);
+            if (!(dbg & 2)) mma(af, bfr);
+        }
     }
 
-    // ---- epilogue: D[row=(lane>>4)*4+r][col=lane&15] ----
+    // ---- epilogue ----
+    // MFMA D layout: lane holds D[row = q*4 + r][col = i16].  A direct store is 112 four-byte stores (+112 residual
+    // loads) per wave -- measured 25 % of the kernel at the 16^3 level.  Each 16-row slab is therefore transposed
+    // through LDS (the ring is free now) so that a lane owns 4 consecutive columns: 16-byte loads and stores.
+    if (dbg & 4) { if (acc[0][0][0] == 123.456f) a.out_f32[0] = 1.f; return; }
     const int V = g.D * g.H * g.W;
+    __syncthreads();                                          // all waves done with the ring
+    float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
+    const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
+    float* part = S > 1 ? (float*)a.workspace + (long)blockIdx.z * M * a.N : nullptr;   // [S][M][N] partial sums
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        if (vec_ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + wm * (BM_ / 2) + i * 16 + q * 4 + r;
-            if (m >= M) continue;
-            const long o = m / V;
+            for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int n = n0 + wn * 112 + j * 16 + i16;
-                if (n >= a.N) continue;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[n];
-                if (a.rowvec) v += a.rowvec[o * a.rowvec_ld + n];
-                if (a.res) v += a.res[m * a.out_ld + n];
-                if (ncdhw) {
-                    a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
-                } else {
-                    if (a.out_f32) a.out_f32[m * a.out_ld + n] = v;
-                    if (a.out_f16) ((_Float16*)a.out_f16)[m * a.out_ld + n] = (_Float16)v;
+                for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
+            __builtin_amdgcn_wave_barrier();
+            // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int idx = lane + 64 * t;
+                const int row = idx / 28, c4 = idx - row * 28;
+                const long m = m0 + wm * WROWS + i * 16 + row;
+                const int n = n0 + wn * 112 + c4 * 4;
+                if (m < M && n < a.N) {
+                    f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
+                    if (part) { *(f4*)&part[m * a.N + n] = v; continue; }
+                    if (a.bias) v += *(const f4*)&a.bias[n];
+                    if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
+                    if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
+                    if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = v;
+                    if (a.out_f16) {
+                        h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + wm * WROWS + i * 16 + q * 4 + r;
+                if (m >= M) continue;
+                const long o = m / V;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int n = n0 + wn * 112 + j * 16 + i16;
+                    if (n >= a.N) continue;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    if (a.rowvec) v += a.rowvec[o * a.rowvec_ld + n];
+                    if (a.res) v += a.res[m * a.out_ld + n];
+                    if (ncdhw) {
+                        a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
+                    } else {
+                        if (a.out_f32) a.out_f32[m * a.out_ld + n] = v;
+                        if (a.out_f16) ((_Float16*)a.out_f16)[m * a.out_ld + n] = (_Float16)v;
+                    }
                 }
             }
         }
@@ -590,6 +702,28 @@ __global__ __launch_bounds__(256) void k_vq_lookup(const es_vq_args a) {
     for (int c = 0; c < a.Cpad; ++c) out[c] = c < 3 ? (_Float16)a.lut[bi * 3 + c] : (_Float16)0.f;
 }
 
+
+// split-K reduction + epilogue: out = sum_z part[z] (fixed order) + bias + rowvec + res
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a, long M, int V, int S) {
+    const long n4 = M * (a.N >> 2);
+    const int N4 = a.N >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long m = i / N4;
+        const int n = (int)(i - m * N4) * 4;
+        const float* p = (const float*)a.workspace + m * a.N + n;
+        f4 v = *(const f4*)p;
+        for (int z = 1; z < S; ++z) v += *(const f4*)(p + (long)z * M * a.N);
+        if (a.bias) v += *(const f4*)&a.bias[n];
+        if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
+        if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
+        if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = v;
+        if (a.out_f16) {
+            h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
+        }
+    }
+}
+
 _Float16* g_zero_page = nullptr;
 
 int ilog2_exact(int v) {
@@ -609,7 +743,14 @@ int es_vol_init(void) {
     return 0;
 }
 
-extern "C" size_t es_pack_conv_f16_size(int N, int Cin, int taps) { return (size_t)((N + 15) / 16 * 16) * taps * Cin; }
+// Tiled weight image consumed by k_conv_mfma: [n-tile of 224][K step][1024 slots of 16 B] where slot p holds
+// row = p >> 2 (output channel within the tile, rows 224..255 are zero padding), physical 16-B chunk p & 3 =
+// logical chunk ^ swizzle(row); K step index = (channel chunk of 32) * taps + tap  (tap inner).
+static inline int h_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+extern "C" size_t es_pack_conv_f16_size(int N, int Cin, int taps) {
+    return (size_t)((N + BN - 1) / BN) * (size_t)(Cin / 32) * taps * (BNP * BK);
+}
 
 static inline uint16_t f32_to_f16_bits(float f) {
     _Float16 h = (_Float16)f;     // round-to-nearest-even, as torch .half()
@@ -618,15 +759,34 @@ static inline uint16_t f32_to_f16_bits(float f) {
     return u;
 }
 
-// h_w: [N][CinW][taps] (PyTorch conv weight flattened over kd,kh,kw) with CinW <= Cin (Cin = padded width)
+// h_w: [N][CinW][taps] (PyTorch conv weight flattened over kd,kh,kw); Cin = CinW rounded up to 32
 extern "C" int es_pack_conv_f16(const float* h_w, int N, int CinW, int taps, uint16_t* h_out) {
     const int Cin = (CinW + 31) / 32 * 32;
-    const int Np = (N + 15) / 16 * 16;
-    for (int n = 0; n < Np; ++n)
+    const int nt = (N + BN - 1) / BN, kch = Cin / 32;
+    for (int t = 0; t < nt; ++t)
+        for (int kc = 0; kc < kch; ++kc)
+            for (int tap = 0; tap < taps; ++tap) {
+                uint16_t* blk = h_out + ((size_t)(t * kch + kc) * taps + tap) * (BNP * BK);
+                for (int p = 0; p < BNP * 4; ++p) {
+                    const int row = p >> 2, lc = (p & 3) ^ h_swz(row);
+                    const int n = t * BN + row;
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = kc * 32 + lc * 8 + e;
+                        blk[p * 8 + e] = (row < BN && n < N && c < CinW)
+                                             ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + tap]) : 0;
+                    }
+                }
+            }
+    return 0;
+}
+
+// Row-major image [N][taps][Cin] for k_conv_small_n (N <= 4)
+extern "C" int es_pack_conv_rows_f16(const float* h_w, int N, int CinW, int taps, uint16_t* h_out) {
+    const int Cin = (CinW + 31) / 32 * 32;
+    for (int n = 0; n < N; ++n)
         for (int t = 0; t < taps; ++t)
             for (int c = 0; c < Cin; ++c)
-                h_out[((size_t)n * taps + t) * Cin + c] =
-                    (n < N && c < CinW) ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + t]) : 0;
+                h_out[((size_t)n * taps + t) * Cin + c] = c < CinW ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + t]) : 0;
     return 0;
 }
 
@@ -642,7 +802,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     if (a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW) { g.Hi = a->H / 2; g.Wi = a->W / 2; }
     g.lw = ilog2_exact(a->W); g.lh = ilog2_exact(a->H); g.ld = ilog2_exact(a->D);
     ES_REQUIRE(g.lw >= 0 && g.lh >= 0 && g.ld >= 0, "es_conv_mfma_f16: D,H,W must be powers of two (%d,%d,%d)", a->D, a->H, a->W);
-    const int ncdhw = a->out_ld < 0 ? 1 : 0;      // out_ld < 0 selects NCDHW fp32 output [O,N,V]
+    int ncdhw = a->out_ld < 0 ? 1 : 0;            // out_ld < 0 selects NCDHW fp32 output [O,N,V]
+    static const char* dbg_env = getenv("ES_CONV_DEBUG");
+    const int dbgf = dbg_env ? atoi(dbg_env) : 0;
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
     if (!g_zero_page) if (int rc = es_vol_init()) return rc;
     const long M = (long)a->O * a->D * a->H * a->W;
@@ -655,20 +817,48 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     }
     const int ntn = (a->N + BN - 1) / BN;
     // small-M layers (16x4x4 level): 64-row tiles double the number of workgroups (>= 1 per CU)
-    const bool small = ((M + 127) / 128) * ntn < 512;
+    // Tile / split choice by workgroup count (256 CUs x 2 resident workgroups):
+    //   >= 256 workgroups of 256 rows -> 8-wave 256x224 tiles;
+    //   otherwise 128x224 tiles, and when even those give < 512 workgroups (16x4x4 level: M = 8192) K is split
+    //   over S workgroups per tile (fixed-order reduction kernel, deterministic).
+    const long wg256 = ((M + 255) / 256) * ntn, wg128 = ((M + 127) / 128) * ntn;
+    const int nks = a->taps * (a->Cin / 32) + (a->a2 ? a->Cin2 / 32 : 0);
     static bool attr_set = false;
-    constexpr int LDS128 = NSTAGE * (128 * BK * 2 + BNP * BK * 2), LDS64 = NSTAGE * (64 * BK * 2 + BNP * BK * 2);
+    constexpr int LDS256 = NSTAGE * (256 * BK * 2 + BNP * BK * 2), LDS128 = NSTAGE * (128 * BK * 2 + BNP * BK * 2),
+                  LDS64 = NSTAGE * (64 * BK * 2 + BNP * BK * 2);
     if (!attr_set) {
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
     }
-    if (small) {
-        dim3 grid((unsigned)((M + 63) / 64), ntn);
-        hipLaunchKernelGGL(k_conv_mfma<64>, grid, dim3(256), LDS64, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+    hipStream_t st = (hipStream_t)stream;
+    int S = a->splitk;
+    const bool can_split = a->workspace && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0);
+    if (S < 0) {                                           // auto
+        S = 1;
+        if (can_split && wg256 < 256 && wg128 < 512) {
+            S = (int)((1536 + wg128 - 1) / wg128);         // ~3 rounds of 512 resident workgroups
+            if (S > 8) S = 8;
+            while (S > 1 && nks / S < 24) --S;
+        }
+    }
+    if (S <= 1 || !can_split) S = 1;
+    const int flags = ncdhw | (dbgf << 8);
+    if (wg256 >= 256 && S == 1) {
+        dim3 grid((unsigned)((M + 255) / 256), ntn, 1);
+        hipLaunchKernelGGL((k_conv_mfma<256, 8>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
+    } else if (wg128 >= 512 || S > 1) {
+        dim3 grid((unsigned)((M + 127) / 128), ntn, S);
+        hipLaunchKernelGGL((k_conv_mfma<128, 4>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
     } else {
-        dim3 grid((unsigned)((M + 127) / 128), ntn);
-        hipLaunchKernelGGL(k_conv_mfma<128>, grid, dim3(256), LDS128, (hipStream_t)stream, *a, g, g_zero_page, ncdhw);
+        dim3 grid((unsigned)((M + 63) / 64), ntn, 1);
+        hipLaunchKernelGGL((k_conv_mfma<64, 4>), grid, dim3(256), LDS64, st, *a, g, g_zero_page, flags);
+    }
+    if (S > 1) {
+        const long n4 = M * (a->N / 4);
+        const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
     }
     ES_CHECK_HIP(hipGetLastError());
     return 0;
@@ -682,7 +872,7 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     const int ntiles = (a->V + GN_VT - 1) / GN_VT;
     float* part = a->stats;      // caller-provided scratch of O*ntiles*groups*2 floats
     hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part);
-    const int vpb = 16;
+    const int vpb = 32;
     hipLaunchKernelGGL(k_gn_apply, dim3((a->V + vpb - 1) / vpb, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, vpb);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
@@ -726,7 +916,7 @@ extern "C" int es_latent_to_cl_f16(const float* x, int O, int C, int V, int Cpad
 extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
     const long n1 = (long)a->O * 32 * 512, n2 = (long)a->O * 512;
     hipLaunchKernelGGL(k_stem1, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
                 ('W', C.c_int32), ('Cin', C.c_int32), ('N', C.c_int32), ('taps', C.c_int32), ('mode', C.c_int32),
                 ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
                 ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
-                ('out_ld', C.c_int32)]
+                ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32)]
 
 
 class GNArgs(C.Structure):
@@ -112,6 +112,7 @@ EXPORTS = {
     'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'es_pack_conv_rows_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_groupnorm_vol': (C.c_int, [C.POINTER(GNArgs), C.c_void_p]),
     'es_layernorm_tokens': (C.c_int, [C.POINTER(LNArgs), C.c_void_p]),
     'es_attention_f16': (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),

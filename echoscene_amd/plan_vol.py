@@ -26,10 +26,15 @@ class PackedConv:
             raise ValueError('conv kernel must be 1x1x1 or 3x3x3')
         self.Cin = (cin + 31) // 32 * 32
         L = hip.lib()
-        n = L.es_pack_conv_f16_size(self.N, self.Cin, self.taps)
-        out = torch.empty(n, dtype=torch.int16)
-        hip.check(L.es_pack_conv_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())),
-                  'es_pack_conv_f16')
+        if self.N <= 4 and self.taps == 27:          # consumed by the direct small-N kernel
+            out = torch.empty(self.N * self.taps * self.Cin, dtype=torch.int16)
+            hip.check(L.es_pack_conv_rows_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps,
+                                              C.c_void_p(out.data_ptr())), 'es_pack_conv_rows_f16')
+        else:
+            n = L.es_pack_conv_f16_size(self.N, self.Cin, self.taps)
+            out = torch.empty(n, dtype=torch.int16)
+            hip.check(L.es_pack_conv_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())),
+                      'es_pack_conv_f16')
         self.w = out.to(device)
         self.b = None if b is None else b.detach().float().contiguous().to(device)
         self.weight_bytes = self.N * cin * self.taps * 2
@@ -136,6 +141,16 @@ class VolBuilderMixin:
         a.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
         a.out_f16 = out_f16.data_ptr() if out_f16 is not None else None
         a.out_ld = -1 if ncdhw else pc.N
+        # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
+        M = O * D * H * W
+        if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0:
+            need = 8 * M * pc.N
+            if getattr(self, '_ws', None) is None or self._ws.numel() < need:
+                self._ws = self.buf(need)
+                for op in self.ops:
+                    if op.kind == hip.OP_CONV and op.u.conv.splitk == -1:
+                        op.u.conv.workspace = self._ws.data_ptr()
+            a.workspace, a.splitk = self._ws.data_ptr(), -1
         self.keep += [pc, bt, skip]
         self.weight_bytes += pc.weight_bytes
         self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N

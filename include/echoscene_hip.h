@@ -124,7 +124,8 @@ enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW 
 
 typedef struct es_conv_args {
     const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
-    const void* w;            /* f16 packed [Npad][taps][Cin]  (K contiguous per output channel) */
+    const void* w;            /* f16 weights packed by es_pack_conv_f16 (tiled LDS-image order); for N <= 4
+                                 3x3x3 convs: es_pack_conv_rows_f16 ([N][27][Cin])                  */
     int32_t O, D, H, W;       /* OUTPUT spatial size                                             */
     int32_t Cin, N;           /* N = true number of output channels                              */
     int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
@@ -141,14 +142,21 @@ typedef struct es_conv_args {
     const float* res;         /* fp32 residual [M, N] or NULL                                    */
     float* out_f32;           /* [M, N] or NULL                                                  */
     void* out_f16;            /* [M, N] or NULL                                                  */
+    void* workspace;          /* optional split-K scratch: splitk * M * N floats (see splitk)       */
+    int32_t splitk;           /* 0/1: none; S > 1: K is split over S workgroups per tile, partial sums go to
+                                 `workspace` and a second kernel reduces them in a fixed order (deterministic)
+                                 and applies the epilogue.  Used for the small-M 16x4x4 level (M = 8192 rows
+                                 cannot fill 256 CUs otherwise).  -1: let the library choose.            */
     int32_t out_ld;           /* leading dimension of both outputs and of res (>= N);
                                  out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
 } es_conv_args;
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
-/* host helper: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16
- * [Npad][taps][Cin] image (Npad = N rounded up to 16). h_out holds uint16 bit patterns. */
+/* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
+ * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
+ * block per K step.  h_out holds uint16 bit patterns. */
 size_t es_pack_conv_f16_size(int N, int Cin, int taps);
 int es_pack_conv_f16(const float* h_w, int N, int Cin, int taps, uint16_t* h_out);
+int es_pack_conv_rows_f16(const float* h_w, int N, int Cin, int taps, uint16_t* h_out);
 
 typedef struct es_gn_args {
     const float* x1; int32_t C1;     /* fp32 channels-last source 1 [O, V, C1]                  */
