@@ -97,12 +97,18 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get('ES_DIST_BACKEND', 'nccl')     # 'gloo' only for single-GPU multi-rank smoke tests
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     O = a.nodes
     full = a.workload == 'full'
@@ -156,7 +162,7 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     lay_ms, shp_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
-    tmax = torch.tensor([wall], device=dev)
+    tmax = torch.tensor([wall], device=dev if backend == 'nccl' else 'cpu')
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())

@@ -13,6 +13,7 @@
 //   * K is split over the 8 waves of a workgroup and reduced through LDS in a fixed order
 //     (deterministic, no float atomics).
 #include "es_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -25,10 +26,11 @@ constexpr int MAXJ = KC / 16 / NWAVE;   // 16-wide k-blocks per wave per chunk
 
 struct Smem {
     float x[MT][LDX];
+    float gb[2][KC];          // gamma / beta of the norm prologue (staged once, read by every row)
 };
 
 __device__ __forceinline__ const float* seg_base(const es_seg& s) {
-    const float* p = s.ptr;
+    const float* p = s.ptr;   // (batched launches add blockIdx.z * a_bstride to segment 0 at the call site)
     if (s.step) p += (long)(*s.step) * s.step_stride;
     return p;
 }
@@ -62,7 +64,7 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, i
         const int lo = max(kc0, koff), hi = min(min(kc0 + kc, koff + sg.width), a.K);
         if (lo < hi) {
             const int w4 = (hi - lo) >> 2;
-            const float* base = seg_base(sg) + (lo - koff);
+            const float* base = seg_base(sg) + (lo - koff) + (s == 0 ? (long)blockIdx.z * a.a_bstride : 0);
             float* dst = &sm.x[r][lo - kc0];
             if (sg.mode == ES_SEG_CSRMEAN) {
                 const int e0 = sg.idx[mc], e1 = sg.idx[mc + 1];
@@ -107,6 +109,80 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, i
     for (int c = kend + cl; c < kc; c += 16) sm.x[r][c] = 0.f;
 }
 
+// Norm prologues (GroupNorm32 [+SiLU] / LayerNorm) done while staging: the thread that stages columns
+// 4*(cl + 16u) of row r keeps them in registers (u < K/64 <= 16), statistics are reduced with lane shuffles inside the
+// 16-lane row group (GroupNorm group = gs/4 adjacent lanes; LayerNorm = all 16), the normalised tile is written to LDS
+// once.  No dependent LDS walks, no per-element global loads of the affine (gamma/beta sit in LDS).
+template <int PRO>
+__device__ __forceinline__ void stage_norm(const es_linear_args& a, Smem& sm, int m0, int tid) {
+    const int r = tid >> 4, cl = tid & 15;
+    const int m = m0 + r;
+    const bool row_ok = m < a.M;
+    const int mc = row_ok ? m : a.M - 1;
+    const int K = a.K, nu = K >> 6;                      // K % 64 == 0 (host-checked)
+    const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0;
+    f4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (u < nu) {
+            const int c0 = u << 6;                       // first column of this 64-wide slice: uniform segment choice
+            const es_seg& sg = c0 < w0 ? a.seg[0] : (c0 < w0 + w1 ? a.seg[1] : a.seg[2]);
+            const int cb = c0 < w0 ? 0 : (c0 < w0 + w1 ? w0 : w0 + w1);
+            v[u] = *(const f4*)(seg_base(sg) + (long)mc * sg.ld + (c0 - cb) + 4 * cl);
+        }
+    }
+    if (PRO == ES_PRO_LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nu) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        const float mean = s / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; q += d * d; }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 16);
+        const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nu) {
+            const int c = (u << 6) + 4 * cl;
+            const f4 ga = *(const f4*)&sm.gb[0][c], be = *(const f4*)&sm.gb[1][c];
+            f4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = row_ok ? (v[u][e] - mean) * rstd * ga[e] + be[e] : 0.f;
+            *(f4*)&sm.x[r][c] = y;
+        }
+    } else {
+        const int gs = K >> 5;                           // channels per group: 4, 8, 16 or 32  (K = 128 .. 1024)
+        const int lpg = gs >> 2;                         // lanes per group: 1, 2, 4, 8
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nu) {
+            float s = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+            for (int o = 1; o < lpg; o <<= 1) s += __shfl_xor(s, o, 16);
+            const float mean = s / (float)gs;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; q += d * d; }
+            for (int o = 1; o < lpg; o <<= 1) q += __shfl_xor(q, o, 16);
+            const float rstd = 1.0f / sqrtf(q / (float)gs + a.eps);
+            const int c = (u << 6) + 4 * cl;
+            const f4 ga = *(const f4*)&sm.gb[0][c], be = *(const f4*)&sm.gb[1][c];
+            f4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[u][e] - mean) * rstd * ga[e] + be[e];
+                if (PRO == ES_PRO_GN_SILU) t = es_silu(t);
+                y[e] = row_ok ? t : 0.f;
+            }
+            *(f4*)&sm.x[r][c] = y;
+        }
+    }
+}
+
 template <int PRO>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a) {
     __shared__ Smem sm;
@@ -115,7 +191,8 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
     const int m0 = blockIdx.y * MT;
     const int Kp = (a.K + 15) & ~15;
     const int nkb_total = Kp >> 4;
-    const f4* wp = (const f4*)a.wpack + (size_t)nt * nkb_total * 64;
+    const int bz = blockIdx.z;                           // batched launch: z-th problem of identical shape
+    const f4* wp = (const f4*)a.wpack + ((size_t)bz * gridDim.x + nt) * nkb_total * 64;
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, q = lane >> 4;
 
@@ -129,82 +206,19 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
             const int kb = min(wave + j * NWAVE, nkb - 1);
             bf[j] = __builtin_nontemporal_load(&wp[(size_t)((kc0 >> 4) + kb) * 64 + lane]);
         }
-        // (2) stage the activation chunk (prologue elementwise part applied on the fly)
+        // (2) stage the activation chunk with its prologue applied
         if (kc0 > 0) __syncthreads();
-        stage_chunk<PRO>(a, sm, m0, kc0, kc, tid);
-        __syncthreads();
-        // (3) norm prologues (host guarantees K <= KC for these)
         if (PRO == ES_PRO_GN || PRO == ES_PRO_GN_SILU || PRO == ES_PRO_LN) {
-            const int r = tid >> 4, sub = tid & 15;     // 16 lanes per row
-            const int K = a.K;
-            if (PRO == ES_PRO_LN) {
-                float s = 0.f;
-                for (int k = sub; k < K; k += 16) s += sm.x[r][k];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-                const float mean = s / (float)K;
-                float v = 0.f;
-                for (int k = sub; k < K; k += 16) { const float d = sm.x[r][k] - mean; v += d * d; }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-                const float rstd = 1.0f / sqrtf(v / (float)K + a.eps);
-                for (int k = sub; k < K; k += 16)
-                    sm.x[r][k] = (sm.x[r][k] - mean) * rstd * a.gamma[k] + a.beta[k];
-            } else {
-                const int gs = K >> 5;                  // 32 groups of gs (= 16 or 32) channels
-                const int gs4 = gs >> 2;
-                if (gs & 3) {                           // narrow test configs (gs = 1, 2): scalar path
-                    for (int h = 0; h < 2; ++h) {
-                        const int g = sub + 16 * h;
-                        float s = 0.f;
-                        for (int k = 0; k < gs; ++k) s += sm.x[r][g * gs + k];
-                        const float mean = s / (float)gs;
-                        float var = 0.f;
-                        for (int k = 0; k < gs; ++k) { const float d = sm.x[r][g * gs + k] - mean; var += d * d; }
-                        const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
-                        for (int k = 0; k < gs; ++k) {
-                            const int kk = g * gs + k;
-                            float y = (sm.x[r][kk] - mean) * rstd * a.gamma[kk] + a.beta[kk];
-                            if (PRO == ES_PRO_GN_SILU) y = es_silu(y);
-                            sm.x[r][kk] = y;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int g = sub + 16 * h;
-                        f4 v[8];
-                        float s = 0.f;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (u < gs4) { v[u] = *(const f4*)&sm.x[r][g * gs + 4 * u]; s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]); }
-                        const float mean = s / (float)gs;
-                        float var = 0.f;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (u < gs4) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; var += d * d; }
-                            }
-                        const float rstd = 1.0f / sqrtf(var / (float)gs + a.eps);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (u < gs4) {
-                                const int kk = g * gs + 4 * u;
-                                const f4 ga = *(const f4*)&a.gamma[kk], be = *(const f4*)&a.beta[kk];
-                                f4 y;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    y[e] = (v[u][e] - mean) * rstd * ga[e] + be[e];
-                                    if (PRO == ES_PRO_GN_SILU) y[e] = es_silu(y[e]);
-                                }
-                                *(f4*)&sm.x[r][kk] = y;
-                            }
-                    }
-                }
+            for (int c = tid * 4; c < a.K; c += NTHREAD * 4) {       // affine -> LDS (K <= KC, single chunk)
+                *(f4*)&sm.gb[0][c] = *(const f4*)&a.gamma[c];
+                *(f4*)&sm.gb[1][c] = *(const f4*)&a.beta[c];
             }
             __syncthreads();
+            stage_norm<PRO>(a, sm, m0, tid);
+        } else {
+            stage_chunk<PRO>(a, sm, m0, kc0, kc, tid);
         }
+        __syncthreads();
         // (4) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block, 2 row tiles
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
@@ -234,13 +248,27 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) s += red[w * 512 + off];
     const int m = m0 + ml, n = nt * 16 + nl;
+    const float* bias = a.bias ? a.bias + (long)bz * a.N : nullptr;
+    float* out = a.out + (long)bz * a.out_bstride;
+    if (a.act == ES_ACT_GEGLU) {
+        // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt + nl, lane nl + 8 its gate
+        float sb = s + ((bias && n < a.N) ? bias[n] : 0.f);
+        const float gate = __shfl_xor(sb, 8, 16);
+        if (m < a.M && nl < 8 && n < a.N) {
+            const int no = nt * 8 + nl;
+            float v = sb * es_gelu(gate);
+            if (a.res) v += a.res[(long)m * a.res_ld + no];
+            out[(long)m * a.out_ld + no] = v;
+        }
+        return;
+    }
     if (m < a.M && n < a.N) {
-        if (a.bias) s += a.bias[n];
+        if (bias) s += bias[n];
         if (a.act == ES_ACT_RELU) s = fmaxf(s, 0.f);
         else if (a.act == ES_ACT_SILU) s = es_silu(s);
         if (a.res) s += a.res[(long)m * a.res_ld + n];
         if (a.res2) s += a.res2[(long)m * a.res2_ld + n];
-        a.out[(long)m * a.out_ld + n] = s;
+        out[(long)m * a.out_ld + n] = s;
     }
 }
 
@@ -293,6 +321,24 @@ extern "C" int es_pack_linear_f32(const float* w, int N, int K, float* out) {
     return 0;
 }
 
+// GEGLU variant: W[2*Nh, K] = [value rows | gate rows]  ->  rows interleaved per 16-row tile as 8 value + 8 gate,
+// then packed as usual.  h_bias (2*Nh, may be NULL) is permuted into h_bias_out the same way.
+extern "C" int es_pack_linear_geglu_f32(const float* w, const float* h_bias, int Nh, int K, float* out, float* h_bias_out) {
+    if (Nh % 8) return 2;
+    const int N = 2 * Nh;
+    float* tmp = (float*)malloc((size_t)N * K * sizeof(float));
+    if (!tmp) return 1;
+    for (int t = 0; t < N / 16; ++t)
+        for (int j = 0; j < 16; ++j) {
+            const int src = j < 8 ? t * 8 + j : Nh + t * 8 + (j - 8);
+            memcpy(tmp + (size_t)(t * 16 + j) * K, w + (size_t)src * K, (size_t)K * sizeof(float));
+            if (h_bias && h_bias_out) h_bias_out[t * 16 + j] = h_bias[src];
+        }
+    const int rc = es_pack_linear_f32(tmp, N, K, out);
+    free(tmp);
+    return rc;
+}
+
 extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
     ES_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "es_linear_rows_f32: nseg=%d", a->nseg);
     int ksum = 0;
@@ -306,14 +352,21 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
     ES_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "es_linear_rows_f32: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     const bool norm = a->prologue == ES_PRO_GN || a->prologue == ES_PRO_GN_SILU || a->prologue == ES_PRO_LN;
     if (norm) {
-        ES_REQUIRE(a->K <= KC, "es_linear_rows_f32: norm prologue needs K <= %d (K=%d)", KC, a->K);
+        ES_REQUIRE(a->K <= KC && a->K % 64 == 0, "es_linear_rows_f32: norm prologue needs K <= %d and K %% 64 == 0 (K=%d)", KC, a->K);
         ES_REQUIRE(a->gamma && a->beta, "es_linear_rows_f32: norm prologue without affine");
+        for (int s = 0; s < a->nseg; ++s)
+            ES_REQUIRE(a->seg[s].mode == ES_SEG_DIRECT && a->seg[s].width % 64 == 0,
+                       "es_linear_rows_f32: norm prologue needs direct segments with width %% 64 == 0");
         if (a->prologue != ES_PRO_LN)
-            ES_REQUIRE(a->K % 32 == 0, "es_linear_rows_f32: GroupNorm32 prologue needs K %% 32 == 0 (K=%d)", a->K);
+            ES_REQUIRE(a->K % 128 == 0, "es_linear_rows_f32: GroupNorm32 prologue needs K %% 128 == 0 (K=%d)", a->K);
     }
     if (a->prologue == ES_PRO_GEGLU)
         ES_REQUIRE(a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
-    dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT);
+    const int nb = a->nbatch > 1 ? a->nbatch : 1;
+    ES_REQUIRE(nb == 1 || (a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT && !norm && !a->res && !a->res2),
+               "es_linear_rows_f32: batched launch supports one direct segment, no norm prologue, no residuals");
+    ES_REQUIRE(a->act != ES_ACT_GEGLU || (a->N % 16 == 0 && !a->res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
+    dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT, nb);
     hipStream_t st = (hipStream_t)stream;
     switch (a->prologue) {
         case ES_PRO_NONE: hipLaunchKernelGGL(k_linear_rows<ES_PRO_NONE>, grid, dim3(NTHREAD), 0, st, *a); break;

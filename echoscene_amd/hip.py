@@ -15,7 +15,7 @@ c_i32p = C.c_void_p
 # enums (include/echoscene_hip.h)
 SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
-ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
 CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW = 0, 1, 2, 3
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
 OP_VQ = 12
@@ -33,7 +33,7 @@ class LinearArgs(C.Structure):
                 ('wpack', C.c_void_p), ('bias', C.c_void_p), ('prologue', C.c_int32), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('eps', C.c_float), ('act', C.c_int32), ('res', C.c_void_p),
                 ('res_ld', C.c_int32), ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
-                ('out_ld', C.c_int32)]
+                ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32)]
 
 
 class UpdateArgs(C.Structure):
@@ -106,6 +106,7 @@ EXPORTS = {
     'es_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     'es_pack_linear_f32_size': (C.c_size_t, [C.c_int, C.c_int]),
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),

@@ -29,7 +29,13 @@ def all_gather_rows(local, num_rows, world, group=None):
     pad = torch.zeros((block,) + tuple(C), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     out = torch.empty((world * block,) + tuple(C), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    if local.is_cuda and dist.get_backend(group) != 'nccl':
+        # test-only path (several ranks sharing one GPU under gloo): stage through host memory
+        outc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(outc, pad.cpu(), group=group)
+        out.copy_(outc)
+    else:
+        dist.all_gather_into_tensor(out, pad, group=group)
     return out[:num_rows]
 
 

@@ -44,19 +44,44 @@ def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=No
 
 
 class PackedLinear:
-    """Device image of one (possibly fused) linear layer in MFMA fragment order."""
+    """Device image of one (possibly fused) linear layer in MFMA fragment order.
+    ``geglu=True``: W = [value rows | gate rows] of a GEGLU projection; rows are interleaved per 16-row tile so
+    that the kernel's epilogue (ES_ACT_GEGLU) can emit value*gelu(gate) directly (N_out = N/2)."""
 
-    def __init__(self, W, b, device):
+    def __init__(self, W, b, device, geglu=False):
         W = W.detach().to(torch.float32).contiguous().cpu()
         self.N, self.K = W.shape
+        self.geglu = geglu
         L = hip.lib()
         n = L.es_pack_linear_f32_size(self.N, self.K)
         out = torch.empty(n, dtype=torch.float32)
-        hip.check(L.es_pack_linear_f32(C.c_void_p(W.data_ptr()), self.N, self.K, C.c_void_p(out.data_ptr())),
-                  'es_pack_linear_f32')
+        if geglu:
+            bh = None if b is None else b.detach().to(torch.float32).contiguous().cpu()
+            bo = None if b is None else torch.empty_like(bh)
+            hip.check(L.es_pack_linear_geglu_f32(C.c_void_p(W.data_ptr()), None if bh is None else C.c_void_p(bh.data_ptr()),
+                                                 self.N // 2, self.K, C.c_void_p(out.data_ptr()),
+                                                 None if bo is None else C.c_void_p(bo.data_ptr())), 'es_pack_linear_geglu_f32')
+            b = bo
+        else:
+            hip.check(L.es_pack_linear_f32(C.c_void_p(W.data_ptr()), self.N, self.K, C.c_void_p(out.data_ptr())),
+                      'es_pack_linear_f32')
         self.w = out.to(device)
         self.b = None if b is None else b.detach().to(torch.float32).contiguous().to(device)
         self.weight_bytes = self.N * self.K * 4
+        self.nbatch = 1
+
+
+class PackedLinearBatch(PackedLinear):
+    """Several linears of identical shape stored back to back (one batched launch, grid.z = len)."""
+
+    def __init__(self, Ws, bs, device):
+        parts = [PackedLinear(W, b, 'cpu') for W, b in zip(Ws, bs)]
+        self.N, self.K, self.geglu = parts[0].N, parts[0].K, False
+        assert all(p.N == self.N and p.K == self.K for p in parts)
+        self.w = torch.cat([p.w for p in parts]).to(device)
+        self.b = torch.cat([p.b for p in parts]).to(device) if parts[0].b is not None else None
+        self.weight_bytes = sum(p.weight_bytes for p in parts)
+        self.nbatch = len(parts)
 
 
 def fold_bn(sd, lin, bn):
@@ -116,6 +141,9 @@ class Builder:
         self.keep = []
         self.weight_bytes = 0      # algorithmic weight bytes streamed per plan execution
         self.tags = {}             # name -> View of an intermediate (parity debugging)
+        import os
+        # side-stream graph branches: measured SLOWER on MI355X (2.27 vs 2.06 ms per layout step) -- off by default
+        self.use_lanes = os.environ.get('ES_LANES', '0') != '0'
         self.flops = 0
 
     def buf(self, *shape, dtype=torch.float32, zero=False):
@@ -128,8 +156,22 @@ class Builder:
         self.keep.append(t)
         return t
 
+    def fork(self, lane):
+        if not self.use_lanes:
+            return
+        op = Op()
+        op.kind, op.lane = hip.OP_FORK, lane
+        self.ops.append(op)
+
+    def join(self, lane):
+        if not self.use_lanes:
+            return
+        op = Op()
+        op.kind, op.lane = hip.OP_JOIN, lane
+        self.ops.append(op)
+
     def linear(self, segs, pl, M, out, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
-               res=None, res2=None, lane=0, use_bias=True):
+               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0):
         a = LinearArgs()
         for i, s in enumerate(segs):
             a.seg[i] = s
@@ -141,7 +183,8 @@ class Builder:
         a.gamma = gamma.data_ptr() if gamma is not None else None
         a.beta = beta.data_ptr() if beta is not None else None
         a.eps = eps
-        a.act = act
+        a.act = hip.ACT_GEGLU if pl.geglu else act
+        a.nbatch, a.a_bstride, a.out_bstride = pl.nbatch, a_bstride, out_bstride
         a.res = res.ptr if res is not None else None
         a.res_ld = res.ld if res is not None else 0
         a.res2 = res2.ptr if res2 is not None else None
@@ -149,12 +192,12 @@ class Builder:
         a.out = out.ptr
         a.out_ld = out.ld
         op = Op()
-        op.kind, op.lane = hip.OP_LINEAR, lane
+        op.kind, op.lane = hip.OP_LINEAR, (lane if self.use_lanes else 0)
         op.u.linear = a
         self.ops.append(op)
         self.keep += [pl, gamma, beta]
         self.weight_bytes += pl.weight_bytes
-        self.flops += 2 * M * pl.K * pl.N
+        self.flops += 2 * M * pl.K * pl.N * pl.nbatch
         return out
 
     def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True):
@@ -265,11 +308,13 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         b.linear([seg(t1)], L['n1b'], T, t2, act=hip.ACT_RELU)
         last = li == n - 1
         if 'proj' in L:
+            # residual projections depend only on the layer input: side lane 2, joined before the last linear
+            b.fork(2)
             proj = View(b.buf(O, Dout))
-            b.linear([seg(obj, width=Dobj)], L['proj'], O, proj)
+            b.linear([seg(obj, width=Dobj)], L['proj'], O, proj, lane=2)
             if not last or want_pred:
                 newp = View(b.buf(T, Dp))
-                b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp))
+                b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp), lane=2)
         else:
             proj = None
             newp = View(t2.t, col=H, ld=W2, width=Dp)
@@ -278,6 +323,8 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRMEAN, idx=ptr, ent_row=rows, ent_off=offs)],
                  L['n2a'], O, n1, act=hip.ACT_RELU)
         dst = out if (last and out is not None) else View(b.buf(O, Dout))
+        if proj is not None:
+            b.join(2)
         b.linear([seg(n1)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
         obj, Dobj = dst, Dout
         if not last or want_pred:
@@ -338,8 +385,8 @@ class UNet1DWeights:
                 # one token, one key: softmax == 1, so attention(x) = to_out(to_v(.)) exactly
                 d['v1'] = P(tb + '.attn1.to_v.weight', None)
                 d['o1'] = P(tb + '.attn1.to_out.0.weight', tb + '.attn1.to_out.0.bias')
-                d['o2'] = P(tb + '.attn2.to_out.0.weight', tb + '.attn2.to_out.0.bias')
-                d['ff1'] = P(tb + '.ff.net.0.proj.weight', tb + '.ff.net.0.proj.bias')
+                d['o2'] = (sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_out.0.bias'])
+                d['ff1'] = PackedLinear(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
                 d['ff2'] = P(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
                 d['proj_out'] = P(name + '.proj_out.weight', name + '.proj_out.bias')
                 self.ca[name] = (len(ca_v), it[1])
@@ -352,6 +399,11 @@ class UNet1DWeights:
         # all ResBlock emb projections / all cross-attention value projections as ONE product each
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
         self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
+        # the 11 cross-attention output projections have identical shapes -> one batched launch
+        names_ca = list(self.ca.keys())
+        assert len({self.ca[n][1] for n in names_ca}) == 1, 'batched cross-attention projections need equal widths'
+        self.o2_all = PackedLinearBatch([self.items[n]['o2'][0] for n in names_ca],
+                                        [self.items[n]['o2'][1] for n in names_ca], device)
         self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
         self.out_conv = P('out.2.weight', 'out.2.bias')
 
@@ -366,6 +418,10 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
     b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
     emb = View(b.buf(O, E))
     b.linear([seg(e1)], w.te2, O, emb)
+    # side lane 1: all 22 ResBlock time projections (92 MB of weights) overlap the GCN chain
+    emb_all = b.buf(O, w.emb_all.N)
+    b.fork(1)
+    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU, lane=1)
     # GCN input  [obj_embed | box_embeddings(x_t) | box_time_emb(emb)]   (denoise_net.py:758-771)
     Dobj = obj_embed_dev.shape[1] + gdim + (gdim if w.enable_t_emb else 0)
     objbuf = b.buf(O, Dobj)
@@ -378,16 +434,15 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
     b.tags.update(emb=emb, ctx=ctx, gcn_in=View(objbuf))
     # batched per-step side products
-    emb_all = b.buf(O, w.emb_all.N)
-    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
     cav = b.buf(O, w.cav_all.N)
     b.linear([seg(ctx)], w.cav_all, O, View(cav))
-    cavo = {}
-    for name, (k, C) in w.ca.items():
-        o = View(b.buf(O, C))
-        off = sum(c for (_, c) in list(w.ca.values())[:k])
-        b.linear([seg(View(cav, col=off, ld=w.cav_all.N, width=C))], w.items[name]['o2'], O, o)
-        cavo[name] = o
+    nca = len(w.ca)
+    Cca = next(iter(w.ca.values()))[1]
+    cavo_all = b.buf(nca, O, Cca)
+    b.linear([seg(View(cav, ld=w.cav_all.N, width=Cca))], w.o2_all, O, View(cavo_all.view(nca * O, Cca)),
+             a_bstride=Cca, out_bstride=O * Cca)
+    cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
+    b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
     def run_block(name_prefix, blk, h_segs, hC):
         """h_segs: list of Views forming the (possibly concatenated) input; returns (View, C)."""
@@ -432,10 +487,10 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
                 b.linear([seg(v1)], d['o1'], O, t2, res=t0, res2=cavo[name])
                 b.tags[name + '.transformer_blocks.0:in'] = t0
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
-                gl = View(b.buf(O, 8 * C))
+                gl = View(b.buf(O, 4 * C))                    # GEGLU applied in the ff1 epilogue
                 b.linear([seg(t2)], d['ff1'], O, gl, prologue=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5)
                 t3 = View(b.buf(O, C))
-                b.linear([seg(View(gl.t, ld=8 * C, width=4 * C))], d['ff2'], O, t3, prologue=hip.PRO_GEGLU, res=t2)
+                b.linear([seg(gl)], d['ff2'], O, t3, res=t2)
                 b.tags[name + '.transformer_blocks.0:ff'] = t3
                 o = View(b.buf(O, C))
                 b.linear([seg(t3)], d['proj_out'], O, o, res=xin)

@@ -48,7 +48,9 @@ int es_device_info(char* name_out, int name_cap, int* cu_count);
  * ---------------------------------------------------------------------------------------- */
 enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2 };
 enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
-enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2 };
+enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2, ES_ACT_GEGLU = 3 };
+/* ES_ACT_GEGLU: W/bias rows are interleaved per 16-row tile as [8 value rows | 8 gate rows] (es_pack_linear_geglu_f32);
+ * the kernel writes N/2 columns: value * gelu(gate)  (GEGLU.forward, attention.py:39-46). */
 
 typedef struct es_seg {
     const float* ptr;      /* source matrix                                                     */
@@ -77,8 +79,11 @@ typedef struct es_linear_args {
     int32_t res_ld;
     const float* res2;        /* optional second residual (cross-attention-with-one-key vector) */
     int32_t res2_ld;
-    float* out;               /* [M, N]                                                        */
+    float* out;               /* [M, N]  (ES_ACT_GEGLU: [M, N/2])                              */
     int32_t out_ld;
+    /* batched launch (grid.z = nbatch): batch z uses seg[0].ptr + z*a_bstride, the z-th packed weight image
+     * (images of equal shape stored back to back), bias + z*N, out + z*out_bstride.  0/1 = single problem. */
+    int32_t nbatch, a_bstride, out_bstride;
 } es_linear_args;
 
 /* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
@@ -86,6 +91,8 @@ typedef struct es_linear_args {
  * holds W[nt*16+j][kb*16+4q .. +3], zero padded. */
 size_t es_pack_linear_f32_size(int N, int K);
 int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
+/* GEGLU projection W[2*Nh,K] (value rows | gate rows): interleave per 16-row tile, then pack (ES_ACT_GEGLU) */
+int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int K, float* h_out, float* h_bias_out);
 
 int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
 

@@ -214,7 +214,7 @@ def test_unet1d_tiny_blockwise_vs_oracle(dev):
     assert not bad, bad[:6]
 
 
-@pytest.mark.parametrize('K,pro', [(64, 'gn'), (128, 'gn'), (64, 'ln'), (96, 'ln'), (1024, 'gn')])
+@pytest.mark.parametrize('K,pro', [(128, 'gn'), (256, 'gn'), (64, 'ln'), (192, 'ln'), (1024, 'gn'), (1024, 'ln')])
 def test_linear_narrow_norms(dev, K, pro):
     from echoscene_amd import hip
     rs = np.random.RandomState(K)
@@ -246,3 +246,35 @@ def test_linear_multisegment_multichunk(dev):
     out = _run_linear(dev, [dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=s), dict(src=pred, width=Dp),
                             dict(src=obj, width=D, mode=hip.SEG_GATHER, idx=o)], W, None, T, act=hip.ACT_RELU)
     _close(out, F.relu(F.linear(torch.cat([obj[s], pred, obj[o]], 1), W)), 2e-5)
+
+
+def test_linear_geglu_epilogue_and_batched(dev):
+    """GEGLU fused into the projection's epilogue (interleaved weight tiles) and the batched launch used for the
+    11 cross-attention output projections."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, PackedLinearBatch, View, seg
+    rs = np.random.RandomState(11)
+    M, K, Nh = 32, 512, 2048
+    X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32))
+    W = torch.from_numpy((rs.standard_normal((2 * Nh, K)) / np.sqrt(K)).astype(np.float32))
+    bias = torch.from_numpy(rs.standard_normal(2 * Nh).astype(np.float32))
+    ga = torch.from_numpy(1 + 0.1 * rs.standard_normal(K).astype(np.float32))
+    be = torch.from_numpy(0.1 * rs.standard_normal(K).astype(np.float32))
+    h = F.linear(F.layer_norm(X, (K,), ga, be, 1e-5), W, bias)
+    a, g = h.chunk(2, -1)
+    b = Builder(dev)
+    out = b.buf(M, Nh, zero=True)
+    b.linear([seg(View(b.dev(X)))], PackedLinear(W, bias, dev, geglu=True), M, View(out), prologue=hip.PRO_LN,
+             gamma=b.dev(ga), beta=b.dev(be), eps=1e-5)
+    nb, C = 5, 64
+    A = torch.from_numpy(rs.standard_normal((M, nb * C)).astype(np.float32))
+    Ws = [torch.from_numpy((rs.standard_normal((C, C)) / 8).astype(np.float32)) for _ in range(nb)]
+    bs = [torch.from_numpy(rs.standard_normal(C).astype(np.float32)) for _ in range(nb)]
+    outb = b.buf(nb, M, C, zero=True)
+    b.linear([seg(View(b.dev(A), ld=nb * C, width=C))], PackedLinearBatch(Ws, bs, dev), M, View(outb.view(nb * M, C)),
+             a_bstride=C, out_bstride=M * C)
+    b.finish().run()
+    torch.cuda.synchronize()
+    _close(out, a * F.gelu(g), 3e-5)
+    for z in range(nb):
+        _close(outb[z], F.linear(A[:, z * C:(z + 1) * C], Ws[z], bs[z]), 2e-5)
