@@ -350,42 +350,59 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
     };
     set_phase();
 
-    auto stage = [&](int b) __attribute__((always_inline)) {   // issue the glds of the next K step into ring slot b, then advance
-        char* As = smem + b * STAGE_BYTES;
-        char* Bs = As + A_BYTES;
+    // The LDS-DMA of one K step is NLOAD independent pieces (NA of the A tile, NB of the B tile).  They are issued
+    // one at a time BETWEEN the MFMA rows of the step being computed, so that their issue cost (60-180 cycles each)
+    // overlaps the matrix pipe instead of preceding it.
+    long st_delta = 0, st_boff = 0;
+    bool st_uni = true;
+    auto stage_prep = [&]() __attribute__((always_inline)) {
         const int Cin = st_phase ? a.Cin2 : a.Cin;
         const int ntap = st_phase ? 1 : a.taps;
-        const long boff = (long)((st_c >> 5) * ntap + st_tap) * (BNP * BK);
-        if (st_phase || uniform_delta) {
-            int kd = 0, kh = 0, kw = 0;
-            if (ntap == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
-            const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
-            const long delta = ((long)(kd * Hi + kh) * Wi + kw) * Cin + st_c;          // wave-uniform
-#pragma unroll
-            for (int j = 0; j < NA; ++j)
-                glds16((((a_msk[j] >> st_tap) & 1u) && !(dbg & 16)) ? a_ctr[j] + delta : zero_page, As + (wave * 64 + NT * j) * 16);
-        } else {                                 // nearest-upsample modes: source index is not a uniform shift
-            const _Float16* Ag = (const _Float16*)a.a;
-            const int kd = st_tap / 9 - 1, kh = (st_tap / 3) % 3 - 1, kw = st_tap % 3 - 1;
-            const int Di = (a.mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
+        st_boff = (long)((st_c >> 5) * ntap + st_tap) * (BNP * BK);
+        st_uni = st_phase || uniform_delta;
+        int kd = 0, kh = 0, kw = 0;
+        if (ntap == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
+        const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+        st_delta = ((long)(kd * Hi + kh) * Wi + kw) * Cin + st_c;                      // wave-uniform
+    };
+    auto stage_piece = [&](int b, int pj) __attribute__((always_inline)) {
+        char* As = smem + b * STAGE_BYTES;
+        char* Bs = As + A_BYTES;
+        if (pj < NA) {
+            const int j = pj;
+            if (st_uni) {
+                glds16((((a_msk[j] >> st_tap) & 1u) && !(dbg & 16)) ? a_ctr[j] + st_delta : zero_page,
+                       As + (wave * 64 + NT * j) * 16);
+            } else {                             // nearest-upsample modes: source index is not a uniform shift
+                const _Float16* Ag = (const _Float16*)a.a;
+                const int kd = st_tap / 9 - 1, kh = (st_tap / 3) % 3 - 1, kw = st_tap % 3 - 1;
+                const int Di = (a.mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
                 int id = a_d[j] + kd, ih = a_h[j] + kh, iw = a_w[j] + kw;
                 const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
                 if (a.mode == ES_CONV_UP_DHW) id >>= 1;
                 ih >>= 1; iw >>= 1;
-                glds16(ok ? Ag + ((((long)a_o[j] * Di + id) * g.Hi + ih) * g.Wi + iw) * Cin + a_lc[j] * 8 + st_c : zero_page,
+                glds16(ok ? Ag + ((((long)a_o[j] * Di + id) * g.Hi + ih) * g.Wi + iw) * a.Cin + a_lc[j] * 8 + st_c : zero_page,
                        As + (wave * 64 + NT * j) * 16);
             }
+        } else {
+            const int j = pj - NA;
+            glds16(b_base + ((dbg & 32) ? 0 : st_boff) + NT * 8 * j, Bs + (wave * 64 + NT * j) * 16);
         }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            glds16(b_base + ((dbg & 32) ? 0 : boff) + NT * 8 * j, Bs + (wave * 64 + NT * j) * 16);
+    };
+    auto stage_advance = [&]() __attribute__((always_inline)) {
+        const int Cin = st_phase ? a.Cin2 : a.Cin;
+        const int ntap = st_phase ? 1 : a.taps;
         if (++st_tap == ntap) {
             st_tap = 0;
             st_c += BK;
             if (st_c == Cin && !st_phase && a.a2) { st_phase = 1; st_c = 0; set_phase(); }
         }
+    };
+    auto stage = [&](int b) __attribute__((always_inline)) {   // whole K step at once (prologue of the pipeline)
+        stage_prep();
+#pragma unroll
+        for (int pj = 0; pj < NLOAD; ++pj) stage_piece(b, pj);
+        stage_advance();
     };
 
     f4 acc[MI][7];
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
             bfr[j] = *(const h8*)(Bs + row * 64 + ((q ^ f_swz(row)) << 4));
         }
     };
-    auto mma = [&](h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline)) {
+    auto mma = [&](h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline, unused)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -433,9 +450,28 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();        // also: every wave finished reading ring slot (ks+2)%3 == (ks-1)%3
-            if (ks + 2 < nloc && !(dbg & 1)) stage((ks + 2) % NSTAGE);
+            const bool pf = (ks + 2 < nloc) && !(dbg & 1);
+            const int slot = (ks + 2) % NSTAGE;
+            if (pf) stage_prep();
             if (!(dbg & 8)) load_frags(ks % NSTAGE, af, bfr);
-            if (!(dbg & 2)) mma(af, bfr);
+            // MFMA rows interleaved with the LDS-DMA pieces of tile ks+2 (order pinned with sched_barrier)
+            constexpr int PPR = (NLOAD + MI - 1) / MI;           // pieces per MFMA row
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (!(dbg & 2)) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pf) {
+#pragma unroll
+                    for (int pp = 0; pp < PPR; ++pp)
+                        if (i * PPR + pp < NLOAD) stage_piece(slot, i * PPR + pp);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pf) stage_advance();
         }
     }
 
