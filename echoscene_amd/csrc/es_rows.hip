@@ -300,6 +300,25 @@ __global__ void k_ddim_update(const es_update_args a) {
 
 __global__ void k_step_inc(int32_t* step) { *step += 1; }
 
+// Box de-normalisation after the layout loop (helpers/util.py:542-568): [-1,1] -> [min,max] for sizes and
+// translations (in place, stats = {min_lhw[3], max_lhw[3], min_xyz[3], max_xyz[3], min_angle, max_angle}) and
+// (sin, cos) -> arctan2 in degrees-or-radians (scale).
+__global__ void k_box_postprocess(float* boxes, int ld, const float* sincos, float* angle_out, const float* stats,
+                                  int O, float angle_scale) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= O) return;
+    if (boxes) {
+        for (int c = 0; c < 6; ++c) {
+            const float lo = stats[c < 3 ? c : 3 + c], hi = stats[c < 3 ? 3 + c : 6 + c];
+            float v = boxes[(long)i * ld + c];
+            v = (v + 1.0f) / 2.0f;
+            boxes[(long)i * ld + c] = v * (hi - lo) + lo;
+        }
+    }
+    if (sincos && angle_out) angle_out[i] = atan2f(sincos[2 * i], sincos[2 * i + 1]) * angle_scale;
+}
+
 }  // namespace
 
 extern "C" size_t es_pack_linear_f32_size(int N, int K) {
@@ -385,6 +404,15 @@ extern "C" int es_ddpm_update(const es_update_args* a, es_stream stream) {
     ES_REQUIRE(a->n > 0 && a->step && a->noise, "es_ddpm_update: bad args");
     hipLaunchKernelGGL(k_ddpm_update, dim3((a->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
     if (a->inc_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, a->step);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_box_postprocess(float* boxes, int ld, const float* sincos, float* angle_out, const float* stats,
+                                  int O, float angle_scale, es_stream stream) {
+    ES_REQUIRE(O > 0 && (!boxes || (stats && ld >= 6)), "es_box_postprocess: bad args");
+    hipLaunchKernelGGL(k_box_postprocess, dim3((O + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, ld, sincos,
+                       angle_out, stats, O, angle_scale);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

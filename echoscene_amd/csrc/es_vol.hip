@@ -881,7 +881,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     }
     if (S <= 1 || !can_split) S = 1;
     const int flags = ncdhw | (dbgf << 8);
-    if (wg256 >= 256 && S == 1) {
+    static const char* tile_env = getenv("ES_CONV_TILE");     // A/B switch: force 128-row tiles
+    const bool no256 = tile_env && atoi(tile_env) == 128;
+    if (wg256 >= 256 && S == 1 && !no256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, 1);
         hipLaunchKernelGGL((k_conv_mfma<256, 8>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
     } else if (wg128 >= 512 || S > 1) {

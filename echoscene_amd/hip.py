@@ -110,6 +110,8 @@ EXPORTS = {
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
+    'es_box_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                     C.c_void_p]),
     'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -122,6 +124,10 @@ EXPORTS = {
     'es_shape_stem': (C.c_int, [C.POINTER(StemArgs), C.c_void_p]),
     'es_vq_lookup': (C.c_int, [C.POINTER(VQArgs), C.c_void_p]),
     'es_init': (C.c_int, []),
+    'es_chamfer_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    'es_chamfer_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'es_plan_create': (C.c_void_p, [C.POINTER(Op), C.c_int]),
     'es_plan_destroy': (None, [C.c_void_p]),
     'es_plan_num_ops': (C.c_int, [C.c_void_p]),

@@ -120,6 +120,12 @@ typedef struct es_update_args {
     int32_t inc_step;
 } es_update_args;
 int es_ddpm_update(const es_update_args* args, es_stream stream);
+/* Post-path box de-normalisation: descale_box_params (helpers/util.py:542-557;
+ * boxes [O, ld>=6] = sizes|translations in [-1,1], updated IN PLACE like the reference does to its argument;
+ * stats = 14 floats of the dataset's boxes_centered_stats file) and postprocess_sincos2arctan (:559-568;
+ * angle_out[O] = atan2(sin, cos) * angle_scale).  Either half may be skipped with NULL pointers. */
+int es_box_postprocess(float* boxes, int ld, const float* sincos, float* angle_out, const float* stats,
+                       int O, float angle_scale, es_stream stream);
 int es_ddim_update(const es_update_args* args, es_stream stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -250,6 +256,18 @@ int es_plan_num_ops(const es_plan* plan);
 int es_plan_run(es_plan* plan, es_stream stream);
 /* capture es_plan_run into a hipGraph (idempotent) */
 int es_plan_capture(es_plan* plan, es_stream stream);
+/* ------------------------------------------------------------------------------------------
+ * Chamfer nearest-neighbour distance (offline consistency metric; the reference's only native kernels,
+ * extension/old_chamfer/chamfer.cu:12-195, bound as chamfer.forward / chamfer.backward in chamfer_cuda.cpp:30-33).
+ * xyz1 [batch,n,3], xyz2 [batch,m,3] fp32; dist = squared distance to the nearest point of the other cloud,
+ * idx = its index (first minimum).  backward ACCUMULATES into gradxyz1/2 (caller zero-fills, as the reference).
+ * ---------------------------------------------------------------------------------------- */
+int es_chamfer_forward(const float* xyz1, const float* xyz2, int batch, int n, int m, float* dist1, int32_t* idx1,
+                       float* dist2, int32_t* idx2, es_stream stream);
+int es_chamfer_backward(const float* xyz1, const float* xyz2, int batch, int n, int m, const float* graddist1,
+                        const float* graddist2, const int32_t* idx1, const int32_t* idx2, float* gradxyz1,
+                        float* gradxyz2, es_stream stream);
+
 /* library-wide one-off device allocations (zero page); call once outside stream capture */
 int es_init(void);
 /* The sampling loops.  `step` is the device scalar the plan's ops read; it is set to first_step,

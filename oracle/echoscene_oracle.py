@@ -503,3 +503,45 @@ def scene_setup(sd, objs, triples, text_feat, rel_feat, model_type='echoscene', 
 def rel_s(sd, feat):
     """rel_s_mlp: Linear-BN-ReLU-Linear (norelu) then unsqueeze(1)  (EchoScene.py:97-100,413-416)."""
     return mlp(sd, 'rel_s_mlp', feat, final_nonlinearity=False).unsqueeze(1)
+
+
+# --------------------------------------------------------------------------------------
+# (f3) post-path box helpers   helpers/util.py:542-557 (descale_box_params), :559-568
+# --------------------------------------------------------------------------------------
+def descale_box_params(boxes, stats):
+    stats = torch.as_tensor(stats, dtype=boxes.dtype)
+    min_lhw, max_lhw, min_xyz, max_xyz = stats[:3], stats[3:6], stats[6:9], stats[9:12]
+    out = boxes.clone()
+    out[:, :3] = (out[:, :3] + 1) / 2
+    out[:, :3] = out[:, :3] * (max_lhw - min_lhw) + min_lhw
+    out[:, 3:6] = (out[:, 3:6] + 1) / 2
+    out[:, 3:6] = out[:, 3:6] * (max_xyz - min_xyz) + min_xyz
+    return out
+
+
+def sincos2arctan(sincos):
+    return torch.arctan2(sincos[:, 0], sincos[:, 1]).reshape(-1, 1)
+
+
+# --------------------------------------------------------------------------------------
+# (f4) chamfer nearest-neighbour distance   extension/old_chamfer/chamfer.cu:12-134 (forward),
+#      :155-174 (backward): squared distance to the nearest point of the other cloud + its index
+# --------------------------------------------------------------------------------------
+def chamfer_forward(xyz1, xyz2):
+    d = ((xyz1[:, :, None, :] - xyz2[:, None, :, :]) ** 2)
+    d = d[..., 0] + d[..., 1] + d[..., 2]                    # dx*dx + dy*dy + dz*dz, fp32
+    dist1, idx1 = d.min(dim=2)
+    dist2, idx2 = d.min(dim=1)
+    return dist1, idx1, dist2, idx2
+
+
+def chamfer_backward(xyz1, xyz2, g1, g2, idx1, idx2):
+    gx1, gx2 = torch.zeros_like(xyz1), torch.zeros_like(xyz2)
+    for b in range(xyz1.shape[0]):
+        v = 2 * g1[b][:, None] * (xyz1[b] - xyz2[b][idx1[b]])
+        gx1[b] += v
+        gx2[b].index_add_(0, idx1[b], -v)
+        v = 2 * g2[b][:, None] * (xyz2[b] - xyz1[b][idx2[b]])
+        gx2[b] += v
+        gx1[b].index_add_(0, idx2[b], -v)
+    return gx1, gx2

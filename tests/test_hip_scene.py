@@ -96,3 +96,42 @@ def test_sgdiff_editing_variants_run():
     tf2, rf2 = synth.synthetic_features(O + 1, triples2.shape[0], seed=5)
     d2 = m.sample_boxes_and_shape_with_additions(objs, triples, tf, rf, objs2, triples2, tf2, rf2, [2])
     assert tuple(d2['sizes'].shape) == (O + 1, 3) and torch.isfinite(d2['sizes']).all()
+
+
+def test_box_postprocess_matches_reference_helpers():
+    """descale_box_params / postprocess_sincos2arctan on the device vs the oracle
+    restatement of helpers/util.py:542-568; the box tensor is updated in place like the reference does."""
+    from echoscene_amd.postprocess import descale_box_params, postprocess_sincos2arctan
+    from oracle import echoscene_oracle as orc
+    rs = np.random.RandomState(0)
+    boxes = torch.from_numpy(rs.uniform(-1.2, 1.2, (33, 6)).astype(np.float32))
+    sc = torch.from_numpy(rs.standard_normal((33, 2)).astype(np.float32))
+    stats = np.concatenate([rs.uniform(0.1, 0.5, 3), rs.uniform(1.0, 3.0, 3), rs.uniform(-4, -2, 3), rs.uniform(2, 4, 3),
+                            [-np.pi, np.pi]])
+    b = boxes.cuda()
+    r = descale_box_params(b, stats=stats)
+    assert r.data_ptr() == b.data_ptr()
+    assert torch.allclose(b.cpu(), orc.descale_box_params(boxes, stats), atol=1e-6, rtol=1e-6)
+    a = postprocess_sincos2arctan(sc.cuda())
+    assert tuple(a.shape) == (33, 1)
+    assert torch.allclose(a.cpu(), orc.sincos2arctan(sc), atol=2e-6)
+
+
+@pytest.mark.parametrize('B,n,m', [(1, 5000, 5000), (3, 700, 1234), (2, 1, 9)])
+def test_chamfer_vs_oracle(B, n, m):
+    """The reference's only native kernel (extension/old_chamfer), re-designed for CDNA4: squared NN distances,
+    indices and the autograd backward vs the CPU oracle (shapes incl. consistency_check.py's 1x5000x3 clouds)."""
+    from echoscene_amd.chamfer import chamferDist
+    from oracle import echoscene_oracle as orc
+    rs = np.random.RandomState(n)
+    a = torch.from_numpy(rs.standard_normal((B, n, 3)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal((B, m, 3)).astype(np.float32))
+    ac, bc = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    d1, d2 = chamferDist()(ac, bc)
+    r1, i1, r2, i2 = orc.chamfer_forward(a, b)
+    assert torch.allclose(d1.detach().cpu(), r1, atol=1e-6, rtol=1e-5) and torch.allclose(d2.detach().cpu(), r2, atol=1e-6, rtol=1e-5)
+    w1 = torch.from_numpy(rs.standard_normal((B, n)).astype(np.float32))
+    w2 = torch.from_numpy(rs.standard_normal((B, m)).astype(np.float32))
+    ((d1 * w1.cuda()).sum() + (d2 * w2.cuda()).sum()).backward()
+    g1, g2 = orc.chamfer_backward(a, b, w1, w2, i1, i2)
+    assert torch.allclose(ac.grad.cpu(), g1, atol=2e-4, rtol=1e-4) and torch.allclose(bc.grad.cpu(), g2, atol=2e-4, rtol=1e-4)
