@@ -14,6 +14,7 @@
 //     contraction epilogue.
 #include "es_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -25,14 +26,14 @@ __device__ __forceinline__ int f_swz(int row) { return (0x1320 >> (((row >> 2) &
 constexpr int GN_VT = 64;
 
 // 4 channels per thread (16-B loads), 64 voxels per workgroup, then channel -> group reduction in LDS.
-__global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* part) {
+__global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* part, int vt) {
     // part: [O][ntiles][groups][2]
     __shared__ float ssum4[4][2048], ssq4[4][2048];       // per voxel-row lane partials (fixed-order combine: deterministic)
     float* ssum = ssum4[0];
     float* ssq = ssq4[0];
     const int o = blockIdx.y, tile = blockIdx.x, C = a.C1 + a.C2;
-    const int v0 = tile * GN_VT;
-    const int nv = min(GN_VT, a.V - v0);
+    const int v0 = tile * vt;
+    const int nv = min(vt, a.V - v0);
     const int c4n = C >> 2;
     const int CX = 64;                                   // 64 lanes span 256 channels per pass
     const int cx = threadIdx.x & (CX - 1), vy = threadIdx.x >> 6;        // 4 voxel rows in flight
@@ -68,18 +69,27 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
     __shared__ float smean[64], srstd[64];
     __shared__ float ssc[2048], ssh[2048];
     const int o = blockIdx.y, C = a.C1 + a.C2, gs = C / a.groups;
-    if (threadIdx.x < a.groups) {
+    {   // statistics: 256/groups slices of the tile list per group, combined in fixed order (deterministic), in double
+        __shared__ double ds[256], dq[256];
+        const int gi = threadIdx.x % a.groups, sl = threadIdx.x / a.groups, nsl = 256 / a.groups;
         double s = 0.0, q = 0.0;
-        for (int t = 0; t < ntiles; ++t) {
-            const float* p = part + (((long)o * ntiles + t) * a.groups + threadIdx.x) * 2;
-            s += p[0]; q += p[1];
+        if (sl < nsl)
+            for (int t = sl; t < ntiles; t += nsl) {
+                const float* p = part + (((long)o * ntiles + t) * a.groups + gi) * 2;
+                s += p[0]; q += p[1];
+            }
+        ds[threadIdx.x] = s; dq[threadIdx.x] = q;
+        __syncthreads();
+        if (threadIdx.x < a.groups) {
+            s = 0.0; q = 0.0;
+            for (int k = 0; k < nsl; ++k) { s += ds[threadIdx.x + k * a.groups]; q += dq[threadIdx.x + k * a.groups]; }
+            const double n = (double)gs * a.V;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            smean[threadIdx.x] = (float)mean;
+            srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
         }
-        const double n = (double)gs * a.V;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        smean[threadIdx.x] = (float)mean;
-        srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -246,13 +256,88 @@ __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
 //   handled by zero-page rows and masked stores (narrow test configs).
 // ---------------------------------------------------------------------------------------------
 constexpr int BN = 224, BK = 32, BNP = 256;     // BNP: B tile rows padded so that every thread issues 4 B loads
-constexpr int NSTAGE = 3;                        // LDS ring depth (tiles ks, ks+1, ks+2)
+// LDS ring depth NS_ is a template parameter: 3 (tiles ks+1, ks+2 in flight; two workgroups per CU hide the rest of
+// the load latency) or 6 for launches with <= 1 workgroup per CU (few objects per GPU, 16x4x4 level): five tiles in
+// flight, because a lone workgroup waits ~2.3 us per tile on HBM otherwise (measured 1.15 us per K step vs 0.3).
 
 struct ConvGeom {
     int O, D, H, W;          // output grid
     int Hi, Wi;              // input grid (H,W may differ from output for DOWN/UP)
     int lw, lh, ld;          // log2 of W, H, D (output)
 };
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue shared by the conv kernels.
+// MFMA D layout: lane holds D[row = q*4 + r][col = i16].  A direct store is 112 four-byte stores (+112 residual
+// loads) per wave -- measured 25 % of the kernel at the 16^3 level.  Each 16-row slab is therefore transposed
+// through LDS (the ring is free now) so that a lane owns 4 consecutive columns: 16-byte loads and stores.
+// ---------------------------------------------------------------------------------------------
+template <int BM_, int NW_>
+__device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvGeom& g, f4 (&acc)[BM_ / (NW_ / 2) / 16][7],
+                                              char* smem, long M, long m0, int n0, int wave, int lane, int S, int bz,
+                                              int ncdhw) {
+    constexpr int WROWS = BM_ / (NW_ / 2), MI = WROWS / 16;
+    const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, q = lane >> 4;
+    const int V = g.D * g.H * g.W;
+    __syncthreads();                                          // all waves done with the ring
+    float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
+    const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
+    float* part = S > 1 ? (float*)a.workspace + (long)bz * M * a.N : nullptr;   // [S][M][N] partial sums
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (vec_ok) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
+            __builtin_amdgcn_wave_barrier();
+            // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int idx = lane + 64 * t;
+                const int row = idx / 28, c4 = idx - row * 28;
+                const long m = m0 + wm * WROWS + i * 16 + row;
+                const int n = n0 + wn * 112 + c4 * 4;
+                if (m < M && n < a.N) {
+                    f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
+                    if (part) { *(f4*)&part[m * a.N + n] = v; continue; }
+                    if (a.bias) v += *(const f4*)&a.bias[n];
+                    if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
+                    if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
+                    if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = v;
+                    if (a.out_f16) {
+                        h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + wm * WROWS + i * 16 + q * 4 + r;
+                if (m >= M) continue;
+                const long o = m / V;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int n = n0 + wn * 112 + j * 16 + i16;
+                    if (n >= a.N) continue;
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    if (a.rowvec) v += a.rowvec[o * a.rowvec_ld + n];
+                    if (a.res) v += a.res[m * a.out_ld + n];
+                    if (ncdhw) {
+                        a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
+                    } else {
+                        if (a.out_f32) a.out_f32[m * a.out_ld + n] = v;
+                        if (a.out_f16) ((_Float16*)a.out_f16)[m * a.out_ld + n] = (_Float16)v;
+                    }
+                }
+            }
+        }
+    }
+}
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -263,8 +348,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 //   <256, 8> wave tile 64 x 112 (16^3 and 16x8x8 levels: A+B bytes per flop -32 % vs <128,4>)
 //   <128, 4> wave tile 64 x 112
 //   < 64, 4> wave tile 32 x 112 (16x4x4 level: enough workgroups to cover the 256 CUs)
-template <int BM_, int NW_>
-__global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw_) {
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int BM_, int NW_, int NS_>
+__global__ __launch_bounds__(64 * NW_, NS_ > 3 ? 1 : 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw_) {
     int ncdhw = ncdhw_;
     constexpr int NT = 64 * NW_;                 // threads
     constexpr int WROWS = BM_ / (NW_ / 2);       // rows per wave
@@ -279,8 +366,26 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.O * g.D * g.H * g.W;
-    const long m0 = (long)blockIdx.x * BM_;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile mapping.  The dispatcher places hardware workgroup id b on XCD b % 8 (observed, speed only):
+    // taken literally, the 8 row tiles that share one weight slab (same column tile / K split) would sit on 8
+    // different XCDs and every XCD's L2 would pull the whole weight matrix from HBM (measured: the 16x4x4 level ran
+    // at 300 GB/s of weight traffic per XCD-copy, 6x off the MFMA time).  Remap (bijective for any grid size) so that
+    // each XCD owns a contiguous range of logical ids = x fastest: neighbours in x share the B slab and the
+    // A halo (adjacent depth slices) inside one L2.
+    int bx, by, bz;
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = L % (int)gridDim.x;
+        const int t = L / (int)gridDim.x;
+        by = t % (int)gridDim.y;
+        bz = t / (int)gridDim.y;
+        if (dbg & 64) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }      // A/B switch: literal mapping
+    }
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
 
     // ---- per-lane staging roles (fixed for the whole K loop) ----
     int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
@@ -310,7 +415,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
     const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
     // split-K: this workgroup handles K steps [ks_begin, ks_end) of the nks steps
     const int S = gridDim.z;
-    const int ks_begin = (int)((long)nks * blockIdx.z / S), ks_end = (int)((long)nks * (blockIdx.z + 1) / S);
+    const int ks_begin = (int)((long)nks * bz / S), ks_end = (int)((long)nks * (bz + 1) / S);
     const int nloc = ks_end - ks_begin;
     int st_phase = ks_begin >= nks0 ? 1 : 0;
     int st_tap = st_phase ? 0 : ks_begin % a.taps;
@@ -323,7 +428,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
     auto set_phase = [&]() __attribute__((always_inline)) {
         const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
         const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
-        b_base = Wg + ((long)blockIdx.y * nks_ph) * (BNP * BK) + tid * 8;
+        b_base = Wg + ((long)by * nks_ph) * (BNP * BK) + tid * 8;
         const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
         const int Cin = st_phase ? a.Cin2 : a.Cin;
         const int mode = st_phase ? (int)ES_CONV_SAME : a.mode;
@@ -439,21 +544,22 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
     // fragments was measured slower: LDS latency is not what this loop waits for)
     {
         h8 af[MI], bfr[7];
-        stage(0);
-        if (nloc > 1) stage(1);
+#pragma unroll
+        for (int t = 0; t < NS_ - 1; ++t)
+            if (t < nloc) stage(t);
         for (int ks = 0; ks < nloc; ++ks) {
-            if (ks + 1 < nloc) {
-                if (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (NLOAD == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();        // also: every wave finished reading ring slot (ks+2)%3 == (ks-1)%3
-            const bool pf = (ks + 2 < nloc) && !(dbg & 1);
-            const int slot = (ks + 2) % NSTAGE;
+            // tile ks must have landed; tiles ks+1 .. ks+NS_-2 may stay in flight (vmcnt counts this wave's loads)
+            const int infl = min(NS_ - 2, nloc - 1 - ks);
+            if (infl >= 4) wait_vmcnt<4 * NLOAD>();
+            else if (infl == 3) wait_vmcnt<3 * NLOAD>();
+            else if (infl == 2) wait_vmcnt<2 * NLOAD>();
+            else if (infl == 1) wait_vmcnt<NLOAD>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();        // also: every wave finished reading ring slot (ks-1)%NS_, refilled below
+            const bool pf = (ks + NS_ - 1 < nloc) && !(dbg & 1);
+            const int slot = (ks + NS_ - 1) % NS_;
             if (pf) stage_prep();
-            if (!(dbg & 8)) load_frags(ks % NSTAGE, af, bfr);
+            if (!(dbg & 8)) load_frags(ks % NS_, af, bfr);
             // MFMA rows interleaved with the LDS-DMA pieces of tile ks+2 (order pinned with sched_barrier)
             constexpr int PPR = (NLOAD + MI - 1) / MI;           // pieces per MFMA row
 #pragma unroll
@@ -475,70 +581,237 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_mfma(const es_conv_args a,
         }
     }
 
-    // ---- epilogue ----
-    // MFMA D layout: lane holds D[row = q*4 + r][col = i16].  A direct store is 112 four-byte stores (+112 residual
-    // loads) per wave -- measured 25 % of the kernel at the 16^3 level.  Each 16-row slab is therefore transposed
-    // through LDS (the ring is free now) so that a lane owns 4 consecutive columns: 16-byte loads and stores.
     if (dbg & 4) { if (acc[0][0][0] == 123.456f) a.out_f32[0] = 1.f; return; }
-    const int V = g.D * g.H * g.W;
-    __syncthreads();                                          // all waves done with the ring
-    float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
-    const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
-    float* part = S > 1 ? (float*)a.workspace + (long)blockIdx.z * M * a.N : nullptr;   // [S][M][N] partial sums
+    conv_epilogue<BM_, NW_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_lean: the same tiling / LDS image / epilogue as k_conv_mfma for the modes whose tap shift is one
+// wave-uniform offset (SAME, DOWN_HW, 1x1 / linear, fused 1x1 skip phase), with the K loop stripped to what the
+// hardware needs.  Why: ablation of k_conv_mfma (tools/microbench_small.py, ES_CONV_DEBUG) showed the loop was
+// INSTRUCTION-ISSUE bound, not memory or MFMA bound -- ~400 instructions per K step (64-bit pointer selects against a
+// zero page, per-piece tap arithmetic, M0 through VALU + readfirstlane, the inlined up-sampling path) against 28 MFMAs:
+// 0.64 us per K step with all loads removed, 0.19 us of it MFMA.  Here:
+//   * A and B stream through `buffer_load_dwordx4 ... offen lds`: the tap shift and the channel chunk are ONE scalar
+//     soffset per K step, the per-lane voffset is loop-invariant, and halo / ragged rows are lanes whose voffset is
+//     out of range -- the hardware writes zeros for them (probe: tools/probes/probe_buffer_lds.hip), no zero page,
+//     no 64-bit select;
+//   * the per-tap offsets sit in one VGPR (lane t = tap t) and are fetched with v_readlane;
+//   * the ring slot is a compile-time constant (loop unrolled x3): LDS fragment reads use immediate offsets.
+// ---------------------------------------------------------------------------------------------
+template <int BM_, int NW_, int ABL = 0>      // ABL: ablation bits for tools/microbench_conv.py (1 no DMA, 2 no MFMA, 8 no LDS reads)
+__global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    constexpr int NS = 3;
+    constexpr int NT = 64 * NW_;
+    constexpr int WROWS = BM_ / (NW_ / 2);
+    constexpr int MI = WROWS / 16;
+    constexpr int NA = BM_ * 4 / NT;
+    constexpr int NB = BNP * 4 / NT;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NLOAD = NA + NB;
+    constexpr unsigned OOB = 0x80000000u;        // >= num_records of both descriptors: the lane's 16 B arrive as zeros
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_mfma)
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = L % (int)gridDim.x;
+        const int t = L / (int)gridDim.x;
+        by = t % (int)gridDim.y;
+        bz = t / (int)gridDim.y;
+    }
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
+
+    // ---- per-lane staging roles ----
+    int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
+    bool a_ok[NA];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        if (vec_ok) {
+    for (int j = 0; j < NA; ++j) {
+        const int p = tid + NT * j;
+        const int row = p >> 2;
+        a_lc[j] = (p & 3) ^ f_swz(row);
+        const long m = m0 + row;
+        a_ok[j] = m < M;
+        const long mm = a_ok[j] ? m : 0;
+        a_w[j] = (int)(mm & (g.W - 1));
+        a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
+        a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+        a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
+    }
+    const int kch0 = a.Cin >> 5;
+    const int nks0 = a.taps * kch0;
+    const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
+    const int S = gridDim.z;
+    const int ks_begin = (int)((long)nks * bz / S), ks_end = (int)((long)nks * (bz + 1) / S);
+    const int nloc = ks_end - ks_begin;
+    // K-step generator state (wave-uniform): phase, tap, channel chunk, byte offset of the B block
+    int st_phase = ks_begin >= nks0 ? 1 : 0;
+    int st_tap = st_phase ? 0 : ks_begin % a.taps;
+    int st_c = st_phase ? (ks_begin - nks0) : (ks_begin / a.taps);               // chunk index (32 channels)
+    int st_ntap = st_phase ? 1 : a.taps, st_kch = st_phase ? (a.Cin2 >> 5) : kch0;
+    unsigned st_boff = (unsigned)(st_phase ? (ks_begin - nks0) : ks_begin) * (unsigned)B_BYTES;
+    unsigned voff[NA], msk[NA];
+    int dtab = 0;                                // lane t: byte shift of tap t (+ bias so that it is >= 0)
+    __amdgpu_buffer_rsrc_t rA, rB;
+    auto set_phase = [&]() __attribute__((always_inline)) {
+        const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
+        const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + ((long)by * nks_ph) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+        const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
+        const int Cin = st_phase ? a.Cin2 : a.Cin;
+        const bool down = !st_phase && a.mode == ES_CONV_DOWN_HW;
+        const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+        const int ntap = st_phase ? 1 : a.taps;
+        const int bias = ntap == 27 ? ((Hi + 1) * Wi + 1) * Cin * 2 : 0;          // bytes; largest negative tap shift
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ag - bias), (short)0, (int)OOB, 0x00020000);
+        {
+            const int t = lane < 27 ? lane : 13;
+            const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+            dtab = ntap == 27 ? ((kd * Hi + kh) * Wi + kw) * Cin * 2 + bias : 0;
+        }
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < NA; ++j) {
+            const int ch = down ? 2 * a_h[j] : a_h[j];
+            const int cw = down ? 2 * a_w[j] : a_w[j];
+            voff[j] = (unsigned)(((((long)a_o[j] * g.D + a_d[j]) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+            unsigned m = 0;
+            if (ntap == 1) {
+                m = a_ok[j] ? 1u : 0u;
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
-            __builtin_amdgcn_wave_barrier();
-            // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
-#pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int idx = lane + 64 * t;
-                const int row = idx / 28, c4 = idx - row * 28;
-                const long m = m0 + wm * WROWS + i * 16 + row;
-                const int n = n0 + wn * 112 + c4 * 4;
-                if (m < M && n < a.N) {
-                    f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
-                    if (part) { *(f4*)&part[m * a.N + n] = v; continue; }
-                    if (a.bias) v += *(const f4*)&a.bias[n];
-                    if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
-                    if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
-                    if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = v;
-                    if (a.out_f16) {
-                        h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
-                    }
+                for (int t = 0; t < 27; ++t) {
+                    const int id = a_d[j] + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
+                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+                    m |= (ok ? 1u : 0u) << t;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            msk[j] = m;
+        }
+    };
+    set_phase();
+    const unsigned voffB = (unsigned)tid * 16u;
+
+    unsigned sA = 0, sbit = 1;                   // per-K-step scalars of the tile being staged
+    auto stage_prep = [&]() __attribute__((always_inline)) {
+        sA = (unsigned)__builtin_amdgcn_readlane(dtab, st_tap) + (unsigned)st_c * 64u;
+        sbit = 1u << st_tap;
+    };
+    auto stage_piece = [&](int slot, int pj) __attribute__((always_inline)) {
+        char* dst = smem + slot * STAGE_BYTES + wave * 1024;
+        if (pj < NA) {
+            const unsigned vo = (msk[pj] & sbit) ? voff[pj] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + pj * (NT * 16)), 16, (int)vo, (int)sA, 0, 0);
         } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = m0 + wm * WROWS + i * 16 + q * 4 + r;
-                if (m >= M) continue;
-                const long o = m / V;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const int n = n0 + wn * 112 + j * 16 + i16;
-                    if (n >= a.N) continue;
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[n];
-                    if (a.rowvec) v += a.rowvec[o * a.rowvec_ld + n];
-                    if (a.res) v += a.res[m * a.out_ld + n];
-                    if (ncdhw) {
-                        a.out_f32[(o * a.N + n) * V + (m - o * V)] = v;
-                    } else {
-                        if (a.out_f32) a.out_f32[m * a.out_ld + n] = v;
-                        if (a.out_f16) ((_Float16*)a.out_f16)[m * a.out_ld + n] = (_Float16)v;
-                    }
-                }
+            const int j = pj - NA;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + A_BYTES + j * (NT * 16)), 16, (int)voffB,
+                                                     (int)(st_boff + (unsigned)j * (NT * 16)), 0, 0);
+        }
+    };
+    auto stage_advance = [&]() __attribute__((always_inline)) {
+        st_boff += (unsigned)B_BYTES;
+        if (++st_tap == st_ntap) {
+            st_tap = 0;
+            if (++st_c == st_kch && !st_phase && a.a2) {
+                st_phase = 1; st_c = 0; st_ntap = 1; st_kch = a.Cin2 >> 5; st_boff = 0;
+                set_phase();
             }
         }
+    };
+    auto stage_all = [&](int slot) __attribute__((always_inline)) {
+        stage_prep();
+#pragma unroll
+        for (int pj = 0; pj < NLOAD; ++pj) stage_piece(slot, pj);
+        stage_advance();
+    };
+
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int i16 = lane & 15, q = lane >> 4;
+    // fragment read addresses: row bits 2..3 (the swizzle key) come from i16 only, so one per-lane base serves every
+    // 16-row MFMA tile with an immediate offset
+    const int fragA = (wm * WROWS + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+
+    unsigned long long tm[4] = {0, 0, 0, 0}, tlast = 0;      // ABL & 16: cycles in vmcnt wait / barrier / rest of the step
+    stage_all(0);
+    if (nloc > 1) stage_all(1);
+    int ks = 0;
+    auto body = [&](auto slot_c) __attribute__((always_inline)) {
+        constexpr int RS = decltype(slot_c)::value;          // ring slot read in this step
+        constexpr int WS = (RS + 2) % NS;                    // ring slot refilled (tile ks + 2)
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if constexpr (ABL & 16) t0 = __builtin_readcyclecounter();
+        if (ks + 1 < nloc) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+        if constexpr (ABL & 16) t1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();            // tile ks visible to all waves; all waves done reading slot WS
+        if constexpr (ABL & 16) { t2 = __builtin_readcyclecounter(); tm[0] += t1 - t0; tm[1] += t2 - t1; if (tlast) tm[2] += t0 - tlast; tlast = t2; }
+        const bool pf = (ks + 2 < nloc) && !(ABL & 1);
+        if (pf) stage_prep();
+        h8 af[MI], bfr[7];
+        const char* As = smem + RS * STAGE_BYTES;
+        if constexpr (!(ABL & 8)) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) bfr[j] = *(const h8*)(As + fragB + j * 1024);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(As + fragA + i * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) bfr[j] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+        }
+        constexpr int PPR = (NLOAD + MI - 1) / MI;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (!(ABL & 2)) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            } else {
+                acc[i][0][0] += (float)af[i][0] + (float)bfr[i][0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 32)) {
+                if (pf) {
+#pragma unroll
+                    for (int pp = 0; pp < PPR; ++pp)
+                        if (i * PPR + pp < NLOAD) stage_piece(WS, i * PPR + pp);
+                }
+            } else {
+                // staggered schedule: the first half of the waves issue their whole share of tile ks+2 before the
+                // second MFMA row, the other half (their SIMD partners) after the last row
+                if (pf && ((i == 0 && wave < NW_ / 2) || (i == MI - 1 && wave >= NW_ / 2))) {
+#pragma unroll
+                    for (int pj = 0; pj < NLOAD; ++pj) stage_piece(WS, pj);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (pf) stage_advance();
+    };
+    while (true) {
+        body(std::integral_constant<int, 0>{}); if (++ks >= nloc) break;
+        body(std::integral_constant<int, 1>{}); if (++ks >= nloc) break;
+        body(std::integral_constant<int, 2>{}); if (++ks >= nloc) break;
     }
+    if constexpr (ABL & 16) {
+        if (lane == 0 && (bx == 0 || bx == 100) && by == 0 && bz == 0)
+            printf("timing bx %d wave %d: K steps %d  vmcnt-wait %.0f  barrier %.0f  compute+issue %.0f cycles/step\n", bx, wave, nloc,
+                   (double)tm[0] / nloc, (double)tm[1] / nloc, (double)tm[2] / (nloc - 1));
+    }
+    conv_epilogue<BM_, NW_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,8 +1117,12 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
     if (!g_zero_page) if (int rc = es_vol_init()) return rc;
     const long M = (long)a->O * a->D * a->H * a->W;
-    if (a->N <= 4 && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16 &&
-        (size_t)a->N * 27 * a->Cin * 2 <= 60000) {
+    // N <= 4 with a narrow input (VQ-VAE conv_out 64 -> 1 at 64^3): direct kernel, weights in the rows layout.  Wider
+    // inputs (UNet eps conv 224 -> 3) go through the MFMA tile: 98 % column padding, but the direct kernel's 756
+    // dependent 16-B loads per voxel cost 2.4x (O=32) to 10x (O=4) more than the padded tile.
+    if (a->N <= 4 && a->taps == 27 && a->Cin <= 64) {
+        ES_REQUIRE(a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16,
+                   "es_conv_mfma_f16: the N<=4, Cin<=64 direct kernel takes SAME mode, fp32 output, no fusions");
         hipLaunchKernelGGL(k_conv_small_n, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->N * 27 * a->Cin * 2,
                            (hipStream_t)stream, *a, g, ncdhw);
         ES_CHECK_HIP(hipGetLastError());
@@ -860,12 +1137,26 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const long wg256 = ((M + 255) / 256) * ntn, wg128 = ((M + 127) / 128) * ntn;
     const int nks = a->taps * (a->Cin / 32) + (a->a2 ? a->Cin2 / 32 : 0);
     static bool attr_set = false;
-    constexpr int LDS256 = NSTAGE * (256 * BK * 2 + BNP * BK * 2), LDS128 = NSTAGE * (128 * BK * 2 + BNP * BK * 2),
-                  LDS64 = NSTAGE * (64 * BK * 2 + BNP * BK * 2);
+    constexpr int LDS256 = 3 * (256 * BK * 2 + BNP * BK * 2), LDS128 = 3 * (128 * BK * 2 + BNP * BK * 2),
+                  LDS64 = 3 * (64 * BK * 2 + BNP * BK * 2);
     if (!attr_set) {
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<256, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+#ifdef ES_CONV_ABLATION
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 26>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+#endif
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -883,15 +1174,41 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const int flags = ncdhw | (dbgf << 8);
     static const char* tile_env = getenv("ES_CONV_TILE");     // A/B switch: force 128-row tiles
     const bool no256 = tile_env && atoi(tile_env) == 128;
+    // k_conv_lean: every mode whose tap shift is wave-uniform, tensors addressable with 31-bit byte offsets
+    static const char* old_env = getenv("ES_CONV_OLD");       // A/B switch: 1 = always the general kernel
+    const long in_bytes = (long)a->O * a->D * g.Hi * g.Wi * a->Cin * 2 + 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
+    const long in2_bytes = a->a2 ? M * a->Cin2 * 2 : 0;
+    const bool lean = (a->mode == ES_CONV_SAME || a->mode == ES_CONV_DOWN_HW) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
+                      !(old_env && atoi(old_env) == 1) && dbgf == 0;
     if (wg256 >= 256 && S == 1 && !no256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, 1);
-        hipLaunchKernelGGL((k_conv_mfma<256, 8>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
+#ifdef ES_CONV_ABLATION      /* tools/microbench_conv.py: build with -DES_CONV_ABLATION, select with ES_LEAN_ABL=<bits> */
+        static const char* abl_env = getenv("ES_LEAN_ABL");
+        const int abl = abl_env ? atoi(abl_env) : 0;
+        bool done = true;
+        if (!lean) done = false;
+        else if (abl == 1) hipLaunchKernelGGL((k_conv_lean<256, 8, 1>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 2) hipLaunchKernelGGL((k_conv_lean<256, 8, 2>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 8) hipLaunchKernelGGL((k_conv_lean<256, 8, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 9) hipLaunchKernelGGL((k_conv_lean<256, 8, 9>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 10) hipLaunchKernelGGL((k_conv_lean<256, 8, 10>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 16) hipLaunchKernelGGL((k_conv_lean<256, 8, 16>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 25) hipLaunchKernelGGL((k_conv_lean<256, 8, 25>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 26) hipLaunchKernelGGL((k_conv_lean<256, 8, 26>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 32) hipLaunchKernelGGL((k_conv_lean<256, 8, 32>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else done = false;
+        if (done) { ES_CHECK_HIP(hipGetLastError()); return 0; }
+#endif
+        if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_mfma<256, 8, 3>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
-        hipLaunchKernelGGL((k_conv_mfma<128, 4>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
+        if (lean) hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_mfma<128, 4, 3>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
     } else {
         dim3 grid((unsigned)((M + 63) / 64), ntn, 1);
-        hipLaunchKernelGGL((k_conv_mfma<64, 4>), grid, dim3(256), LDS64, st, *a, g, g_zero_page, flags);
+        if (lean) hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_mfma<64, 4, 3>), grid, dim3(256), LDS64, st, *a, g, g_zero_page, flags);
     }
     if (S > 1) {
         const long n4 = M * (a->N / 4);
@@ -907,10 +1224,14 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     ES_REQUIRE(C % a->groups == 0 && C <= 2048 && a->groups <= 64, "es_groupnorm_vol: C=%d groups=%d", C, a->groups);
     ES_REQUIRE(a->C1 % 8 == 0 && a->C2 % 8 == 0, "es_groupnorm_vol: channel counts must be multiples of 8 (%d,%d)", a->C1, a->C2);
     ES_REQUIRE(a->stats != nullptr, "es_groupnorm_vol: stats scratch missing");
-    const int ntiles = (a->V + GN_VT - 1) / GN_VT;
-    float* part = a->stats;      // caller-provided scratch of O*ntiles*groups*2 floats
-    hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part);
-    const int vpb = 32;
+    // voxel-tile sizes by workgroup count: small problems (few objects per GPU when sharded) get smaller tiles
+    int vt = GN_VT;
+    while (vt > 8 && (long)a->O * ((a->V + vt - 1) / vt) < 512) vt >>= 1;
+    const int ntiles = (a->V + vt - 1) / vt;
+    float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats
+    hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
+    int vpb = 32;
+    while (vpb > 8 && (long)a->O * ((a->V + vpb - 1) / vpb) < 512) vpb >>= 1;
     hipLaunchKernelGGL(k_gn_apply, dim3((a->V + vpb - 1) / vpb, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, vpb);
     ES_CHECK_HIP(hipGetLastError());
     return 0;

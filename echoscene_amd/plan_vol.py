@@ -26,7 +26,7 @@ class PackedConv:
             raise ValueError('conv kernel must be 1x1x1 or 3x3x3')
         self.Cin = (cin + 31) // 32 * 32
         L = hip.lib()
-        if self.N <= 4 and self.taps == 27:          # consumed by the direct small-N kernel
+        if self.N <= 4 and self.taps == 27 and self.Cin <= 64:   # consumed by the direct small-N kernel (VQ-VAE conv_out)
             out = torch.empty(self.N * self.taps * self.Cin, dtype=torch.int16)
             hip.check(L.es_pack_conv_rows_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps,
                                               C.c_void_p(out.data_ptr())), 'es_pack_conv_rows_f16')
@@ -122,7 +122,7 @@ class VolBuilderMixin:
         return len(self.ops) - 1
 
     def conv(self, a_f16, pc, O, dims, mode=hip.CONV_SAME, bias=None, rowvec=None, res=None, out_f32=None,
-             out_f16=None, skip=None, ncdhw=False):
+             out_f16=None, skip=None, ncdhw=False, splitk=None):
         """dims = (D,H,W) of the OUTPUT grid. skip = (raw_f16 tensor, PackedConv) for the fused 1x1 skip."""
         D, H, W = dims
         a = ConvArgs()
@@ -144,13 +144,13 @@ class VolBuilderMixin:
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
         if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0:
-            need = 8 * M * pc.N
+            need = max(8, splitk or 0) * M * pc.N
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
                 self._ws = self.buf(need)
                 for op in self.ops:
-                    if op.kind == hip.OP_CONV and op.u.conv.splitk == -1:
+                    if op.kind == hip.OP_CONV and op.u.conv.workspace:
                         op.u.conv.workspace = self._ws.data_ptr()
-            a.workspace, a.splitk = self._ws.data_ptr(), -1
+            a.workspace, a.splitk = self._ws.data_ptr(), (-1 if splitk is None else splitk)
         self.keep += [pc, bt, skip]
         self.weight_bytes += pc.weight_bytes
         self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
@@ -162,8 +162,11 @@ class VolBuilderMixin:
         a.x2, a.C2 = (x2.data_ptr(), C2) if x2 is not None else (None, 0)
         a.O, a.V, a.groups, a.eps = O, V, groups, eps
         a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), int(silu)
-        ntiles = (V + 63) // 64
-        a.stats = self.buf(O * ntiles * groups * 2).data_ptr()
+        need = O * ((V + 7) // 8) * groups * 2          # es_groupnorm_vol: scratch for the smallest voxel tile (8)
+        st = getattr(self, '_gn_stats', None)           # one scratch shared by all GroupNorms (same stream, in order)
+        if st is None or st.numel() < need:
+            st = self._gn_stats = self.buf(need)
+        a.stats = st.data_ptr()
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
         self.keep += [gamma, beta]

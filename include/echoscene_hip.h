@@ -137,8 +137,8 @@ enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW 
 
 typedef struct es_conv_args {
     const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
-    const void* w;            /* f16 weights packed by es_pack_conv_f16 (tiled LDS-image order); for N <= 4
-                                 3x3x3 convs: es_pack_conv_rows_f16 ([N][27][Cin])                  */
+    const void* w;            /* f16 weights packed by es_pack_conv_f16 (tiled LDS-image order); for N <= 4,
+                                 Cin <= 64 3x3x3 convs: es_pack_conv_rows_f16 ([N][27][Cin])        */
     int32_t O, D, H, W;       /* OUTPUT spatial size                                             */
     int32_t Cin, N;           /* N = true number of output channels                              */
     int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
@@ -178,7 +178,7 @@ typedef struct es_gn_args {
     int32_t groups; float eps;
     const float* gamma; const float* beta;   /* [C1+C2]                                         */
     int32_t silu;                    /* 0 none, 1 SiLU, 2 GELU (VQ-VAE norm_out, vqvae_modules.py:404-406) */
-    float* stats;                    /* scratch [O, groups, 2]                                  */
+    float* stats;                    /* scratch, O*ceil(V/8)*groups*2 floats (per-tile partials)  */
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
 } es_gn_args;

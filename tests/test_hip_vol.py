@@ -253,8 +253,10 @@ def test_unet3d_full_eps_vs_reference_golden(dev):
 
 
 def test_two_object_shards_equal_unsharded(dev):
-    """The multi-GPU decomposition on one GPU: two shards (world=2) stepped with a simulated all-gather give
-    bit-identical latents to the unsharded run (every kernel treats objects independently)."""
+    """The multi-GPU decomposition on one GPU: two shards (world=2) stepped with a simulated all-gather give the
+    latents of the unsharded run.  Every kernel treats objects independently; tile sizes / K splits adapt to the
+    LOCAL object count, so the fp32 summation order (not the arithmetic) may differ; a last-bit fp32 difference can
+    flip the fp16 rounding of an MFMA operand (2^-11 relative on that element), hence 2e-3 (measured 5e-4 after 4 steps)."""
     g = load_golden('ddim_tiny')
     noise1 = synth.shape_noise(seed=7)
     z_ref = _shape(dev, 32, 64, 'unet3d_tiny.', 4).sample(g['uc_s'], g['triples'], noise1)
@@ -277,4 +279,6 @@ def test_two_object_shards_equal_unsharded(dev):
         for sh in shards:
             sh.step(i, codes)
     z = torch.cat([sh.latents_local() for sh in shards], 0)
-    assert torch.equal(z, z_ref)
+    e = _rel(z, z_ref)
+    print('two shards vs unsharded: rel err %.3e' % e)
+    assert e < 2e-3

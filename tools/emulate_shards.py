@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Single-GPU emulation of rank 0 of an N-way object-sharded shape loop (no collective: the all-gather is
+replaced by a local pad) -> predicted strong-scaling curve before the driver's 8-GPU run.
+usage: python tools/emulate_shards.py [--nodes 32] [--steps 20]"""
+import argparse, os, sys, time, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from echoscene_amd import parallel
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--nodes', type=int, default=32)
+ap.add_argument('--steps', type=int, default=20)
+ap.add_argument('--worlds', default='1,2,4,8')
+a = ap.parse_args()
+dev = torch.device('cuda', 0)
+O = a.nodes
+net, lden, obj_embed, triples = bench.build_layout(dev, O, seed=100)
+
+
+def fake_gather(local, num_rows, world, group=None):
+    out = torch.zeros((num_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out[:local.shape[0]] = local
+    return out
+
+
+parallel.all_gather_rows = fake_gather
+res = {}
+for w in [int(x) for x in a.worlds.split(',')]:
+    df, sden, uc = bench.build_shape(dev, O, 100, triples, 0, w)
+    noise1 = torch.randn(1, 3, 16, 16, 16, device=dev)
+    sden.sample(uc, triples, noise1=noise1, n_steps=3)
+    ss = next(iter(sden._plans.values()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if w == 1:
+        ss['plan'].sample(ss['step'], 0, a.steps)
+    else:
+        sden._cur, sden._use_graph = ss, True
+        parallel.sharded_ddim_loop(sden, O, a.steps, w)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    res[w] = dt * 1e3
+    print('world %d: O_local %d  shape step %.3f ms  speed-up vs 1: %.2f' % (w, ss['hi'] - ss['lo'], dt * 1e3, res[1] / (dt * 1e3) if 1 in res else 0), flush=True)
+    del df, sden, ss
+    torch.cuda.empty_cache()
+print(json.dumps(res))
