@@ -8,10 +8,13 @@ box loop (BASELINE configs[1]); with ``--workload full`` one layout step + one D
 over the same O objects (the metric's "layout+SDF" step; needs the volume path).
 Inputs (weights, graph, noise tables) are resident in HBM before the timed region starts.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI): ONE scene whose objects are
-block-partitioned over the ranks (the per-object shape UNet is 99.98 % of the step FLOPs); each DDIM step
-exchanges the 64-d conv-pool codes with one all-gather ("echo" message passing), the layout branch is
-replicated.  Strong scaling: value = steps of that one scene / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  The objects of the collated
+(block-diagonal) batch graph are block-partitioned over the ranks (the per-object shape UNet is 99.98 % of the step
+FLOPs); each DDIM step exchanges the 64-d conv-pool codes with one all-gather ("echo" message passing) and every
+rank runs the small shape GCN on the full graph.
+  --scaling weak (default): a batch of N scenes of --nodes objects each, collated as the reference's collate_fn does
+      (BASELINE configs[4]); per-GPU work is fixed, value = N scenes x steps / max-over-ranks time (scene-steps/s).
+  --scaling strong: ONE scene sharded over the N GPUs (BASELINE configs[3]); value = steps / time.
 """
 import argparse
 import json
@@ -28,15 +31,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s ac
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 
 
-def build_layout(dev, O, seed):
+def build_layout(dev, O, seed, graph_seed=None):
     from echoscene_amd import synth, config as escfg
     from echoscene_amd.model.unet import UNet1DModel
     from echoscene_amd.samplers import LayoutDenoiser
     net = UNet1DModel(**escfg.layout_denoiser_kwargs(512))
     synth.seeded_fill_(net, prefix='bench.layout.')
     den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(1000), dev)
-    objs, triples = synth.synthetic_graph(O, seed=seed)
-    rs = torch.Generator().manual_seed(seed)
+    objs, triples = synth.synthetic_graph(O, seed=seed if graph_seed is None else graph_seed)
+    rs = torch.Generator().manual_seed(seed if graph_seed is None else graph_seed)
     obj_embed = torch.randn(O, 640, generator=rs)
     return net, den, obj_embed, triples
 
@@ -90,6 +93,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--workload', default='full', choices=['full', 'layout'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     a = ap.parse_args()
@@ -112,9 +116,20 @@ def main():
 
     O = a.nodes
     full = a.workload == 'full'
-    # N > 1: ONE scene, its objects block-partitioned over the ranks (strong scaling);
-    # the layout branch (1 % of the work, couples all nodes every step) is replicated on every rank.
-    net, den, obj_embed, triples = build_layout(dev, O, seed=100)
+    weak = a.scaling == 'weak' and world > 1
+    scenes = world if weak else 1
+    # strong: ONE scene, objects block-partitioned over the ranks; the layout branch (1 % of
+    #         the work, couples all nodes of a scene every step) is replicated on every rank.
+    # weak:   `world` scenes collated into one block-diagonal graph; the shape branch shards its objects (= one scene
+    #         per rank for equal scene sizes) and still exchanges codes / runs the GCN on the full graph (the code path
+    #         does not look at connectivity); each rank runs the layout loop of its own scene.
+    net, den, obj_embed, triples = build_layout(dev, O, seed=100, graph_seed=100 + (rank if weak else 0))
+    if weak:
+        from echoscene_amd import synth
+        objs_all, triples_all = synth.collate_graphs([synth.synthetic_graph(O, seed=100 + s) for s in range(scenes)])
+    else:
+        triples_all = triples
+    O_all = O * scenes
     use_graph = not a.no_graph
     # untimed warm-up (also builds the plans and captures the graphs)
     den.sample(obj_embed, triples, noise=None, n_steps=max(a.warmup, 1), use_graph=use_graph)
@@ -122,9 +137,9 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O, 100, triples, rank, world)
+        df, sden, uc = build_shape(dev, O_all, 100, triples_all, rank, world)
         noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
-        sden.sample(uc, triples, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
+        sden.sample(uc, triples_all, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
         ss['x'].normal_()
     torch.cuda.synchronize()
@@ -154,7 +169,7 @@ def main():
             else:                               # per-step echo all-gather over RCCL (parallel.sharded_ddim_loop)
                 from echoscene_amd.parallel import sharded_ddim_loop
                 sden._cur, sden._use_graph = ss, use_graph
-                sharded_ddim_loop(sden, O, n, world)
+                sharded_ddim_loop(sden, O_all, n, world)
             done += n
         ev[3].record()
     torch.cuda.synchronize()
@@ -172,7 +187,7 @@ def main():
 
     if rank == 0:
         ms_per_step = wall * 1e3 / a.steps
-        value = a.steps / wall
+        value = scenes * a.steps / wall           # scene-steps per second (scenes == 1 unless weak scaling)
         T = int(triples.shape[0])
         lay = {'steps_per_s': round(a.steps / (lay_ms * 1e-3), 2), 'ms_per_step': round(lay_ms / a.steps, 4),
                'kernels_per_step': st['plan'].n_ops, 'weight_bytes_per_step': st['plan'].weight_bytes,
@@ -184,12 +199,14 @@ def main():
                 'metric': 'denoising steps/sec (layout+SDF) for 32-node scene-graph, 64^3 SDF (3x16^3 latent), '
                           'full step = one DDPM layout step + one DDIM shape step over all objects',
                 'value': round(value, 4), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
+                'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling,
                 'vs_baseline': None, 'dtype': 'f16 MFMA operands / f32 accumulate (shape UNet); f32 (layout, GCN)',
                 'data': 'synthetic',
                 'config': {'workload': 'EchoScene full (layout+SDF) %d-node synthetic graph (T=%d), 3x16^3 latent -> '
-                                       '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules; 1 scene, objects sharded over %d GPU(s)'
-                                       % (O, T, world), 'hip_graph': use_graph, 'layout': lay,
+                                       '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules; %s'
+                                       % (O, T, ('%d scenes collated into one graph, one per GPU, echo all-gather of codes every step'
+                                                 % scenes) if weak else ('1 scene, objects sharded over %d GPU(s)' % world)),
+                           'scenes': scenes, 'hip_graph': use_graph, 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
                                      'kernels_per_step': ss['plan'].n_ops,
@@ -203,7 +220,7 @@ def main():
             out = {
                 'metric': 'denoising steps/sec (layout box-denoiser loop, 32-node scene graph, 1000-step DDPM)',
                 'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-                'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': 'strong',
+                'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': a.scaling,
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'configs[1]: EchoLayout box diffusion, %d-node synthetic graph (T=%d triples), '
                                        '1000-step DDPM, HIP denoiser + graph conv' % (O, T),
