@@ -283,6 +283,40 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
     const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
     float* part = S > 1 ? (float*)a.workspace + (long)bz * M * a.N : nullptr;   // [S][M][N] partial sums
+    if (a.epilogue == ES_EPI_GEGLU) {
+        // wave wn = 0 holds 112 value columns, its partner wn = 1 the matching 112 gate columns (tile-interleaved
+        // weight packing): both transpose their slab into LDS, the value wave combines and stores f16 [M, 4C].
+        const float* vslab = (const float*)smem + (wave & ~1) * (16 * 116);    // value slab (wn = 0 wave of the pair)
+        const float* gslab = vslab + 16 * 116;                                  // gate slab (wn = 1)
+        const int oc0 = n0 >> 1;                              // output column of this tile's first value column
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
+            __syncthreads();
+            // each wave of the pair combines 8 of the 16 rows: 8 x 28 float4 = 224 items, 3.5 per lane
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t;
+                if (idx < 224) {
+                    const int row = idx / 28 + 8 * wn, c4 = idx % 28;
+                    const long m = m0 + wm * WROWS + i * 16 + row;
+                    if (m < M) {
+                        const f4 v = *(const f4*)&vslab[row * 116 + c4 * 4] + *(const f4*)&a.bias[n0 + c4 * 4];
+                        const f4 gt = *(const f4*)&gslab[row * 116 + c4 * 4] + *(const f4*)&a.bias[n0 + 112 + c4 * 4];
+                        h4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] * es_gelu(gt[e]));
+                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + oc0 + c4 * 4) = hv;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         if (vec_ok) {
@@ -598,8 +632,14 @@ __global__ __launch_bounds__(64 * NW_, NS_ > 3 ? 1 : 2) void k_conv_mfma(const e
 //     no 64-bit select;
 //   * the per-tap offsets sit in one VGPR (lane t = tap t) and are fetched with v_readlane;
 //   * the ring slot is a compile-time constant (loop unrolled x3): LDS fragment reads use immediate offsets.
+// Tried on top of this and measured neutral (kept out): a register double buffer of the fragments (reads of step
+// ks+1 under the MFMAs of step ks, 4 tiles in flight), a 6-deep ring for lone workgroups, issuing a wave's DMA pieces
+// in one block staggered against its SIMD partner.
 // ---------------------------------------------------------------------------------------------
-template <int BM_, int NW_, int ABL = 0>      // ABL: ablation bits for tools/microbench_conv.py (1 no DMA, 2 no MFMA, 8 no LDS reads)
+// UP_: nearest-neighbour up-sampling fused into the gather (UP_HW / UP_DHW): the source of tap k along an up-sampled
+// axis is (x + k) >> 1, i.e. the centre source shifted by -1 (k = -1, x even), +1 (k = +1, x odd) or 0 -- two per-lane
+// byte shifts per axis, selected by the wave-uniform tap.
+template <int BM_, int NW_, int ABL = 0, bool UP_ = false>      // ABL: ablation bits (1 no DMA, 2 no MFMA, 8 no LDS reads)
 __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a, const ConvGeom g, int ncdhw) {
     constexpr int NS = 3;
     constexpr int NT = 64 * NW_;
@@ -659,6 +699,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     int st_ntap = st_phase ? 1 : a.taps, st_kch = st_phase ? (a.Cin2 >> 5) : kch0;
     unsigned st_boff = (unsigned)(st_phase ? (ks_begin - nks0) : ks_begin) * (unsigned)B_BYTES;
     unsigned voff[NA], msk[NA];
+    int upm[NA][3], upp[NA][3];                  // UP_: byte shift of tap -1 / +1 along (d, h, w) for this lane's row
     int dtab = 0;                                // lane t: byte shift of tap t (+ bias so that it is >= 0)
     __amdgpu_buffer_rsrc_t rA, rB;
     auto set_phase = [&]() __attribute__((always_inline)) {
@@ -670,18 +711,29 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
         const bool down = !st_phase && a.mode == ES_CONV_DOWN_HW;
         const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
         const int ntap = st_phase ? 1 : a.taps;
+        const bool updhw = UP_ && a.mode == ES_CONV_UP_DHW;
+        const int Di = updhw ? g.D / 2 : g.D;
         const int bias = ntap == 27 ? ((Hi + 1) * Wi + 1) * Cin * 2 : 0;          // bytes; largest negative tap shift
         rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ag - bias), (short)0, (int)OOB, 0x00020000);
         {
             const int t = lane < 27 ? lane : 13;
             const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
             dtab = ntap == 27 ? ((kd * Hi + kh) * Wi + kw) * Cin * 2 + bias : 0;
+            if (UP_) dtab = ntap == 27 ? (updhw ? 0 : kd * Hi * Wi * Cin * 2) + bias : 0;     // h, w (and d) shifts are per lane
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int ch = down ? 2 * a_h[j] : a_h[j];
             const int cw = down ? 2 * a_w[j] : a_w[j];
             voff[j] = (unsigned)(((((long)a_o[j] * g.D + a_d[j]) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+            if (UP_) {
+                const int sd = updhw ? a_d[j] >> 1 : a_d[j];
+                voff[j] = (unsigned)(((((long)a_o[j] * Di + sd) * Hi + (a_h[j] >> 1)) * Wi + (a_w[j] >> 1)) * Cin * 2 + a_lc[j] * 16);
+                const int SD = Hi * Wi * Cin * 2, SH = Wi * Cin * 2, SW = Cin * 2;
+                upm[j][0] = (updhw && !(a_d[j] & 1)) ? -SD : 0; upp[j][0] = (updhw && (a_d[j] & 1)) ? SD : 0;
+                upm[j][1] = !(a_h[j] & 1) ? -SH : 0;            upp[j][1] = (a_h[j] & 1) ? SH : 0;
+                upm[j][2] = !(a_w[j] & 1) ? -SW : 0;            upp[j][2] = (a_w[j] & 1) ? SW : 0;
+            }
             unsigned m = 0;
             if (ntap == 1) {
                 m = a_ok[j] ? 1u : 0u;
@@ -689,7 +741,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
                     const int id = a_d[j] + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
-                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
                     m |= (ok ? 1u : 0u) << t;
                 }
             }
@@ -700,14 +752,22 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     const unsigned voffB = (unsigned)tid * 16u;
 
     unsigned sA = 0, sbit = 1;                   // per-K-step scalars of the tile being staged
+    int ukd = 0, ukh = 0, ukw = 0;               // UP_: tap coordinates of the tile being staged
     auto stage_prep = [&]() __attribute__((always_inline)) {
         sA = (unsigned)__builtin_amdgcn_readlane(dtab, st_tap) + (unsigned)st_c * 64u;
         sbit = 1u << st_tap;
+        if (UP_) { ukd = st_tap / 9 - 1; ukh = (st_tap / 3) % 3 - 1; ukw = st_tap % 3 - 1; }
     };
     auto stage_piece = [&](int slot, int pj) __attribute__((always_inline)) {
         char* dst = smem + slot * STAGE_BYTES + wave * 1024;
         if (pj < NA) {
-            const unsigned vo = (msk[pj] & sbit) ? voff[pj] : OOB;
+            unsigned vs = voff[pj];
+            if (UP_) {
+                vs += (unsigned)(ukd < 0 ? upm[pj][0] : ukd > 0 ? upp[pj][0] : 0);
+                vs += (unsigned)(ukh < 0 ? upm[pj][1] : ukh > 0 ? upp[pj][1] : 0);
+                vs += (unsigned)(ukw < 0 ? upm[pj][2] : ukw > 0 ? upp[pj][2] : 0);
+            }
+            const unsigned vo = (msk[pj] & sbit) ? vs : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + pj * (NT * 16)), 16, (int)vo, (int)sA, 0, 0);
         } else {
             const int j = pj - NA;
@@ -1104,6 +1164,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     ES_REQUIRE(a->taps == 27 || a->taps == 1, "es_conv_mfma_f16: taps=%d", a->taps);
     ES_REQUIRE(!a->a2 || (a->Cin2 % 32 == 0 && a->Cin2 > 0), "es_conv_mfma_f16: Cin2=%d", a->Cin2);
     ES_REQUIRE(a->out_f32 || a->out_f16, "es_conv_mfma_f16: no output");
+    ES_REQUIRE(a->epilogue == ES_EPI_NONE || (a->epilogue == ES_EPI_GEGLU && a->N % 224 == 0 && a->out_f16 && !a->out_f32 && !a->res &&
+                                              !a->rowvec && !a->a2 && a->bias && a->out_ld >= a->N / 2 && a->out_ld % 4 == 0 && a->splitk <= 1),
+               "es_conv_mfma_f16: GEGLU epilogue needs N %% 224 == 0 (N=%d), bias, f16 output only, no split-K", a->N);
     ConvGeom g;
     g.O = a->O; g.D = a->D; g.H = a->H; g.W = a->W;
     g.Hi = a->H; g.Wi = a->W;
@@ -1157,6 +1220,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
 #endif
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1170,6 +1236,17 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             while (S > 1 && nks / S < 24) --S;
         }
     }
+    bool split256 = false;
+    if (a->splitk < 0 && S == 1 && can_split && wg256 >= 256) {
+        // tile quantisation: e.g. 384 workgroups of 256 rows on 256 CUs = 2 rounds, the second half empty.  Split K by
+        // the smallest factor that fills the last round (>= 95 %) if the plain launch wastes more than 20 %.
+        const long r1 = (wg256 + 255) / 256;
+        if ((double)wg256 / (double)(r1 * 256) < 0.8)
+            for (int s2 = 2; s2 <= 4; ++s2) {
+                const long w = wg256 * s2;
+                if ((double)w / (double)(((w + 255) / 256) * 256) >= 0.95 && nks / s2 >= 48) { S = s2; split256 = true; break; }
+            }
+    }
     if (S <= 1 || !can_split) S = 1;
     const int flags = ncdhw | (dbgf << 8);
     static const char* tile_env = getenv("ES_CONV_TILE");     // A/B switch: force 128-row tiles
@@ -1178,10 +1255,11 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     static const char* old_env = getenv("ES_CONV_OLD");       // A/B switch: 1 = always the general kernel
     const long in_bytes = (long)a->O * a->D * g.Hi * g.Wi * a->Cin * 2 + 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
     const long in2_bytes = a->a2 ? M * a->Cin2 * 2 : 0;
-    const bool lean = (a->mode == ES_CONV_SAME || a->mode == ES_CONV_DOWN_HW) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
+    const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
+    const bool lean = (!upm || (!a->a2 && a->taps == 27)) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
                       !(old_env && atoi(old_env) == 1) && dbgf == 0;
-    if (wg256 >= 256 && S == 1 && !no256) {
-        dim3 grid((unsigned)((M + 255) / 256), ntn, 1);
+    if (wg256 >= 256 && (S == 1 || split256) && !no256) {
+        dim3 grid((unsigned)((M + 255) / 256), ntn, S);
 #ifdef ES_CONV_ABLATION      /* tools/microbench_conv.py: build with -DES_CONV_ABLATION, select with ES_LEAN_ABL=<bits> */
         static const char* abl_env = getenv("ES_LEAN_ABL");
         const int abl = abl_env ? atoi(abl_env) : 0;
@@ -1199,15 +1277,18 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         else done = false;
         if (done) { ES_CHECK_HIP(hipGetLastError()); return 0; }
 #endif
-        if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<256, 8, 0, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_mfma<256, 8, 3>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
-        if (lean) hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
+        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<128, 4, 0, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
+        else if (lean) hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_mfma<128, 4, 3>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
     } else {
         dim3 grid((unsigned)((M + 63) / 64), ntn, 1);
-        if (lean) hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
+        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<64, 4, 0, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
+        else if (lean) hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_mfma<64, 4, 3>), grid, dim3(256), LDS64, st, *a, g, g_zero_page, flags);
     }
     if (S > 1) {

@@ -17,6 +17,7 @@ SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
 CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU = 0, 1
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
 OP_VQ = 12
 OP_FORK, OP_JOIN = 13, 14
@@ -47,7 +48,7 @@ class ConvArgs(C.Structure):
                 ('W', C.c_int32), ('Cin', C.c_int32), ('N', C.c_int32), ('taps', C.c_int32), ('mode', C.c_int32),
                 ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
                 ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
-                ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32)]
+                ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32), ('epilogue', C.c_int32)]
 
 
 class GNArgs(C.Structure):

@@ -18,8 +18,17 @@ from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn)
 class PackedConv:
     """f16 [Npad][taps][Cin32] image of a conv / linear weight + fp32 bias on the device."""
 
-    def __init__(self, W, b, device):
+    def __init__(self, W, b, device, geglu=False):
         W = W.detach().float().contiguous().cpu()
+        self.geglu = False
+        if geglu and W.dim() == 2 and (W.shape[0] // 2) % 112 == 0 and b is not None:
+            # GEGLU fused into the contraction epilogue (ES_EPI_GEGLU): per 224-column tile 112 value rows, then their
+            # 112 gate rows (value = first half of the projection, attention.py:39-46)
+            C4 = W.shape[0] // 2
+            idx = torch.cat([torch.cat([torch.arange(t, t + 112), C4 + torch.arange(t, t + 112)]) for t in range(0, C4, 112)])
+            W = W[idx].contiguous()
+            b = b.detach().float()[idx].contiguous()
+            self.geglu = True
         self.N, cin = W.shape[0], W.shape[1]
         self.taps = 1 if W.dim() == 2 else int(W[0, 0].numel())
         if self.taps not in (1, 27):
@@ -94,7 +103,7 @@ class UNet3DWeights:
                                                  sd[tb + '.attn1.to_v.weight']], 0), None, device)
                 d['o1'] = PC(tb + '.attn1.to_out.0.weight', tb + '.attn1.to_out.0.bias')
                 d['o2'] = PL(tb + '.attn2.to_out.0.weight', tb + '.attn2.to_out.0.bias')     # rows path
-                d['ff1'] = PC(tb + '.ff.net.0.proj.weight', tb + '.ff.net.0.proj.bias')
+                d['ff1'] = PackedConv(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
                 d['ff2'] = PC(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
                 d['proj_out'] = PackedConv(sd[name + '.proj_out.weight'].flatten(1), sd[name + '.proj_out.bias'], device)
                 self.ca[name] = (len(ca_v), it[1])
@@ -122,7 +131,7 @@ class VolBuilderMixin:
         return len(self.ops) - 1
 
     def conv(self, a_f16, pc, O, dims, mode=hip.CONV_SAME, bias=None, rowvec=None, res=None, out_f32=None,
-             out_f16=None, skip=None, ncdhw=False, splitk=None):
+             out_f16=None, skip=None, ncdhw=False, splitk=None, epilogue=0, out_ld=None):
         """dims = (D,H,W) of the OUTPUT grid. skip = (raw_f16 tensor, PackedConv) for the fused 1x1 skip."""
         D, H, W = dims
         a = ConvArgs()
@@ -140,10 +149,11 @@ class VolBuilderMixin:
         a.res = res.data_ptr() if res is not None else None
         a.out_f32 = out_f32.data_ptr() if out_f32 is not None else None
         a.out_f16 = out_f16.data_ptr() if out_f16 is not None else None
-        a.out_ld = -1 if ncdhw else pc.N
+        a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
+        a.epilogue = epilogue
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
-        if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0:
+        if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
             need = max(8, splitk or 0) * M * pc.N
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
                 self._ws = self.buf(need)
@@ -323,10 +333,13 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, row=lo), res=t0, out_f32=t2)
                 l3 = b.buf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
-                gl = b.buf(M, 8 * Cc)
-                b.conv(l3, d['ff1'], O, dm, out_f32=gl)
                 gg = b.buf(M, 4 * Cc, dtype=f16)
-                b.geglu(gl, M, 4 * Cc, gg)
+                if d['ff1'].geglu:               # GEGLU in the contraction epilogue: the [M, 8C] fp32 tensor never exists
+                    b.conv(l3, d['ff1'], O, dm, out_f16=gg, epilogue=hip.EPI_GEGLU, out_ld=4 * Cc)
+                else:
+                    gl = b.buf(M, 8 * Cc)
+                    b.conv(l3, d['ff1'], O, dm, out_f32=gl)
+                    b.geglu(gl, M, 4 * Cc, gg)
                 t3 = b.buf(M, Cc, dtype=f16)
                 b.conv(gg, d['ff2'], O, dm, res=t2, out_f16=t3)
                 o = b.buf(M, Cc)

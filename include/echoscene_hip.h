@@ -162,7 +162,12 @@ typedef struct es_conv_args {
                                  cannot fill 256 CUs otherwise).  -1: let the library choose.            */
     int32_t out_ld;           /* leading dimension of both outputs and of res (>= N);
                                  out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
+    int32_t epilogue;         /* ES_EPI_NONE, or ES_EPI_GEGLU: GEGLU (attention.py:39-46) fused into the FeedForward
+                                 proj: the weight rows are packed tile-interleaved (per 224-column tile: 112 value
+                                 rows c0..c0+111, then their 112 gate rows 4C+c0..), N = 8C, the only output is
+                                 out_f16 [M, 4C] = (value + b) * gelu(gate + b), out_ld = leading dim of that  */
 } es_conv_args;
+enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
 /* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
  * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
