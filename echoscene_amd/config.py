@@ -59,11 +59,14 @@ def load_yaml(path):
 # config/full_mp.yaml:18-52 (layout), config/sdfusion-txt2shape_mp.yaml (shape),
 # config/vqvae_snet.yaml (VQ-VAE).  SURVEY.md appendix A.
 # ---------------------------------------------------------------------------
-def layout_denoiser_kwargs(model_channels=512, enable_t_emb=True):
+def layout_denoiser_kwargs(model_channels=512, enable_t_emb=True, concat=False):
+    """config/full_mp.yaml:18-37; ``concat=True``: config/full_concat_mp.yaml:18-37 (AttentionBlocks instead of
+    spatial transformers, the GCN output appended to the box vector)."""
     return AttrDict(
         dims=1, in_channels=8, out_channels=8, model_channels=model_channels,
         channel_mult=[1, 1, 1, 1], num_res_blocks=2, attention_resolutions=[4, 2], num_heads=8,
-        use_spatial_transformer=True, transformer_depth=1, conditioning_key='crossattn',
+        use_spatial_transformer=not concat, transformer_depth=1,
+        conditioning_key='concat' if concat else 'crossattn',
         concat_dim=1280, crossattn_dim=1280, use_checkpoint=True, enable_t_emb=enable_t_emb)
 
 
@@ -73,7 +76,15 @@ def layout_diffusion_kwargs(time_num=1000):
                     loss_iou=False, iou_type='obb', train_stats_file=None)
 
 
-def shape_unet_params(model_channels=224):
+def shape_unet_params(model_channels=224, concat=False):
+    """config/sdfusion-txt2shape_mp.yaml; ``concat=True``: config/sdfusion-txt2shape_concat_mp.yaml (in_channels 5,
+    dims 4 = Conv3d with stride 2 / nearest x2 in all three axes, AttentionBlocks, no context)."""
+    if concat:
+        return AttrDict(
+            image_size=16, in_channels=5, out_channels=3, model_channels=model_channels,
+            num_res_blocks=2, attention_resolutions=[4, 2], channel_mult=[1, 2, 3], num_heads=8, dims=4,
+            use_spatial_transformer=False, transformer_depth=1, context_dim=None, use_checkpoint=True,
+            legacy=False, messsage_passing=True, enable_t_emb=True)
     return AttrDict(
         image_size=16, in_channels=3, out_channels=3, model_channels=model_channels,
         num_res_blocks=2, attention_resolutions=[4, 2], channel_mult=[1, 2, 3], num_heads=8, dims=3,
@@ -81,12 +92,12 @@ def shape_unet_params(model_channels=224):
         legacy=False, messsage_passing=True, enable_t_emb=True)
 
 
-def shape_df_conf(model_channels=224):
+def shape_df_conf(model_channels=224, concat=False):
     return AttrDict(
         model=AttrDict(params=AttrDict(linear_start=0.00085, linear_end=0.012,
-                                       conditioning_key='crossattn', timesteps=1000,
+                                       conditioning_key='concat' if concat else 'crossattn', timesteps=1000,
                                        scale_factor=0.18215)),
-        unet=AttrDict(params=shape_unet_params(model_channels)))
+        unet=AttrDict(params=shape_unet_params(model_channels, concat)))
 
 
 def vqvae_conf(ch=64):

@@ -50,7 +50,11 @@ static int dispatch(const es_op& op, hipStream_t s) {
         case ES_OP_DDPM: return es_ddpm_update(&op.u.update, s);
         case ES_OP_DDIM: return es_ddim_update(&op.u.update, s);
         case ES_OP_COPY:
-            ES_CHECK_HIP(hipMemcpyAsync(op.u.copy.dst, op.u.copy.src, op.u.copy.bytes, hipMemcpyDeviceToDevice, s));
+            if (op.u.copy.rows > 1)
+                ES_CHECK_HIP(hipMemcpy2DAsync(op.u.copy.dst, op.u.copy.dst_pitch, op.u.copy.src, op.u.copy.src_pitch,
+                                              op.u.copy.bytes, (size_t)op.u.copy.rows, hipMemcpyDeviceToDevice, s));
+            else
+                ES_CHECK_HIP(hipMemcpyAsync(op.u.copy.dst, op.u.copy.src, op.u.copy.bytes, hipMemcpyDeviceToDevice, s));
             return 0;
         case ES_OP_CONV: return es_conv_mfma_f16(&op.u.conv, s);
         case ES_OP_GN: return es_groupnorm_vol(&op.u.gn, s);

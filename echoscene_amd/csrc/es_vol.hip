@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int
 
 // ---------------------------------------------------------------------------------------------
 // conv-pool stem of shape_messsage_passing (openai_model_3d.py:757-764), fp32, tiny.
-//   stage 1: Conv3d(3->32,k3,p1) @16^3 then MaxPool3d(2,2)  -> [O,32,8,8,8]
+//   stage 1: Conv3d(3|4->32,k3,p1) @16^3 then MaxPool3d(2,2)  -> [O,32,8,8,8]   (4 input channels: 'concat' family)
 //   stage 2: Conv3d(32->64,k3,p1) @8^3 then MaxPool3d(k=2,s=4) -> [O,64,2,2,2] -> flatten(512)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stem1(const es_stem_args a) {
@@ -196,13 +196,14 @@ __global__ __launch_bounds__(256) void k_stem1(const es_stem_args a) {
     if (i >= n) return;
     const int pw = i & 7, ph = (i >> 3) & 7, pd = (i >> 6) & 7, c = (i >> 9) & 31;
     const long o = i >> 14;
-    const float* x = a.x + o * 3 * 4096;
-    const float* w = a.w0 + c * 81;
+    const int Cx = a.Cin ? a.Cin : 3;
+    const float* x = a.x + o * (a.x_ostride ? a.x_ostride : Cx * 4096);
+    const float* w = a.w0 + c * Cx * 27;
     float best = -INFINITY;
     for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
         const int d = 2 * pd + dz, h = 2 * ph + dy, ww = 2 * pw + dx;
         float s = a.b0[c];
-        for (int ci = 0; ci < 3; ++ci)
+        for (int ci = 0; ci < Cx; ++ci)
             for (int kd = 0; kd < 3; ++kd) { const int id = d + kd - 1; if (id < 0 || id > 15) continue;
                 for (int kh = 0; kh < 3; ++kh) { const int ih = h + kh - 1; if (ih < 0 || ih > 15) continue;
                     for (int kw = 0; kw < 3; ++kw) { const int iw = ww + kw - 1; if (iw < 0 || iw > 15) continue;
@@ -263,6 +264,7 @@ constexpr int BN = 224, BK = 32, BNP = 256;     // BNP: B tile rows padded so th
 struct ConvGeom {
     int O, D, H, W;          // output grid
     int Hi, Wi;              // input grid (H,W may differ from output for DOWN/UP)
+    int Di;                  // input depth (differs from D for DOWN_DHW / UP_DHW)
     int lw, lh, ld;          // log2 of W, H, D (output)
 };
 
@@ -708,7 +710,9 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
         rB = __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + ((long)by * nks_ph) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
         const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
         const int Cin = st_phase ? a.Cin2 : a.Cin;
-        const bool down = !st_phase && a.mode == ES_CONV_DOWN_HW;
+        const bool down = !st_phase && (a.mode == ES_CONV_DOWN_HW || a.mode == ES_CONV_DOWN_DHW);
+        const bool downd = !st_phase && a.mode == ES_CONV_DOWN_DHW;
+        const int Dsrc = downd ? 2 * g.D : g.D;
         const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
         const int ntap = st_phase ? 1 : a.taps;
         const bool updhw = UP_ && a.mode == ES_CONV_UP_DHW;
@@ -725,7 +729,8 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
         for (int j = 0; j < NA; ++j) {
             const int ch = down ? 2 * a_h[j] : a_h[j];
             const int cw = down ? 2 * a_w[j] : a_w[j];
-            voff[j] = (unsigned)(((((long)a_o[j] * g.D + a_d[j]) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+            const int cd = downd ? 2 * a_d[j] : a_d[j];
+            voff[j] = (unsigned)(((((long)a_o[j] * Dsrc + cd) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
             if (UP_) {
                 const int sd = updhw ? a_d[j] >> 1 : a_d[j];
                 voff[j] = (unsigned)(((((long)a_o[j] * Di + sd) * Hi + (a_h[j] >> 1)) * Wi + (a_w[j] >> 1)) * Cin * 2 + a_lc[j] * 16);
@@ -740,8 +745,8 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
             } else {
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
-                    const int id = a_d[j] + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
-                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
+                    const int id = cd + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
+                    const bool ok = a_ok[j] && id >= 0 && id < Dsrc && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
                     m |= (ok ? 1u : 0u) << t;
                 }
             }
@@ -1170,7 +1175,10 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     ConvGeom g;
     g.O = a->O; g.D = a->D; g.H = a->H; g.W = a->W;
     g.Hi = a->H; g.Wi = a->W;
+    g.Di = a->D;
     if (a->mode == ES_CONV_DOWN_HW) { g.Hi = 2 * a->H; g.Wi = 2 * a->W; }
+    if (a->mode == ES_CONV_DOWN_DHW) { g.Hi = 2 * a->H; g.Wi = 2 * a->W; g.Di = 2 * a->D; }
+    if (a->mode == ES_CONV_UP_DHW) g.Di = a->D / 2;
     if (a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW) { g.Hi = a->H / 2; g.Wi = a->W / 2; }
     g.lw = ilog2_exact(a->W); g.lh = ilog2_exact(a->H); g.ld = ilog2_exact(a->D);
     ES_REQUIRE(g.lw >= 0 && g.lh >= 0 && g.ld >= 0, "es_conv_mfma_f16: D,H,W must be powers of two (%d,%d,%d)", a->D, a->H, a->W);
@@ -1253,11 +1261,12 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const bool no256 = tile_env && atoi(tile_env) == 128;
     // k_conv_lean: every mode whose tap shift is wave-uniform, tensors addressable with 31-bit byte offsets
     static const char* old_env = getenv("ES_CONV_OLD");       // A/B switch: 1 = always the general kernel
-    const long in_bytes = (long)a->O * a->D * g.Hi * g.Wi * a->Cin * 2 + 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
+    const long in_bytes = (long)a->O * g.Di * g.Hi * g.Wi * a->Cin * 2 + 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
     const long in2_bytes = a->a2 ? M * a->Cin2 * 2 : 0;
     const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
     const bool lean = (!upm || (!a->a2 && a->taps == 27)) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
                       !(old_env && atoi(old_env) == 1) && dbgf == 0;
+    ES_REQUIRE(lean || a->mode != ES_CONV_DOWN_DHW, "es_conv_mfma_f16: DOWN_DHW needs the lean kernel (tensor < 2 GiB, ES_CONV_OLD unset)");
     if (wg256 >= 256 && (S == 1 || split256) && !no256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
 #ifdef ES_CONV_ABLATION      /* tools/microbench_conv.py: build with -DES_CONV_ABLATION, select with ES_LEAN_ABL=<bits> */

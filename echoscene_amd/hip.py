@@ -16,7 +16,7 @@ c_i32p = C.c_void_p
 SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
-CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW = 0, 1, 2, 3
+CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW, CONV_DOWN_DHW = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
 OP_VQ = 12
@@ -73,7 +73,8 @@ class GegluArgs(C.Structure):
 
 
 class CopyArgs(C.Structure):
-    _fields_ = [('dst', C.c_void_p), ('src', C.c_void_p), ('bytes', C.c_size_t)]
+    _fields_ = [('dst', C.c_void_p), ('src', C.c_void_p), ('bytes', C.c_size_t), ('rows', C.c_int32),
+                ('dst_pitch', C.c_size_t), ('src_pitch', C.c_size_t)]
 
 
 class ToClArgs(C.Structure):
@@ -83,7 +84,7 @@ class ToClArgs(C.Structure):
 
 class StemArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w0', C.c_void_p), ('b0', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p),
-                ('scratch', C.c_void_p), ('out', C.c_void_p), ('O', C.c_int32)]
+                ('scratch', C.c_void_p), ('out', C.c_void_p), ('O', C.c_int32), ('Cin', C.c_int32), ('x_ostride', C.c_int32)]
 
 
 class VQArgs(C.Structure):

@@ -107,6 +107,17 @@ class SpatialTransformer(_Holder):
         self.proj_out = Conv(dims, inner, ch, 1)
 
 
+class AttentionBlock(_Holder):
+    """AttentionBlock of the 'concat' family (denoise_net.py:316-363 == openai_model_3d.py:317-363): GroupNorm32,
+    Conv1d qkv with rows ordered [head][q|k|v][ch] (QKVAttentionLegacy), Conv1d proj_out."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.norm = Affine(ch)
+        self.qkv = Conv(1, ch, 3 * ch, 1)
+        self.proj_out = Conv(1, ch, ch, 1)
+
+
 class Downsample(_Holder):
     def __init__(self, dims, ch):
         super().__init__()
@@ -121,7 +132,7 @@ class Upsample(_Holder):
 
 class _UNetTrunk(_Holder):
     def _build_trunk(self, dims, in_channels, out_channels, model_channels, channel_mult,
-                     num_res_blocks, attention_resolutions, num_heads, context_dim):
+                     num_res_blocks, attention_resolutions, num_heads, context_dim, transformer=True):
         emb = model_channels * 4
         self.time_embed = seq(Lin(model_channels, emb), Slot(), Lin(emb, emb))
         inp, mid, out = topology(model_channels, list(channel_mult), num_res_blocks,
@@ -135,6 +146,8 @@ class _UNetTrunk(_Holder):
             if kind == 'res':
                 return ResBlock(dims, item[1], emb, item[2])
             if kind == 'attn':
+                if not transformer:
+                    return AttentionBlock(item[1])
                 return SpatialTransformer(dims, item[1], num_heads, item[1] // num_heads, context_dim)
             if kind == 'down':
                 return Downsample(dims, item[1])
@@ -160,18 +173,25 @@ class UNet1DModel(_UNetTrunk):
                  concat_dim=None, crossattn_dim=None, conditioning_key='crossattn', using_clip=True,
                  enable_t_emb=False):
         super().__init__()
-        if conditioning_key != 'crossattn' or not use_spatial_transformer or transformer_depth != 1:
+        self.concat = conditioning_key == 'concat'
+        if not ((conditioning_key == 'crossattn' and use_spatial_transformer and transformer_depth == 1) or
+                (self.concat and not use_spatial_transformer)):
             raise NotImplementedError(
-                "only the crossattn + spatial-transformer (depth 1) layout denoiser is built; "
-                "'concat' variants are SURVEY.md section 8(f) rank 2")
-        if dims != 1 or use_scale_shift_norm or resblock_updown or num_heads == -1:
+                "layout denoiser: 'crossattn' + spatial transformer (depth 1, config/full_mp.yaml) or 'concat' + "
+                "AttentionBlock (config/full_concat_mp.yaml)")
+        if dims != 1 or use_scale_shift_norm or resblock_updown or num_heads == -1 or num_head_channels != -1 \
+                or use_new_attention_order:
             raise NotImplementedError("unsupported UNet1DModel option")
+        # NOTE: the reference stores in_channels + concat_dim in self.in_channels for 'concat' (denoise_net.py:531);
+        # here in_channels stays the box dimension and trunk_in_channels is the input conv's.
         self.dims, self.in_channels, self.out_channels = 1, in_channels, out_channels
+        self.trunk_in_channels = in_channels + (concat_dim if self.concat else 0)
         self.model_channels, self.num_heads = model_channels, num_heads
         self.conditioning_key, self.using_clip, self.enable_t_emb = conditioning_key, using_clip, enable_t_emb
-        self.context_dim = crossattn_dim
-        self._build_trunk(1, in_channels, out_channels, model_channels, channel_mult,
-                          num_res_blocks, attention_resolutions, num_heads, crossattn_dim)
+        self.context_dim = None if self.concat else crossattn_dim
+        self._build_trunk(1, self.trunk_in_channels, out_channels, model_channels, channel_mult,
+                          num_res_blocks, attention_resolutions, num_heads, self.context_dim,
+                          transformer=not self.concat)
         g = 64  # gconv_dim hard-coded by the reference (denoise_net.py:717)
         add = 512 if using_clip else 0
         self.pred_embeddings = Emb(16, 2 * g)
@@ -197,26 +217,31 @@ class UNet3DModel(_UNetTrunk):
                  transformer_depth=1, context_dim=None, n_embed=None, legacy=True, using_clip=True,
                  messsage_passing=False, enable_t_emb=False, conditioning_key='concat'):
         super().__init__()
-        if conditioning_key != 'crossattn' or not use_spatial_transformer or transformer_depth != 1:
+        self.concat = conditioning_key == 'concat'
+        if not ((conditioning_key == 'crossattn' and use_spatial_transformer and transformer_depth == 1 and dims == 3) or
+                (self.concat and not use_spatial_transformer and dims == 4)):
             raise NotImplementedError(
-                "only the crossattn + spatial-transformer (depth 1) shape denoiser is built; "
-                "'concat' variants are SURVEY.md section 8(f) rank 2")
-        if dims != 3 or num_classes is not None or n_embed is not None or num_heads == -1 \
-                or use_scale_shift_norm or resblock_updown:
+                "shape denoiser: 'crossattn' + spatial transformer, dims 3 (sdfusion-txt2shape_mp.yaml) or 'concat' + "
+                "AttentionBlock, dims 4 (sdfusion-txt2shape_concat_mp.yaml)")
+        if num_classes is not None or n_embed is not None or num_heads == -1 or num_head_channels != -1 \
+                or use_scale_shift_norm or resblock_updown or use_new_attention_order:
             raise NotImplementedError("unsupported UNet3DModel option")
-        self.dims, self.in_channels, self.out_channels = 3, in_channels, out_channels
+        # dims == 4 is still Conv3d (ldm_diffusion_util.py:251-252) but strides / up-samples ALL three axes
+        self.dims, self.in_channels, self.out_channels = dims, in_channels, out_channels
         self.model_channels, self.num_heads, self.image_size = model_channels, num_heads, image_size
         self.conditioning_key, self.messsage_passing, self.enable_t_emb = \
             conditioning_key, messsage_passing, enable_t_emb
+        context_dim = 4096 if self.concat else context_dim      # x_dim (openai_model_3d.py:749-754)
         self.context_dim = context_dim
         self._build_trunk(3, in_channels, out_channels, model_channels, channel_mult,
-                          num_res_blocks, attention_resolutions, num_heads, context_dim)
+                          num_res_blocks, attention_resolutions, num_heads, None if self.concat else context_dim,
+                          transformer=not self.concat)
         if messsage_passing:
             g = 64
             self.pred_embeddings = Emb(16, 2 * g)
             # conv-pool stem that turns x_t into a 64-d shape code (openai_model_3d.py:757-764)
             self.shape_embeddings = nn.ModuleList([
-                Conv(3, 3, 32, 3), Slot(), Conv(3, 32, 64, 3), Slot(), Slot(), Lin(64 * 2 * 2 * 2, g)])
+                Conv(3, 4 if self.concat else 3, 32, 3), Slot(), Conv(3, 32, 64, 3), Slot(), Slot(), Lin(64 * 2 * 2 * 2, g)])
             obj_dim = g + context_dim
             if enable_t_emb:
                 self.shape_time_emb = Lin(model_channels * 4, g)

@@ -214,9 +214,11 @@ class Builder:
         op.u.update = a
         self.ops.append(op)
 
-    def copy(self, dst, src, nbytes):
+    def copy(self, dst, src, nbytes, rows=0, dst_pitch=0, src_pitch=0):
+        """flat copy of nbytes, or (rows > 1) a 2-D copy of rows x nbytes with byte pitches"""
         a = CopyArgs()
         a.dst, a.src, a.bytes = dst, src, nbytes
+        a.rows, a.dst_pitch, a.src_pitch = rows, dst_pitch, src_pitch
         op = Op()
         op.kind, op.lane = hip.OP_COPY, 0
         op.u.copy = a
@@ -344,6 +346,8 @@ class UNet1DWeights:
         self.topo = net.topo
         self.enable_t_emb = net.enable_t_emb
         self.in_ch, self.out_ch = net.in_channels, net.out_channels
+        self.concat = bool(getattr(net, 'concat', False))
+        self.heads = net.num_heads
         dv = lambda k: sd[k].detach().float().contiguous().to(device)
         P = lambda w, bname: PackedLinear(centre_tap(sd[w]), sd[bname] if bname else None, device)
         self.te0 = P('time_embed.0.weight', 'time_embed.0.bias')
@@ -376,6 +380,18 @@ class UNet1DWeights:
                 emb_b.append(sd[name + '.emb_layers.1.bias'])
                 self.emb_slices[name] = (off, it[2])
                 off += it[2]
+            elif kind == 'attn' and self.concat:
+                # AttentionBlock on ONE token: softmax over one key == 1, so the block is
+                # x + proj_out(V-rows of qkv(GroupNorm(x)))  (QKVAttentionLegacy rows are [head][q|k|v][ch]);
+                # the two 1x1 convs are folded into one matrix in fp64.
+                Cc = it[1]
+                ch = Cc // self.heads
+                vrows = torch.cat([torch.arange(h * 3 * ch + 2 * ch, h * 3 * ch + 3 * ch) for h in range(self.heads)])
+                Wv = centre_tap(sd[name + '.qkv.weight']).double()[vrows]
+                bv = sd[name + '.qkv.bias'].double()[vrows]
+                Wp = centre_tap(sd[name + '.proj_out.weight']).double()
+                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
+                d['av'] = PackedLinear((Wp @ Wv).float(), (Wp @ bv + sd[name + '.proj_out.bias'].double()).float(), device)
             elif kind == 'attn':
                 tb = name + '.transformer_blocks.0'
                 d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
@@ -398,12 +414,13 @@ class UNet1DWeights:
             self.items[name] = d
         # all ResBlock emb projections / all cross-attention value projections as ONE product each
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
-        self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
-        # the 11 cross-attention output projections have identical shapes -> one batched launch
-        names_ca = list(self.ca.keys())
-        assert len({self.ca[n][1] for n in names_ca}) == 1, 'batched cross-attention projections need equal widths'
-        self.o2_all = PackedLinearBatch([self.items[n]['o2'][0] for n in names_ca],
-                                        [self.items[n]['o2'][1] for n in names_ca], device)
+        if not self.concat:
+            self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
+            # the 11 cross-attention output projections have identical shapes -> one batched launch
+            names_ca = list(self.ca.keys())
+            assert len({self.ca[n][1] for n in names_ca}) == 1, 'batched cross-attention projections need equal widths'
+            self.o2_all = PackedLinearBatch([self.items[n]['o2'][0] for n in names_ca],
+                                            [self.items[n]['o2'][1] for n in names_ca], device)
         self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
         self.out_conv = P('out.2.weight', 'out.2.bias')
 
@@ -433,15 +450,17 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
     pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
     b.tags.update(emb=emb, ctx=ctx, gcn_in=View(objbuf))
-    # batched per-step side products
-    cav = b.buf(O, w.cav_all.N)
-    b.linear([seg(ctx)], w.cav_all, O, View(cav))
-    nca = len(w.ca)
-    Cca = next(iter(w.ca.values()))[1]
-    cavo_all = b.buf(nca, O, Cca)
-    b.linear([seg(View(cav, ld=w.cav_all.N, width=Cca))], w.o2_all, O, View(cavo_all.view(nca * O, Cca)),
-             a_bstride=Cca, out_bstride=O * Cca)
-    cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
+    cavo = {}
+    if not w.concat:
+        # batched per-step side products
+        cav = b.buf(O, w.cav_all.N)
+        b.linear([seg(ctx)], w.cav_all, O, View(cav))
+        nca = len(w.ca)
+        Cca = next(iter(w.ca.values()))[1]
+        cavo_all = b.buf(nca, O, Cca)
+        b.linear([seg(View(cav, ld=w.cav_all.N, width=Cca))], w.o2_all, O, View(cavo_all.view(nca * O, Cca)),
+                 a_bstride=Cca, out_bstride=O * Cca)
+        cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
     def run_block(name_prefix, blk, h_segs, hC):
@@ -473,6 +492,13 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
                 b.linear([seg(h1)], d['conv2'], O, o, prologue=hip.PRO_GN_SILU, gamma=d['gn2'][0],
                          beta=d['gn2'][1], eps=1e-5, res=resv)
                 h_segs, hC = [o], cout
+            elif kind == 'attn' and w.concat:
+                C = it[1]
+                xin = h_segs[0]
+                o = View(b.buf(O, C))
+                b.linear([seg(xin)], d['av'], O, o, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1], eps=1e-5,
+                         res=xin)
+                h_segs, hC = [o], C
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
@@ -505,6 +531,8 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
     inp, mid, out = w.topo
     hs = []
     h_segs, hC = [View(x)], w.in_ch
+    if w.concat:                               # box vector and GCN output as input channels (denoise_net.py:789-790)
+        h_segs, hC = [View(x), ctx], w.in_ch + w.ctx_dim
     for i, blk in enumerate(inp):
         h_segs, hC = run_block(f'input_blocks.{i}', blk, h_segs, hC)
         hs.append((h_segs[0], hC))

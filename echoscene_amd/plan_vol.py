@@ -56,6 +56,7 @@ class UNet3DWeights:
         self.device, self.mc, self.topo = device, net.model_channels, net.topo
         self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
         self.heads = net.num_heads
+        self.concat = bool(getattr(net, 'concat', False))
         if not self.mp:
             raise NotImplementedError('shape denoiser without message passing (config full.yaml) is not built yet')
         dv = lambda k: sd[k].detach().float().contiguous().to(device)
@@ -93,6 +94,16 @@ class UNet3DWeights:
                 emb_b.append(sd[name + '.emb_layers.1.bias'])
                 self.emb_slices[name] = (off, it[2])
                 off += it[2]
+            elif kind == 'attn' and self.concat:
+                # AttentionBlock (openai_model_3d.py:317-363).  QKVAttentionLegacy orders the qkv rows
+                # [head][q|k|v][ch]; the attention kernel wants [q | k | v] with heads inside each: row permutation.
+                Cc = it[1]
+                ch = Cc // self.heads
+                perm = torch.cat([torch.cat([torch.arange(h * 3 * ch + part * ch, h * 3 * ch + (part + 1) * ch)
+                                             for h in range(self.heads)]) for part in range(3)])
+                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
+                d['qkv'] = PackedConv(sd[name + '.qkv.weight'].flatten(1)[perm], sd[name + '.qkv.bias'][perm], device)
+                d['proj_out'] = PackedConv(sd[name + '.proj_out.weight'].flatten(1), sd[name + '.proj_out.bias'], device)
             elif kind == 'attn':
                 tb = name + '.transformer_blocks.0'
                 d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
@@ -114,7 +125,7 @@ class UNet3DWeights:
                 d['conv'] = PC(name + '.conv.weight', name + '.conv.bias')
             self.items[name] = d
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
-        self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
+        self.cav_all = None if self.concat else PackedLinear(torch.cat(ca_v, 0), None, device)
         self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
         self.out_conv = PC('out.2.weight', 'out.2.bias')
         self.in_ch, self.out_ch = net.in_channels, net.out_channels
@@ -207,17 +218,22 @@ class VolBuilderMixin:
         a.x, a.O, a.C, a.V, a.Cpad, a.out = x.data_ptr(), O, Cc, V, Cpad, out.data_ptr()
         return self._push(hip.OP_TO_CL, 'tocl', a)
 
-    def stem(self, x, w, scratch, out, O):
+    def stem(self, x, w, scratch, out, O, cin=3, ostride=0):
         a = StemArgs()
         a.x = x.data_ptr()
         a.w0, a.b0, a.w1, a.b1 = [t.data_ptr() for t in w]
         a.scratch, a.out, a.O = scratch.data_ptr(), out.data_ptr(), O
+        a.Cin, a.x_ostride = cin, ostride
         self.keep += list(w)
         return self._push(hip.OP_STEM, 'stem', a)
 
 
-def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None):
+def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None, c_dev=None):
     """One UNet3DModel.forward: x f32 [Ol,3,D,H,W] (NCDHW) -> eps_out f32 [Ol,3,D,H,W].
+
+    'concat' family (``w.concat``; c_dev f32 [Ol, V] = this rank's rows of c_s): the network input is the 5-channel
+    NCDHW staging tensor xc = [x_t (3) | c_s (1) | GCN output (1)] (diffusion_shape/network.py:26-28,
+    openai_model_3d.py:841-842); its first four channels feed the conv-pool stem.
 
     Object sharding (multi-GPU): this rank owns objects [lo, hi) of the O-node graph; x / eps_out hold only
     those.  The per-object vector ops (time MLP, GCN over the FULL graph, projections) are computed for all O
@@ -241,7 +257,16 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     objbuf = b.buf(O, Dobj)
     objbuf[:, :ucw].copy_(uc_dev)
     code512 = b.buf(Ol, 512)
-    b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
+    xc = None
+    if w.concat:
+        assert c_dev is not None and ucw == V0 and tuple(c_dev.shape) == (Ol, V0), 'concat: uc_s / c_s must be [O, D*H*W]'
+        xc = b.buf(Ol, 5, V0)
+        xc[:, 3].copy_(c_dev)                  # constant over the loop: written once at plan build
+        b.copy(xc.data_ptr(), x.data_ptr(), 3 * V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=3 * V0 * 4)
+        b.stem(xc, w.stem, b.buf(Ol, 32 * 512), code512, Ol, cin=4, ostride=5 * V0)
+        b.xc = xc
+    else:
+        b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
     if Ol == Ofull:
         b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
         b.codes_local = None
@@ -257,14 +282,19 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     b.tags.update(emb=emb, ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
     emb_all = b.buf(O, w.emb_all.N)
     b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
-    cav = b.buf(O, w.cav_all.N)
-    b.linear([seg(ctx)], w.cav_all, O, View(cav))
     cavo, coff = {}, 0
-    for name, (k, Cc) in w.ca.items():
-        o = View(b.buf(O, Cc))
-        b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
-        cavo[name] = o
-        coff += Cc
+    if w.concat:
+        # GCN output rows of the local objects -> fifth input channel
+        assert ctx.width == V0
+        b.copy(xc[:, 4].data_ptr(), ctx.ptr + lo * ctx.ld * 4, V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=ctx.ld * 4)
+    else:
+        cav = b.buf(O, w.cav_all.N)
+        b.linear([seg(ctx)], w.cav_all, O, View(cav))
+        for name, (k, Cc) in w.ca.items():
+            o = View(b.buf(O, Cc))
+            b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
+            cavo[name] = o
+            coff += Cc
 
     # ---- volume path ----
     state = dict(h=None, C=0, dims=dims, last_op=None, h16=None)
@@ -290,7 +320,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             M = O * V_(dm)
             if kind == 'conv_in':
                 xcl = b.buf(O * V0, 32, dtype=f16)
-                b.to_cl(x, O, w.in_ch, V0, 32, xcl)
+                b.to_cl(xc if w.concat else x, O, w.in_ch, V0, 32, xcl)
                 o = b.buf(M, mc)
                 state['last_op'] = b.conv(xcl, d['conv'], O, dm, out_f32=o)
                 state.update(h=o, C=mc, h16=None)
@@ -315,6 +345,18 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                     state['last_op'] = b.conv(y2, d['conv2'], O, dm, res=x1, out_f32=o)
                 state.update(h=o, C=cout, h16=None)
                 skip = None
+            elif kind == 'attn' and w.concat:
+                Cc = it[1]
+                xin = state['h']
+                yn = b.buf(M, Cc, dtype=f16)
+                b.groupnorm(xin, Cc, None, 0, O, V_(dm), d['gn'][0], d['gn'][1], 1e-5, False, yn)
+                qkv = b.buf(M, 3 * Cc, dtype=f16)
+                b.conv(yn, d['qkv'], O, dm, out_f16=qkv)
+                at = b.buf(M, Cc, dtype=f16)
+                b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
+                o = b.buf(M, Cc)
+                state['last_op'] = b.conv(at, d['proj_out'], O, dm, res=xin, out_f32=o)
+                state.update(h=o, h16=None)
             elif kind == 'attn':
                 Cc = it[1]
                 xin = state['h']
@@ -349,15 +391,15 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 state.update(h=o, h16=None)
             elif kind == 'down':
                 a16 = need_f16()
-                nd = (dm[0], dm[1] // 2, dm[2] // 2)
+                nd = (dm[0] // 2, dm[1] // 2, dm[2] // 2) if w.concat else (dm[0], dm[1] // 2, dm[2] // 2)
                 o = b.buf(O * V_(nd), state['C'])
-                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_DOWN_HW, out_f32=o)
+                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_DOWN_DHW if w.concat else hip.CONV_DOWN_HW, out_f32=o)
                 state.update(h=o, dims=nd, h16=None)
             elif kind == 'up':
                 a16 = need_f16()
-                nd = (dm[0], dm[1] * 2, dm[2] * 2)
+                nd = (dm[0] * 2, dm[1] * 2, dm[2] * 2) if w.concat else (dm[0], dm[1] * 2, dm[2] * 2)
                 o = b.buf(O * V_(nd), state['C'])
-                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_UP_HW, out_f32=o)
+                state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_UP_DHW if w.concat else hip.CONV_UP_HW, out_f32=o)
                 state.update(h=o, dims=nd, h16=None)
             b.tags[name] = View(state['h'])
 

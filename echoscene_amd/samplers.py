@@ -128,10 +128,15 @@ class ShapeDenoiser:
         self.rank, self.world, self.group = rank, world, group
         self._plans = {}
 
-    def _plan_for(self, uc, triples):
+    def _plan_for(self, uc, triples, c=None):
         from .parallel import partition
         uc = uc.reshape(uc.shape[0], -1)
         O = uc.shape[0]
+        concat = self.w.concat
+        if concat:
+            if c is None:
+                raise ValueError("'concat' shape denoiser needs the conditioning c_s [O, 4096] (echo2shape.py:234-235)")
+            c = c.reshape(O, -1).to(self.device).float()
         key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
         st = self._plans.get(key)
         if st is None:
@@ -142,11 +147,12 @@ class ShapeDenoiser:
             eps = b.buf(hi - lo, *self.z_shape)
             step = b.buf(1, dtype=torch.int32, zero=True)
             ucd = b.dev(uc)
-            objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi)
+            objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi,
+                                      c_dev=c[lo:hi] if concat else None)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
             st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
-                      codes_local=b.codes_local, code_cols=b.code_cols)
+                      codes_local=b.codes_local, code_cols=b.code_cols, xc=getattr(b, 'xc', None))
 
             def sub(ops):
                 b2 = Builder(self.device)
@@ -160,6 +166,8 @@ class ShapeDenoiser:
                 st['main_plan'] = sub(b.ops[b.split:])
             self._plans = {key: st}
         st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
+        if concat:
+            st['xc'][:, 3].copy_(c[st['lo']:st['hi']])
         return st
 
     # -- shard backend protocol of parallel.sharded_ddim_loop ------------------------------------------------
@@ -177,19 +185,19 @@ class ShapeDenoiser:
     def latents_local(self):
         return self._cur['x']
 
-    def eps(self, x, uc, triples, iteration):
+    def eps(self, x, uc, triples, iteration, c=None):
         assert self.world == 1
-        st = self._plan_for(uc, triples)
+        st = self._plan_for(uc, triples, c)
         st['x'].copy_(x.to(self.device))
         st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
         return st['eps'].clone()
 
-    def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True):
+    def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True, c=None):
         """DDIM loop; ``noise1`` f32[1,C,D,H,W] is shared by all objects as in the reference
         (echo2shape.py:507-510); None draws it on the device (world > 1: pass it, or every rank draws its own).
         Returns the latents of ALL objects [O,C,D,H,W] (all-gathered when sharded)."""
         from .parallel import sharded_ddim_loop
-        st = self._plan_for(uc, triples)
+        st = self._plan_for(uc, triples, c)
         n_steps = self.S if n_steps is None else n_steps
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)

@@ -133,7 +133,7 @@ int es_ddim_update(const es_update_args* args, es_stream stream);
  * channels-last [O, D, H, W, C]; the residual stream is fp32, every contraction reads fp16
  * operands and accumulates in fp32 on MFMA (v_mfma_f32_16x16x32_f16).
  * ---------------------------------------------------------------------------------------- */
-enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW = 3 };
+enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW = 3, ES_CONV_DOWN_DHW = 4 };
 
 typedef struct es_conv_args {
     const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
@@ -144,7 +144,9 @@ typedef struct es_conv_args {
     int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
     int32_t mode;             /* ES_CONV_*: SAME; DOWN_HW = stride (1,2,2) (Downsample, :188);
                                  UP_HW = nearest x2 on H,W folded into addressing (Upsample, :150-153);
-                                 UP_DHW = nearest x2 on D,H,W (VQ-VAE Upsample, vqvae_modules.py:24-39) */
+                                 UP_DHW = nearest x2 on D,H,W (VQ-VAE Upsample, vqvae_modules.py:24-39; 'concat' UNet,
+                                 dims=4, openai_model_3d.py:155-156); DOWN_DHW = stride 2 on D,H,W ('concat' UNet
+                                 Downsample with dims=4, :188)                                              */
     /* optional second contraction accumulated into the same tile: the 1x1 skip_connection of a
        ResBlock whose channel count changes (out = conv2(h) + skip(x), :294-314) */
     const void* a2; const void* w2; int32_t Cin2;
@@ -223,12 +225,14 @@ int es_vq_lookup(const es_vq_args* args, es_stream stream);
  * shape_messsage_passing (openai_model_3d.py:757-764). */
 int es_latent_to_cl_f16(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f16, es_stream s);
 typedef struct es_stem_args {
-    const float* x;        /* [O,3,16,16,16] fp32 NCDHW                                          */
+    const float* x;        /* [O,Cin,16,16,16] fp32 NCDHW, object stride x_ostride floats            */
     const float* w0; const float* b0;   /* Conv3d(3,32,3)  weights [32,3,3,3,3]                   */
     const float* w1; const float* b1;   /* Conv3d(32,64,3) weights [64,32,3,3,3]                  */
     float* scratch;        /* [O,32,8,8,8] pooled stage-1 output                                 */
     float* out;            /* [O,512] = flatten(MaxPool3d(k2,s4)(conv2)) in NCDHW order          */
     int32_t O;
+    int32_t Cin;           /* 3 ('crossattn': x_t) or 4 ('concat': x_t and the c_s channel); 0 = 3      */
+    int32_t x_ostride;     /* floats between objects in x; 0 = Cin * 4096                              */
 } es_stem_args;
 int es_shape_stem(const es_stem_args* args, es_stream stream);
 
@@ -242,7 +246,10 @@ enum {
     ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_VQ = 12,
     ES_OP_FORK = 13, ES_OP_JOIN = 14
 };
-typedef struct es_copy_args { void* dst; const void* src; size_t bytes; } es_copy_args;
+typedef struct es_copy_args {      /* device-to-device copy: flat (rows <= 1) or 2-D (rows x bytes with pitches) */
+    void* dst; const void* src; size_t bytes;
+    int32_t rows; size_t dst_pitch, src_pitch;
+} es_copy_args;
 typedef struct es_tocl_args { const float* x; int32_t O, C, V, Cpad; void* out; } es_tocl_args;
 typedef struct es_op {
     int32_t kind;

@@ -213,8 +213,39 @@ def spatial_transformer(sd, p, x, context, heads, nm=EXACT, trunk=False, trace=N
     return h + x
 
 
-def _run_block(sd, p, h, emb, context, heads, nm, trunk, trace=None):
-    """One TimestepEmbedSequential; sub-module kinds inferred from the keys."""
+def attention_block(sd, p, x, heads, nm=EXACT, trunk=False):
+    """AttentionBlock + QKVAttentionLegacy of the 'concat' model family (denoise_net.py:316-410 ==
+    openai_model_3d.py:317-411): GroupNorm32, 1x1 qkv with rows ordered [head][q|k|v][ch], softmax(q k^T / sqrt(ch)) v
+    per head, 1x1 proj_out, residual."""
+    shp = x.shape
+    B, C = shp[:2]
+    xf = x.reshape(B, C, -1)
+    hn = F.group_norm(xf, 32, sd[p + '.norm.weight'], sd[p + '.norm.bias'], 1e-5)
+    w, b = sd[p + '.qkv.weight'], sd[p + '.qkv.bias']
+    if trunk:
+        hn, w = nm.r(hn), nm.r(w)
+    qkv = F.conv1d(hn, w, b)
+    T = qkv.shape[-1]
+    ch = C // heads
+    q, k, v = qkv.reshape(B * heads, 3 * ch, T).split(ch, dim=1)
+    if trunk:
+        q, k, v = nm.r(q), nm.r(k), nm.r(v)
+    scale = 1.0 / math.sqrt(math.sqrt(ch))
+    wgt = torch.einsum('bct,bcs->bts', q * scale, k * scale).softmax(dim=-1)
+    if trunk:
+        wgt = nm.r(wgt)
+    a = torch.einsum('bts,bcs->bct', wgt, v).reshape(B, C, T)
+    wp = sd[p + '.proj_out.weight']
+    if trunk:
+        a, wp = nm.r(a), nm.r(wp)
+    h = F.conv1d(a, wp, sd[p + '.proj_out.bias'])
+    return (xf + h).reshape(shp)
+
+
+def _run_block(sd, p, h, emb, context, heads, nm, trunk, trace=None, full3d=False):
+    """One TimestepEmbedSequential; sub-module kinds inferred from the keys.  ``full3d``: the 'concat' shape UNet
+    is built with dims=4 (config/sdfusion-txt2shape_concat_mp.yaml), i.e. Conv3d with stride 2 / nearest x2 in ALL
+    three axes (openai_model_3d.py:150-156,188) instead of the (1,2,2) of dims=3."""
     j = 0
     while any(k.startswith(f'{p}.{j}.') for k in sd):
         q = f'{p}.{j}'
@@ -222,12 +253,16 @@ def _run_block(sd, p, h, emb, context, heads, nm, trunk, trace=None):
             h = res_block(sd, q, h, emb, nm, trunk)
         elif (q + '.transformer_blocks.0.norm1.weight') in sd:
             h = spatial_transformer(sd, q, h, context, heads, nm, trunk, trace)
-        elif (q + '.op.weight') in sd:     # Downsample: stride 2 (1-D) or (1,2,2) (3-D)
-            stride = 2 if sd[q + '.op.weight'].dim() == 3 else (1, 2, 2)
+        elif (q + '.qkv.weight') in sd:
+            h = attention_block(sd, q, h, heads, nm, trunk)
+        elif (q + '.op.weight') in sd:     # Downsample: stride 2 (1-D, dims=4) or (1,2,2) (dims=3)
+            stride = 2 if (sd[q + '.op.weight'].dim() == 3 or full3d) else (1, 2, 2)
             h = _conv(sd, q + '.op', h, nm, trunk, stride=stride)
         elif (q + '.conv.weight') in sd:   # Upsample: nearest, then conv
             if h.dim() == 3:
                 h = F.interpolate(h, scale_factor=1, mode='nearest')       # denoise_net.py:154
+            elif full3d:
+                h = F.interpolate(h, scale_factor=2, mode='nearest')
             else:
                 h = F.interpolate(h, (h.shape[2], h.shape[3] * 2, h.shape[4] * 2), mode='nearest')
             h = _conv(sd, q + '.conv', h, nm, trunk)
@@ -241,17 +276,17 @@ def _run_block(sd, p, h, emb, context, heads, nm, trunk, trace=None):
     return h
 
 
-def _unet_trunk(sd, h, emb, context, heads, nm, trunk, trace=None):
+def _unet_trunk(sd, h, emb, context, heads, nm, trunk, trace=None, full3d=False):
     hs = []
     n_in = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('input_blocks.'))
     n_out = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('output_blocks.'))
     for i in range(n_in):
-        h = _run_block(sd, f'input_blocks.{i}', h, emb, context, heads, nm, trunk, trace)
+        h = _run_block(sd, f'input_blocks.{i}', h, emb, context, heads, nm, trunk, trace, full3d)
         hs.append(h)
-    h = _run_block(sd, 'middle_block', h, emb, context, heads, nm, trunk, trace)
+    h = _run_block(sd, 'middle_block', h, emb, context, heads, nm, trunk, trace, full3d)
     for i in range(n_out):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_block(sd, f'output_blocks.{i}', h, emb, context, heads, nm, trunk, trace)
+        h = _run_block(sd, f'output_blocks.{i}', h, emb, context, heads, nm, trunk, trace, full3d)
     h = F.silu(F.group_norm(h, 32, sd['out.0.weight'], sd['out.0.bias'], 1e-5))
     return _conv(sd, 'out.2', h, nm, trunk)
 
@@ -260,6 +295,8 @@ def _unet_trunk(sd, h, emb, context, heads, nm, trunk, trace=None):
 # a4/a5  UNet1DModel.forward (+ box_messsage_passing)   denoise_net.py:758-806
 # --------------------------------------------------------------------------------------
 def unet1d_forward(sd, box_t, obj_embed, triples, timesteps, heads=8, enable_t_emb=True, trace=None):
+    """conditioning_key 'crossattn' (GCN output = the one cross-attention key) or 'concat' (GCN output appended to the
+    box vector as input channels, denoise_net.py:789-790) -- told apart by the input conv's channel count."""
     mc = sd['time_embed.0.weight'].shape[1]
     t_emb = timestep_embedding(timesteps, mc)
     emb = _linear(sd, 'time_embed.2', F.silu(_linear(sd, 'time_embed.0', t_emb)))
@@ -272,6 +309,9 @@ def unet1d_forward(sd, box_t, obj_embed, triples, timesteps, heads=8, enable_t_e
     ctx, _ = gcn_net(sd, 'box_graph_cov', obj, pred_embed, edges)
     context = ctx.unsqueeze(1)           # overwrites the caller's context (denoise_net.py:791-792)
     h = box_t.unsqueeze(1).permute(0, 2, 1)          # [O, 8, 1]
+    if sd['input_blocks.0.0.weight'].shape[1] != box_t.shape[1]:        # 'concat'
+        h = torch.cat([box_t, ctx], dim=1).unsqueeze(-1)
+        context = None
     if trace is not None:
         trace.update(emb=emb, ctx=ctx, gcn_in=obj)
     out = _unet_trunk(sd, h, emb, context, heads, EXACT, False, trace)
@@ -291,7 +331,7 @@ def shape_stem(sd, x):
 
 
 def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
-                   enable_t_emb=True, nm=EXACT, trace=None, code_all=None, rows=None):
+                   enable_t_emb=True, nm=EXACT, trace=None, code_all=None, rows=None, c_concat=None):
     """sd: keys of UNet3DModel (i.e. without the 'diffusion_net.' prefix).
 
     ``code_all`` / ``rows`` (test support for the multi-GPU sharding, echoscene_amd/parallel.py): x holds only
@@ -300,6 +340,9 @@ def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
     mc = sd['time_embed.0.weight'].shape[1]
     t_emb = timestep_embedding(timesteps, mc)
     emb = _linear(sd, 'time_embed.2', F.silu(_linear(sd, 'time_embed.0', t_emb)))
+    concat = c_concat is not None        # DiffusionUNet.forward 'concat' (diffusion_shape/network.py:26-28)
+    if concat:
+        x = torch.cat([x, c_concat.reshape(x.shape[0], -1, *x.shape[2:])], dim=1)
     if 'shape_code_graph_cov.gconvs.0.net1.0.weight' in sd:           # messsage_passing
         edges, p = _edges(triples)
         code = shape_stem(sd, x) if code_all is None else code_all
@@ -312,10 +355,14 @@ def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
         ctx, _ = gcn_net(sd, 'shape_code_graph_cov', obj, sd['pred_embeddings.weight'][p], edges)
         if rows is not None:
             ctx = ctx[rows]
-        context = ctx.unsqueeze(1)       # "we dont use the previous context" (:843-844)
+        if concat:                       # GCN output becomes a fifth input channel (:841-842)
+            x = torch.cat([x, ctx.view(-1, 1, *x.shape[2:])], dim=1)
+            context = None
+        else:
+            context = ctx.unsqueeze(1)   # "we dont use the previous context" (:843-844)
         if trace is not None:
             trace.update(emb=emb, ctx=ctx, code=code)
-    return _unet_trunk(sd, x, emb, context, heads, nm, True, trace)
+    return _unet_trunk(sd, x, emb, context, heads, nm, True, trace, full3d=concat)
 
 
 # --------------------------------------------------------------------------------------
@@ -397,7 +444,7 @@ def ddim_step(x, e_t, a_t, a_prev, sqrt_1m_at):
 
 
 def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, enable_t_emb=True,
-                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None):
+                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None, c_concat=None):
     """rel2shape's DDIM loop (echo2shape.py:484-521, ddim.py:127-181): one noise tensor shared by
     all objects, 'elif True' branch (single UNet call, no CFG), eta 0."""
     ac = shape_alphas_cumprod(linear_start, linear_end)
@@ -410,7 +457,7 @@ def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, e
         index = total - 1 - i
         step = int(ts[index])
         t_ = torch.full((O,), step, dtype=torch.long)
-        e = unet3d_forward(sd, x, uc_s, triples, t_, None, heads, enable_t_emb, nm)
+        e = unet3d_forward(sd, x, uc_s, triples, t_, None, heads, enable_t_emb, nm, c_concat=c_concat)
         x = ddim_step(x, e, a[index], a_prev[index], s1m[index])
         if trace is not None:
             trace.append(x.clone())

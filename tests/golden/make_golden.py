@@ -122,9 +122,9 @@ def case_gcn():
              cfg=np.array([96, 32, 3, 64, int(residual), int(norm == 'batch'), 80]))
 
 
-def _unet1d(model_channels, ctx_dim, time_num=1000):
+def _unet1d(model_channels, ctx_dim, time_num=1000, concat=False):
     from model.networks.diffusion_layout.denoise_net import UNet1DModel
-    kw = dict(escfg.layout_denoiser_kwargs(model_channels))
+    kw = dict(escfg.layout_denoiser_kwargs(model_channels, concat=concat))
     kw['concat_dim'] = kw['crossattn_dim'] = ctx_dim
     return UNet1DModel(**kw), kw
 
@@ -216,11 +216,12 @@ def case_unet1d_full():
     save('unet1d_full', **out)
 
 
-def _unet3d(model_channels, ctx_dim):
+def _unet3d(model_channels, ctx_dim, concat=False):
     from model.networks.diffusion_shape.network import DiffusionUNet
-    p = escfg.shape_unet_params(model_channels)
-    p['context_dim'] = ctx_dim
-    return DiffusionUNet(p, vq_conf=None, conditioning_key='crossattn')
+    p = escfg.shape_unet_params(model_channels, concat=concat)
+    if not concat:
+        p['context_dim'] = ctx_dim
+    return DiffusionUNet(p, vq_conf=None, conditioning_key='concat' if concat else 'crossattn')
 
 
 def case_unet3d_tiny():
@@ -289,6 +290,55 @@ def case_unet3d_full():
     with torch.no_grad():
         eps = net(x, uc, triples, t, c_crossattn=[uc])
     save('unet3d_full', x=x, uc_s=uc, triples=triples, t=t, eps=eps)
+
+
+def case_concat():
+    """the 'concat'-conditioned model family (config/full_concat_mp.yaml,
+    sdfusion-txt2shape_concat_mp.yaml) -- reference modules, seeded weights, tiny and full widths."""
+    # layout denoiser: eps + 10 ancestral steps
+    for tag, mc, cd, O in (('tiny', 128, 128, 8), ('full', 512, 1280, 6)):
+        net, kw = _unet1d(mc, cd, concat=True)
+        fill(net, 'unet1d_concat_%s.' % tag)
+        objs, triples = synth.synthetic_graph(O, seed=12)
+        box = rnd((O, 8), 121)
+        oe = rnd((O, 640), 122)
+        t = torch.full((O,), 437, dtype=torch.int64)
+        with torch.no_grad():
+            eps = net(box, oe, triples, t)
+        out = dict(box=box, obj_embed=oe, triples=triples, t=t, eps=eps.squeeze(-1))
+        if tag == 'tiny':
+            noise = synth.layout_noise(8, 8, 100, seed=9)
+            oe2, tri2, x, traj, _ = _layout_loop(net, kw, 8, 13, 100, 10, noise)
+            out.update(loop_obj_embed=oe2, loop_triples=tri2, loop_x10=x)
+        save('unet1d_concat_' + tag, **out)
+    # shape denoiser: eps (tiny + full) and a 4-step DDIM loop (tiny) through the reference's own sampler
+    from model.networks.diffusion_shape.echo2shape import EchoToShape
+    from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+    for tag, mc, O in (('tiny', 32, 3), ('full', 224, 2)):
+        net = _unet3d(mc, None, concat=True)
+        fill(net, 'unet3d_concat_%s.' % tag)
+        objs, triples = synth.synthetic_graph(O, seed=14)
+        x = rnd((O, 3, 16, 16, 16), 151)
+        uc = rnd((O, 1, 4096), 152)
+        c = rnd((O, 1, 16, 16, 16), 153)
+        t = torch.full((O,), 401, dtype=torch.long)
+        with torch.no_grad():
+            eps = net(x, uc, triples, t, c_concat=[c])
+        out = dict(x=x, uc_s=uc, c_s=c, triples=triples, t=t, eps=eps)
+        if tag == 'tiny':
+            shim = _ShapeShim()
+            shim.df = shim.df_module = net
+            EchoToShape.register_schedule(shim, timesteps=1000, linear_start=0.00085, linear_end=0.012)
+            shim.apply_model = lambda *a, **k: EchoToShape.apply_model(shim, *a, **k)
+            DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+            noise1 = synth.shape_noise(seed=7)
+            with torch.no_grad():
+                z, _ = DDIMSampler(shim).sample(S=4, batch_size=O, shape=(3, 16, 16, 16), conditioning=c,
+                                                x_T=noise1.repeat(O, 1, 1, 1, 1), verbose=False,
+                                                unconditional_guidance_scale=3., unconditional_conditioning=uc,
+                                                triplet=triples, eta=0.0)
+            out.update(z_final=z)
+        save('unet3d_concat_' + tag, **out)
 
 
 def _vqvae(ch, n_embed):
@@ -385,7 +435,7 @@ def case_scene_e2e():
     save('scene_e2e_tiny', **out)
 
 
-CASES = dict(gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e)

@@ -278,3 +278,22 @@ def test_linear_geglu_epilogue_and_batched(dev):
     _close(out, a * F.gelu(g), 3e-5)
     for z in range(nb):
         _close(outb[z], F.linear(A[:, z * C:(z + 1) * C], Ws[z], bs[z]), 2e-5)
+
+
+# ---- 'concat'-conditioned layout denoiser (config/full_concat_mp.yaml) ----
+@pytest.mark.parametrize('tag,mc,cd', [('tiny', 128, 128), ('full', 512, 1280)])
+def test_unet1d_concat_vs_reference_golden(dev, tag, mc, cd):
+    from echoscene_amd.model.unet import UNet1DModel
+    from echoscene_amd.samplers import LayoutDenoiser
+    g = load_golden('unet1d_concat_' + tag)
+    kw = dict(escfg.layout_denoiser_kwargs(mc, concat=True))
+    kw['concat_dim'] = kw['crossattn_dim'] = cd
+    net = UNet1DModel(**kw)
+    synth.seeded_fill_(net, prefix='unet1d_concat_%s.' % tag)
+    den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(1000), dev)
+    eps = den.eps(g['box'], g['obj_embed'], g['triples'], iteration=999 - int(g['t'][0]))
+    _close(eps, g['eps'], 1e-4)
+    if tag == 'tiny':
+        den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(100), dev)
+        x = den.sample(g['loop_obj_embed'], g['loop_triples'], synth.layout_noise(8, 8, 100, seed=9), n_steps=10)
+        _close(x, g['loop_x10'], 2e-4)

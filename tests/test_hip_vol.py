@@ -282,3 +282,52 @@ def test_two_object_shards_equal_unsharded(dev):
     e = _rel(z, z_ref)
     print('two shards vs unsharded: rel err %.3e' % e)
     assert e < 2e-3
+
+
+# ---- 'concat'-conditioned shape denoiser (sdfusion-txt2shape_concat_mp.yaml) ----
+def _shape_concat(dev, mc, prefix, S):
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    df = DiffusionUNet(escfg.shape_unet_params(mc, concat=True), conditioning_key='concat')
+    synth.seeded_fill_(df, prefix=prefix)
+    return ShapeDenoiser(df, escfg.shape_df_conf(concat=True).model.params, ddim_steps=S, device=dev)
+
+
+@pytest.mark.parametrize('tag,mc', [('tiny', 32), ('full', 224)])
+def test_unet3d_concat_eps_vs_reference_golden(dev, tag, mc):
+    """AttentionBlock / QKVAttentionLegacy, 5-channel input, stride-2 / nearest-x2 in all three axes."""
+    g = load_golden('unet3d_concat_' + tag)
+    den = _shape_concat(dev, mc, 'unet3d_concat_%s.' % tag, 100)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it, c=g['c_s'])
+    e = _rel(eps, g['eps'])
+    print('unet3d concat %s: fp16-MFMA eps vs fp32 reference golden: rel err %.3e' % (tag, e))
+    assert e < 2e-2
+
+
+def test_ddim_concat_tiny_loop_vs_reference_golden(dev):
+    g = load_golden('unet3d_concat_tiny')
+    den = _shape_concat(dev, 32, 'unet3d_concat_tiny.', 4)
+    z = den.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), c=g['c_s'])
+    e = _rel(z, g['z_final'])
+    print('ddim concat tiny: rel err %.3e' % e)
+    assert e < 2e-2
+
+
+def test_conv_down_dhw(dev):
+    """Stride-2 conv in all three axes (ES_CONV_DOWN_DHW) against F.conv3d on fp16-rounded operands."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder
+    from echoscene_amd.plan_vol import PackedConv
+    O, Cin, N, (D, H, W) = 2, 64, 48, (4, 4, 4)
+    x = _rnd((O, Cin, 2 * D, 2 * H, 2 * W), 1).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3), 2) / np.sqrt(Cin * 27)).half().float()
+    bias = _rnd((N,), 3)
+    ref = F.conv3d(x, wt, bias, stride=2, padding=1)
+    b = Builder(dev)
+    xin = b.dev(_cl(x), torch.float16)
+    out = b.buf(O * D * H * W, N, zero=True)
+    b.conv(xin, PackedConv(wt, bias, dev), O, (D, H, W), mode=hip.CONV_DOWN_DHW, out_f32=out)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, _cl(ref)) < 1e-4

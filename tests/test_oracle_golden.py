@@ -168,3 +168,34 @@ def test_scene_e2e_tiny_oracle_vs_reference_api():
             sdf = orc.vqvae_decode_no_quant(vsd, z)
             assert tuple(sdf.shape) == (O, 1, 64, 64, 64)
             _close(sdf[:, :, ::4, ::4, ::4], g['echoscene_shapes'], 2e-3)
+
+
+# --------------------------------------------------------------------------------------------------------
+# the 'concat'-conditioned model family (config/full_concat_mp.yaml,
+# sdfusion-txt2shape_concat_mp.yaml): AttentionBlock / QKVAttentionLegacy, GCN output as input channels,
+# full 3-D down/up-sampling (dims=4).  Goldens: tests/golden/make_golden.py case_concat (reference modules).
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,mc,cd', [('tiny', 128, 128), pytest.param('full', 512, 1280, marks=pytest.mark.slow)])
+def test_unet1d_concat(tag, mc, cd):
+    g = load_golden('unet1d_concat_' + tag)
+    kw = dict(escfg.layout_denoiser_kwargs(mc, concat=True))
+    kw['concat_dim'] = kw['crossattn_dim'] = cd
+    sd = seeded_state_dict(UNet1DModel(**kw), 'unet1d_concat_%s.' % tag)
+    eps = orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'])
+    _close(eps, g['eps'], 2e-5)
+    if tag == 'tiny':
+        noise = synth.layout_noise(8, 8, 100, seed=9)
+        x = orc.layout_sample_loop(sd, g['loop_obj_embed'], g['loop_triples'], noise, 100, n_steps=10)
+        _close(x, g['loop_x10'], 5e-5)
+
+
+@pytest.mark.parametrize('tag,mc', [('tiny', 32), pytest.param('full', 224, marks=pytest.mark.slow)])
+def test_unet3d_concat(tag, mc):
+    g = load_golden('unet3d_concat_' + tag)
+    df = DiffusionUNet(escfg.shape_unet_params(mc, concat=True), conditioning_key='concat')
+    sd = {k[len('diffusion_net.'):]: v for k, v in seeded_state_dict(df, 'unet3d_concat_%s.' % tag).items()}
+    eps = orc.unet3d_forward(sd, g['x'], g['uc_s'], g['triples'], g['t'], c_concat=g['c_s'])
+    _close(eps, g['eps'], 5e-5)
+    if tag == 'tiny':
+        z = orc.shape_sample_loop(sd, g['uc_s'], g['triples'], synth.shape_noise(seed=7), S=4, c_concat=g['c_s'])
+        _close(z, g['z_final'], 2e-4)
