@@ -108,9 +108,9 @@ def vqvae_conf(ch=64):
                           dropout=0.0))))
 
 
-def default_diff_opt(device='cuda', time_num=1000, logs_dir=None):
-    """Equivalent of ``OmegaConf.load('config/full_mp.yaml')`` with the two nested yaml
-    files inlined (``df_cfg`` / ``vq_cfg`` may also be paths, as in the reference)."""
+def default_diff_opt(device='cuda', time_num=1000, logs_dir=None, concat=False):
+    """Equivalent of ``OmegaConf.load('config/full_mp.yaml')`` (``concat=True``: ``config/full_concat_mp.yaml``) with
+    the two nested yaml files inlined (``df_cfg`` / ``vq_cfg`` may also be paths, as in the reference)."""
     return AttrDict(
         hyper=AttrDict(batch_size=64, gpu_ids=0, logs_dir=logs_dir, results_dir=logs_dir, name='./',
                        isTrain=False, device=device, distributed=0, lr_init=1e-4,
@@ -118,11 +118,11 @@ def default_diff_opt(device='cuda', time_num=1000, logs_dir=None):
         dataset=AttrDict(res=64, trunc_thres=0.2, ratio=1),
         layout_branch=AttrDict(
             model='diffusion_scene_layout_ddpm', angle_dim=2, denoiser='unet1d',
-            relation_condition=True, denoiser_kwargs=layout_denoiser_kwargs(),
+            relation_condition=True, denoiser_kwargs=layout_denoiser_kwargs(concat=concat),
             diffusion_kwargs=layout_diffusion_kwargs(time_num)),
         shape_branch=AttrDict(
-            model='sdfusion-txt2shape_mp', sampling='greedy', ckpt=None,
-            df_cfg=shape_df_conf(), ddim_steps=100, ddim_eta=0.0, uc_scale=3.0,
+            model='sdfusion-txt2shape_concat_mp' if concat else 'sdfusion-txt2shape_mp', sampling='greedy', ckpt=None,
+            df_cfg=shape_df_conf(concat=concat), ddim_steps=100, ddim_eta=0.0, uc_scale=3.0,
             vq_model='vqvae', vq_cfg=vqvae_conf(), vq_dset=None, vq_cat=None, vq_ckpt=None),
         misc=AttrDict(debug=0, seed=111, backend='gloo', local_rank=0))
 
@@ -135,16 +135,16 @@ def resolve_nested(cfg_or_path):
     return to_plain(cfg_or_path)
 
 
-def tiny_diff_opt(device='cuda', logs_dir=None, vq_ckpt=None):
+def tiny_diff_opt(device='cuda', logs_dir=None, vq_ckpt=None, concat=False):
     """Narrow end-to-end test configuration (same topology as full_mp.yaml, widths 128 / 32 / 32,
     100 layout steps, 64-entry codebook).  Used by tests/golden/make_golden.py (on the reference) and
     by the parity tests (on this build)."""
-    opt = default_diff_opt(device=device, time_num=100, logs_dir=logs_dir)
+    opt = default_diff_opt(device=device, time_num=100, logs_dir=logs_dir, concat=concat)
     opt.hyper.isTrain = False
-    opt.layout_branch.denoiser_kwargs = layout_denoiser_kwargs(128)
+    opt.layout_branch.denoiser_kwargs = layout_denoiser_kwargs(128, concat=concat)
     opt.layout_branch.denoiser_kwargs.concat_dim = 128
     opt.layout_branch.denoiser_kwargs.crossattn_dim = 128
-    opt.shape_branch.df_cfg = shape_df_conf(32)
+    opt.shape_branch.df_cfg = shape_df_conf(32, concat=concat)
     vqc = vqvae_conf(32)
     vqc.model.params.n_embed = 64
     opt.shape_branch.vq_cfg = vqc

@@ -174,7 +174,10 @@ class EchoToShape(object):
         if noise is None:
             g = torch.Generator(device=den.device).manual_seed(int(time.time()))
             noise = torch.randn((1,) + tuple(self.z_shape), device=den.device, generator=g)
-        z = den.sample(self.uc_rel, self.triples, noise1=noise)
+        # 'concat': c_s is a constant fourth input channel (echo2shape.py:234-235, network.py:26-28); 'crossattn' + mp
+        # ignores it (the GCN output overwrites the context, openai_model_3d.py:843-844)
+        z = den.sample(self.uc_rel, self.triples, noise1=noise,
+                       c=self.rel if self.df.conditioning_key == 'concat' else None)
         self.gen_df = self._decoder().decode_no_quant(z)
         return self.gen_df
 

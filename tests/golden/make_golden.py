@@ -360,7 +360,12 @@ def case_vqvae():
              sdf_sum=sdf.double().sum(), sdf_abs=sdf.double().abs().sum(), cfg=np.array([ch, ne]))
 
 
-def case_scene_e2e():
+def case_scene_e2e_concat():
+    """Same as case_scene_e2e for the 'concat' family (config/full_concat_mp.yaml equivalent, tiny widths)."""
+    case_scene_e2e(concat=True)
+
+
+def case_scene_e2e(concat=False):
     """The full boundary: the reference's ``SGDiff`` API end to end on CPU (SURVEY.md section 8(c)
     recipe) with a tiny-width config -- setup GCNs, 100-step layout loop, 4-step DDIM, VQ-VAE decode."""
     import tempfile
@@ -371,7 +376,7 @@ def case_scene_e2e():
     fill(vq, 'e2e.vqvae.')
     vq_path = os.path.join(tmp, 'vq.pth')
     torch.save(vq.state_dict(), vq_path)
-    opt = escfg.tiny_diff_opt(device='cpu', logs_dir=tmp, vq_ckpt=vq_path)
+    opt = escfg.tiny_diff_opt(device='cpu', logs_dir=tmp, vq_ckpt=vq_path, concat=concat)
     opt.misc.debug = 0
     import model.networks.diffusion_shape.echo2shape as e2s
     e2s.init_mesh_renderer = lambda **k: None
@@ -379,7 +384,7 @@ def case_scene_e2e():
     DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
     from model.SGDiff import SGDiff
     out = {}
-    for typ in ('echoscene', 'echolayout'):
+    for typ in (('echoscene',) if concat else ('echoscene', 'echolayout')):
         m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
                    gconv_pooling='avg', with_angles=True, clip=True, separated=False)
         synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), seed=0, prefix='e2e.diff.')
@@ -432,13 +437,13 @@ def case_scene_e2e():
             if k == 'shapes':
                 out['%s_shapes_abs' % typ] = v.double().abs().sum()
     out.update(objs=objs, triples=triples)
-    save('scene_e2e_tiny', **out)
+    save('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny', **out)
 
 
 CASES = dict(concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
-             scene_e2e=case_scene_e2e)
+             scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -37,16 +37,17 @@ def test_vqvae_decode_vs_reference_golden(tag):
     assert ea < 5e-3
 
 
-@pytest.mark.parametrize('typ', ['echolayout', 'echoscene'])
-def test_sgdiff_api_end_to_end_vs_reference_golden(typ):
-    """model.SGDiff.SGDiff(...).sample_box_and_shape on the GPU == the reference's own call (tiny widths)."""
+@pytest.mark.parametrize('typ,concat', [('echolayout', False), ('echoscene', False), ('echoscene', True)])
+def test_sgdiff_api_end_to_end_vs_reference_golden(typ, concat):
+    """model.SGDiff.SGDiff(...).sample_box_and_shape on the GPU == the reference's own call (tiny widths);
+    ``concat``: the config/full_concat_mp.yaml model family."""
     import sys
     from model.SGDiff import SGDiff          # the drop-in import path eval_3dfront.py uses
-    g = load_golden('scene_e2e_tiny')
+    g = load_golden('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny')
     objs, triples = g['objs'], g['triples']
     O = objs.shape[0]
     tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
-    m = SGDiff(typ, escfg.tiny_diff_opt('cuda'), synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
+    m = SGDiff(typ, escfg.tiny_diff_opt('cuda', concat=concat), synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
                gconv_pooling='avg', with_angles=True, clip=True, separated=False)
     synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), prefix='e2e.diff.')
     if typ == 'echoscene':

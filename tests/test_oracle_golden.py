@@ -142,16 +142,18 @@ def test_vqvae_decode(tag):
     assert abs(sdf.double().abs().sum().item() - g['sdf_abs'].item()) < 1e-4 * g['sdf_abs'].item()
 
 
-def test_scene_e2e_tiny_oracle_vs_reference_api():
+@pytest.mark.parametrize('concat', [False, True])
+def test_scene_e2e_tiny_oracle_vs_reference_api(concat):
     """Whole boundary on the CPU oracle vs the reference's own ``SGDiff.sample_box_and_shape`` (tiny widths):
-    setup GCNs -> 100-step layout loop -> rel_s_mlp -> 4-step DDIM -> VQ-VAE decode."""
+    setup GCNs -> 100-step layout loop -> rel_s_mlp -> 4-step DDIM -> VQ-VAE decode.  ``concat``: the
+    config/full_concat_mp.yaml family (c_s enters the shape denoiser as an input channel)."""
     from echoscene_amd.model.scene import SGDiff
-    g = load_golden('scene_e2e_tiny')
+    g = load_golden('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny')
     objs, triples = g['objs'], g['triples']
     O = objs.shape[0]
     tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
-    for typ in ('echoscene', 'echolayout'):
-        m = SGDiff(typ, escfg.tiny_diff_opt('cpu'), synth.VOCAB, residual=True, with_angles=True)
+    for typ in (('echoscene',) if concat else ('echoscene', 'echolayout')):
+        m = SGDiff(typ, escfg.tiny_diff_opt('cpu', concat=concat), synth.VOCAB, residual=True, with_angles=True)
         sd = seeded_state_dict(m.diff, 'e2e.diff.')
         oe, latent_m, _ = orc.scene_setup(sd, objs, triples, tf, rf, model_type=typ)
         lsd = {k[len('LayoutDiff.df.model.'):]: v for k, v in sd.items() if k.startswith('LayoutDiff.df.model.')}
@@ -163,7 +165,8 @@ def test_scene_e2e_tiny_oracle_vs_reference_api():
             uc = orc.rel_s(sd, oe)
             dsd = seeded_state_dict(m.diff.ShapeDiff.df, 'e2e.shape_df.')
             dsd = {k[len('diffusion_net.'):]: v for k, v in dsd.items()}
-            z = orc.shape_sample_loop(dsd, uc, triples, synth.shape_noise(seed=7), S=4)
+            z = orc.shape_sample_loop(dsd, uc, triples, synth.shape_noise(seed=7), S=4,
+                                      c_concat=orc.rel_s(sd, latent_m) if concat else None)
             vsd = seeded_state_dict(m.diff.ShapeDiff.vqvae, 'e2e.vqvae.')
             sdf = orc.vqvae_decode_no_quant(vsd, z)
             assert tuple(sdf.shape) == (O, 1, 64, 64, 64)
