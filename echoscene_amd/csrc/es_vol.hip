@@ -274,11 +274,19 @@ struct ConvGeom {
 // loads) per wave -- measured 25 % of the kernel at the 16^3 level.  Each 16-row slab is therefore transposed
 // through LDS (the ring is free now) so that a lane owns 4 consecutive columns: 16-byte loads and stores.
 // ---------------------------------------------------------------------------------------------
-template <int BM_, int NW_>
+// LOWREG: k_conv_ws runs 12 waves per CU (168 VGPRs): the 7 float4 items per lane are processed one at a time instead of
+// all in flight (fully unrolled the epilogue spilled 100 registers there and cost more than the K loop gained).
+template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
 __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvGeom& g, f4 (&acc)[BM_ / (NW_ / 2) / 16][7],
                                               char* smem, long M, long m0, int n0, int wave, int lane, int S, int bz,
                                               int ncdhw) {
     constexpr int WROWS = BM_ / (NW_ / 2), MI = WROWS / 16;
+    if constexpr (!ACTIVE) {
+        __syncthreads();
+        if (a.epilogue == ES_EPI_GEGLU)
+            for (int i = 0; i < MI; ++i) { __syncthreads(); __syncthreads(); }
+        return;
+    }
     const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, q = lane >> 4;
     const int V = g.D * g.H * g.W;
     __syncthreads();                                          // all waves done with the ring
@@ -329,7 +337,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
             __builtin_amdgcn_wave_barrier();
             // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
-#pragma unroll
+#pragma unroll LOWREG ? 1 : 7
             for (int t = 0; t < 7; ++t) {
                 const int idx = lane + 64 * t;
                 const int row = idx / 28, c4 = idx - row * 28;
@@ -765,6 +773,8 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     };
     auto stage_piece = [&](int slot, int pj) __attribute__((always_inline)) {
         char* dst = smem + slot * STAGE_BYTES + wave * 1024;
+        if constexpr ((ABL & 1024) != 0) { if (pj < NA) return; }       // ablation: no A pieces
+        if constexpr ((ABL & 2048) != 0) { if (pj >= NA) return; }      // ablation: no B pieces
         if (pj < NA) {
             unsigned vs = voff[pj];
             if (UP_) {
@@ -838,8 +848,16 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
             for (int i = 0; i < MI; ++i) af[i] = h8{1, 1, 1, 1, 1, 1, 1, 1};
         }
         constexpr int PPR = (NLOAD + MI - 1) / MI;
+        if constexpr (ABL & 256) {               // variant: all DMA pieces of tile ks+2 first, under the LDS read latency
+            if (pf) {
+#pragma unroll
+                for (int pj = 0; pj < NLOAD; ++pj) stage_piece(WS, pj);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            if constexpr (ABL & 512) __builtin_amdgcn_s_setprio(1);
             if constexpr (!(ABL & 2)) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j)
@@ -847,7 +865,9 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
             } else {
                 acc[i][0][0] += (float)af[i][0] + (float)bfr[i][0];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL & 512) __builtin_amdgcn_s_setprio(0);
+            if constexpr (ABL & 256) continue;
+            if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 32)) {
                 if (pf) {
 #pragma unroll
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
                     for (int pj = 0; pj < NLOAD; ++pj) stage_piece(WS, pj);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
         }
         if (pf) stage_advance();
     };
@@ -877,6 +897,231 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
                    (double)tm[0] / nloc, (double)tm[1] / nloc, (double)tm[2] / (nloc - 1));
     }
     conv_epilogue<BM_, NW_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_ws: warp-specialised version of k_conv_lean (same tile, LDS image, K order and epilogue).
+// Why: in k_conv_lean every wave alternates MFMA rows with LDS-DMA issue, and a wave is blocked for ~100-190 cycles
+// per DMA piece while the TA path accepts it -- the K step costs MFMA time PLUS DMA issue time (ablation: 0.46 us + 0.5
+// us per step; tools/microbench_conv.py).  A probe (tools/probes/probe_mfma_vs_dma.hip) shows the block is per WAVE, not
+// per SIMD: a wave that only issues DMA does not slow the MFMA stream of its SIMD partners at all (16.6 cycles per
+// MFMA with or without it).  So the roles are split: NC_ consumer waves (2 per SIMD; LDS fragment reads + MFMA, never
+// touch vmcnt) and NP_ producer waves (1 per SIMD; all LDS-DMA of the tile, counted vmcnt).  12 waves per CU need
+// <= 168 VGPRs per lane; the consumers hold 112 accumulators + 44 fragment registers.
+// One s_barrier per K step, shared by both roles:
+//   producer:  wait(own pieces of tile ks) -> barrier -> issue tile ks+2 into the slot the consumers just released
+//   consumer:  barrier -> read fragments of tile ks -> 28 MFMAs
+// ---------------------------------------------------------------------------------------------
+template <int MI, int ABL>
+__device__ __forceinline__ void ws_read_frags(const char* As, int fragA, int fragB, h8 (&af)[MI], h8 (&bfr)[7]) {
+    if constexpr (!(ABL & 8)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bfr[j] = *(const h8*)(As + fragB + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(As + fragA + i * 1024);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bfr[j] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+    }
+}
+
+template <int MI, int I0, int I1, int ABL>
+__device__ __forceinline__ void ws_mma_rows(f4 (&acc)[MI][7], const h8 (&af)[MI], const h8 (&bfr)[7]) {
+    if constexpr (!(ABL & 2)) {
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = I0; i < I1; ++i) acc[i][0][0] += (float)af[i][0] + (float)bfr[i][0];
+    }
+}
+
+template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0>
+__global__ __launch_bounds__(64 * (NC_ + NP_)) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    constexpr int NS = 3;
+    constexpr int WROWS = BM_ / (NC_ / 2);
+    constexpr int MI = WROWS / 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int APIECES = BM_ / 16, BPIECES = BNP / 16;          // 1 KiB pieces per tile
+    constexpr int NA = APIECES / NP_, NB = BPIECES / NP_, NLOAD = NA + NB;        // per producer wave
+    static_assert(APIECES % NP_ == 0 && BPIECES % NP_ == 0, "pieces must divide over the producer waves");
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_mfma)
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = L % (int)gridDim.x;
+        const int t = L / (int)gridDim.x;
+        by = t % (int)gridDim.y;
+        bz = t / (int)gridDim.y;
+    }
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
+    const int kch0 = a.Cin >> 5;
+    const int nks0 = a.taps * kch0;
+    const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
+    const int S = gridDim.z;
+    const int ks_begin = (int)((long)nks * bz / S), ks_end = (int)((long)nks * (bz + 1) / S);
+    const int nloc = ks_end - ks_begin;
+
+    if (wave >= NC_) {
+        // =============================== producer ===============================
+        const int pw = wave - NC_;
+        int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
+        bool a_ok[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (pw + NP_ * j) * 64 + lane;    // 16-B slot of the A tile: row = p >> 2, physical chunk = p & 3
+            const int row = p >> 2;
+            a_lc[j] = (p & 3) ^ f_swz(row);
+            const long m = m0 + row;
+            a_ok[j] = m < M;
+            const long mm = a_ok[j] ? m : 0;
+            a_w[j] = (int)(mm & (g.W - 1));
+            a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
+            a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+            a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
+        }
+        int st_phase = ks_begin >= nks0 ? 1 : 0;
+        int st_tap = st_phase ? 0 : ks_begin % a.taps;
+        int st_c = st_phase ? (ks_begin - nks0) : (ks_begin / a.taps);
+        int st_ntap = st_phase ? 1 : a.taps, st_kch = st_phase ? (a.Cin2 >> 5) : kch0;
+        unsigned st_boff = (unsigned)(st_phase ? (ks_begin - nks0) : ks_begin) * (unsigned)B_BYTES;
+        unsigned voff[NA], msk[NA];
+        int upm[NA][3], upp[NA][3];
+        int dtab = 0;
+        __amdgpu_buffer_rsrc_t rA, rB;
+        auto set_phase = [&]() __attribute__((always_inline)) {
+            const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
+            const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
+            rB = __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + ((long)by * nks_ph) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+            const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
+            const int Cin = st_phase ? a.Cin2 : a.Cin;
+            const bool down = !st_phase && (a.mode == ES_CONV_DOWN_HW || a.mode == ES_CONV_DOWN_DHW);
+            const bool downd = !st_phase && a.mode == ES_CONV_DOWN_DHW;
+            const int Dsrc = downd ? 2 * g.D : g.D;
+            const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+            const int ntap = st_phase ? 1 : a.taps;
+            const bool updhw = UP_ && a.mode == ES_CONV_UP_DHW;
+            const int Di = updhw ? g.D / 2 : g.D;
+            const int bias = ntap == 27 ? ((Hi + 1) * Wi + 1) * Cin * 2 : 0;
+            rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ag - bias), (short)0, (int)OOB, 0x00020000);
+            {
+                const int t = lane < 27 ? lane : 13;
+                const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+                dtab = ntap == 27 ? ((kd * Hi + kh) * Wi + kw) * Cin * 2 + bias : 0;
+                if (UP_) dtab = ntap == 27 ? (updhw ? 0 : kd * Hi * Wi * Cin * 2) + bias : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int ch = down ? 2 * a_h[j] : a_h[j];
+                const int cw = down ? 2 * a_w[j] : a_w[j];
+                const int cd = downd ? 2 * a_d[j] : a_d[j];
+                voff[j] = (unsigned)(((((long)a_o[j] * Dsrc + cd) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+                if (UP_) {
+                    const int sd = updhw ? a_d[j] >> 1 : a_d[j];
+                    voff[j] = (unsigned)(((((long)a_o[j] * Di + sd) * Hi + (a_h[j] >> 1)) * Wi + (a_w[j] >> 1)) * Cin * 2 + a_lc[j] * 16);
+                    const int SD = Hi * Wi * Cin * 2, SH = Wi * Cin * 2, SW = Cin * 2;
+                    upm[j][0] = (updhw && !(a_d[j] & 1)) ? -SD : 0; upp[j][0] = (updhw && (a_d[j] & 1)) ? SD : 0;
+                    upm[j][1] = !(a_h[j] & 1) ? -SH : 0;            upp[j][1] = (a_h[j] & 1) ? SH : 0;
+                    upm[j][2] = !(a_w[j] & 1) ? -SW : 0;            upp[j][2] = (a_w[j] & 1) ? SW : 0;
+                }
+                unsigned m = 0;
+                if (ntap == 1) {
+                    m = a_ok[j] ? 1u : 0u;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 27; ++t) {
+                        const int id = cd + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
+                        const bool ok = a_ok[j] && id >= 0 && id < Dsrc && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
+                        m |= (ok ? 1u : 0u) << t;
+                    }
+                }
+                msk[j] = m;
+            }
+        };
+        set_phase();
+        const unsigned voffB = (unsigned)lane * 16u;
+        auto stage_tile = [&](int slot) __attribute__((always_inline)) {
+            const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, st_tap) + (unsigned)st_c * 64u;
+            const unsigned sbit = 1u << st_tap;
+            int ukd = 0, ukh = 0, ukw = 0;
+            if (UP_) { ukd = st_tap / 9 - 1; ukh = (st_tap / 3) % 3 - 1; ukw = st_tap % 3 - 1; }
+            char* dst = smem + slot * STAGE_BYTES;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                unsigned vs = voff[j];
+                if (UP_) {
+                    vs += (unsigned)(ukd < 0 ? upm[j][0] : ukd > 0 ? upp[j][0] : 0);
+                    vs += (unsigned)(ukh < 0 ? upm[j][1] : ukh > 0 ? upp[j][1] : 0);
+                    vs += (unsigned)(ukw < 0 ? upm[j][2] : ukw > 0 ? upp[j][2] : 0);
+                }
+                const unsigned vo = (msk[j] & sbit) ? vs : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (pw + NP_ * j) * 1024), 16, (int)vo, (int)sA, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = pw + NP_ * j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + A_BYTES + q * 1024), 16, (int)voffB,
+                                                         (int)(st_boff + (unsigned)q * 1024u), 0, 0);
+            }
+            st_boff += (unsigned)B_BYTES;
+            if (++st_tap == st_ntap) {
+                st_tap = 0;
+                if (++st_c == st_kch && !st_phase && a.a2) {
+                    st_phase = 1; st_c = 0; st_ntap = 1; st_kch = a.Cin2 >> 5; st_boff = 0;
+                    set_phase();
+                }
+            }
+        };
+        stage_tile(0);
+        if (nloc > 1) stage_tile(1);
+        for (int ks = 0; ks < nloc; ++ks) {
+            if (ks + 1 < nloc) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of tile ks have landed
+            __builtin_amdgcn_s_barrier();        // tile ks visible to the consumers; slot (ks+2)%3 released by them
+            if (ks + 2 < nloc && !(ABL & 1)) stage_tile((ks + 2) % NS);
+        }
+        f4 dummy[MI][7];
+        conv_epilogue<BM_, NC_, false, true>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        return;
+    }
+
+    // =============================== consumer ===============================
+    const int wm = wave >> 1, wn = wave & 1;
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fragA = (wm * WROWS + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    int ks = 0;
+    h8 af[MI], bfr[7];
+    const char* const As0 = smem, * const As1 = smem + STAGE_BYTES, * const As2 = smem + 2 * STAGE_BYTES;
+    // (A half-step stagger of the two consumer waves of a SIMD -- one in its MFMA phase while the other waits for LDS --
+    //  needs the previous tile's fragments live across the barrier; under the 168-register cap the allocator spilled the
+    //  accumulators, so both consumers of a SIMD run in phase.)
+    while (true) {
+        __builtin_amdgcn_s_barrier(); ws_read_frags<MI, ABL>(As0, fragA, fragB, af, bfr); ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
+        if (++ks >= nloc) break;
+        __builtin_amdgcn_s_barrier(); ws_read_frags<MI, ABL>(As1, fragA, fragB, af, bfr); ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
+        if (++ks >= nloc) break;
+        __builtin_amdgcn_s_barrier(); ws_read_frags<MI, ABL>(As2, fragA, fragB, af, bfr); ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
+        if (++ks >= nloc) break;
+    }
+    conv_epilogue<BM_, NC_, true, true>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1223,12 +1468,29 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 1034>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 2058>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 26>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
 #endif
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+#ifdef ES_CONV_ABLATION
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+#endif
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
@@ -1283,10 +1545,35 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         else if (abl == 25) hipLaunchKernelGGL((k_conv_lean<256, 8, 25>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else if (abl == 26) hipLaunchKernelGGL((k_conv_lean<256, 8, 26>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else if (abl == 32) hipLaunchKernelGGL((k_conv_lean<256, 8, 32>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 128) hipLaunchKernelGGL((k_conv_lean<256, 8, 128>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 256) hipLaunchKernelGGL((k_conv_lean<256, 8, 256>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 512) hipLaunchKernelGGL((k_conv_lean<256, 8, 512>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 640) hipLaunchKernelGGL((k_conv_lean<256, 8, 640>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 1034) hipLaunchKernelGGL((k_conv_lean<256, 8, 1034>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 2058) hipLaunchKernelGGL((k_conv_lean<256, 8, 2058>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 1024) hipLaunchKernelGGL((k_conv_lean<256, 8, 1024>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else if (abl == 2048) hipLaunchKernelGGL((k_conv_lean<256, 8, 2048>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else done = false;
         if (done) { ES_CHECK_HIP(hipGetLastError()); return 0; }
 #endif
-        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<256, 8, 0, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        static const char* ws_env = getenv("ES_CONV_WS");         // A/B switch: 0 = no warp specialisation
+        const bool ws = !(ws_env && atoi(ws_env) == 0);
+#ifdef ES_CONV_ABLATION
+        static const char* wabl_env = getenv("ES_WS_ABL");
+        const int wabl = wabl_env ? atoi(wabl_env) : 0;
+        if (lean && ws && !upm && wabl) {
+            if (wabl == 1) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 1>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else if (wabl == 2) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 2>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else if (wabl == 8) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 8>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else if (wabl == 9) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 9>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 10>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            ES_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+#endif
+        if (lean && ws && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+        else if (lean && ws) hipLaunchKernelGGL((k_conv_ws<256, 8, 4>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+        else if (lean && upm) hipLaunchKernelGGL((k_conv_lean<256, 8, 0, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_mfma<256, 8, 3>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
     } else if (wg128 >= 512 || S > 1) {
