@@ -1128,15 +1128,18 @@ __global__ __launch_bounds__(64 * (NC_ + NP_)) void k_conv_ws(const es_conv_args
 // Self-attention, flash style, fp16 MFMA.  One workgroup = 64 query rows of one (batch, head);
 // 4 waves x 16 rows.  K tile [64 keys][dp], V tile transposed [dp][64 keys] in LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int AT_Q = 64, AT_K = 64;
+constexpr int AT_K = 64;
 
-template <int DP>   // padded head dim: 32, 64, 96 or 256 (VQ-VAE AttnBlock: one head of 256)
-__global__ __launch_bounds__(256) void k_attention(const es_attn_args a) {
+// DP: padded head dim 32, 64, 96 or 256 (VQ-VAE AttnBlock: one head of 256).  NWV waves x 16 query rows per workgroup:
+// 8 waves (128 rows) for long sequences halve the K/V staging traffic per query.
+template <int DP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_attention(const es_attn_args a) {
+    constexpr int AT_Q = 16 * NWV;
     constexpr int KLD = DP + 8;              // halfs; +8 keeps 16-B alignment and skews banks
     constexpr int VLD = AT_K + 8;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[AT_K * KLD];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[DP * VLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Ps[4][16 * VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Ps[NWV][16 * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
@@ -1162,9 +1165,11 @@ __global__ __launch_bounds__(256) void k_attention(const es_attn_args a) {
 
     for (int k0 = 0; k0 < a.Ntok; k0 += AT_K) {
         __syncthreads();
-        // stage K [64][DP] and V^T [DP][64]; 4-half (8 B) granularity (dhead % 4 == 0)
-        for (int idx = tid; idx < AT_K * (DP / 4); idx += 256) {
-            const int key = idx / (DP / 4), d = (idx - key * (DP / 4)) * 4;
+        // stage K [64][DP] and V^T [DP][64]; 4-half (8 B) granularity (dhead % 4 == 0).  Consecutive lanes take
+        // consecutive KEYS of one 4-channel chunk: the transposed V writes are then consecutive halfs (the other
+        // assignment, consecutive channel chunks, put 64 lanes on 4 banks: 16-way conflicts on every ds_write_b16).
+        for (int idx = tid; idx < AT_K * (DP / 4); idx += 64 * NWV) {
+            const int key = idx & (AT_K - 1), d = (idx >> 6) * 4;
             h4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
             if (d < a.dhead && k0 + key < a.Ntok) {
                 const _Float16* p = base + (long)(k0 + key) * ldq + d;
@@ -1623,11 +1628,13 @@ extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
 
 extern "C" int es_attention_f16(const es_attn_args* a, es_stream stream) {
     ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 256 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 256)", a->dhead);
-    dim3 grid((a->Ntok + AT_Q - 1) / AT_Q, a->B * a->heads);
-    if (a->dhead <= 32) hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->dhead <= 64) hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->dhead <= 96) hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL(k_attention<256>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    const bool big = a->Ntok >= 512 && a->dhead <= 96;       // 128 query rows per workgroup
+    dim3 grid((a->Ntok + (big ? 128 : 64) - 1) / (big ? 128 : 64), a->B * a->heads);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dhead <= 32) { if (big) hipLaunchKernelGGL((k_attention<32, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<32, 4>), grid, dim3(256), 0, st, *a); }
+    else if (a->dhead <= 64) { if (big) hipLaunchKernelGGL((k_attention<64, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<64, 4>), grid, dim3(256), 0, st, *a); }
+    else if (a->dhead <= 96) { if (big) hipLaunchKernelGGL((k_attention<96, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<96, 4>), grid, dim3(256), 0, st, *a); }
+    else hipLaunchKernelGGL((k_attention<256, 4>), grid, dim3(256), 0, st, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
