@@ -56,6 +56,40 @@ def build_shape(dev, O, seed, triples, rank=0, world=1):
     return df, den, uc
 
 
+def time_dominant_kernel(ss, dev, reps=3):
+    """roofline.achieved for the dominant kernel: the step's conv launches that the library dispatches to the
+    warp-specialised 256-row-tile kernel k_conv_ws (workgroup count >= 256: the 16^3 and 16x8x8 levels) are replayed as
+    their own plan, timed with HIP events on the stream they are launched on.  Returns (TFLOP/s, avg us, launches)."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder
+    plan = ss['plan']
+    ops, flops = [], 0.0
+    for op in list(plan._arr):
+        if op.kind != hip.OP_CONV:
+            continue
+        c = op.u.conv
+        M = c.O * c.D * c.H * c.W
+        if ((M + 255) // 256) * ((c.N + 223) // 224) < 256 or (c.N <= 4 and c.Cin <= 64) or c.Cin == 32:
+            continue                             # (Cin == 32: the zero-padded 3-channel input conv, not counted)
+        ops.append(op)
+        flops += 2.0 * M * c.N * (c.Cin * c.taps + c.Cin2)
+    if not ops:
+        return None
+    b = Builder(dev)
+    b.ops, b.keep = ops, plan.keep
+    sub = b.finish()
+    sub.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sub.run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    return flops / us / 1e6, us / len(ops), len(ops)
+
+
 def cpu_baseline_shape(df, uc, triples, O_sample):
     """One DDIM step of the CPU oracle on the first O_sample objects (cost is linear in objects)."""
     from oracle import echoscene_oracle as orc
@@ -194,7 +228,9 @@ def main():
                'hbm_GBps_algorithmic': round(st['plan'].weight_bytes / (lay_ms * 1e-3 / a.steps) / 1e9, 1)}
         if full:
             flops = ss['plan'].flops          # this rank's share of the step
-            ach = flops / (shp_ms * 1e-3 / a.steps) / 1e12
+            ach_step = flops / (shp_ms * 1e-3 / a.steps) / 1e12
+            dom = time_dominant_kernel(ss, dev)
+            ach, dom_us, dom_n = dom if dom else (ach_step, None, 0)
             out = {
                 'metric': 'denoising steps/sec (layout+SDF) for 32-node scene-graph, 64^3 SDF (3x16^3 latent), '
                           'full step = one DDPM layout step + one DDIM shape step over all objects',
@@ -212,8 +248,13 @@ def main():
                                      'kernels_per_step': ss['plan'].n_ops,
                                      'algorithmic_TFLOP_per_step': round(flops / 1e12, 3)}},
                 'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'k_conv_mfma',
-                             'note': 'algorithmic FLOPs of one shape step / measured shape-step time (all kernels)'},
+                             'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'k_conv_ws',
+                             'launches_per_step': dom_n, 'avg_launch_us': None if dom_us is None else round(dom_us, 1),
+                             'whole_shape_step_TFLOPs': round(ach_step, 1),
+                             'note': 'achieved = algorithmic FLOPs of the k_conv_ws launches of one shape step / their '
+                                     'duration (HIP events on the launch stream, launches replayed back to back); '
+                                     'whole_shape_step = all FLOPs of the step / shape-step time (all kernels); traffic: '
+                                     'PMC bytes per launch are in profiles/ (separate rocprofv3 --pmc passes)'},
             }
         else:
             ach = lay['hbm_GBps_algorithmic']
