@@ -1531,7 +1531,11 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     if (S < 0) {                                           // auto
         S = 1;
         if (can_split && wg256 < 256 && wg128 < 512) {
-            S = (int)((1536 + wg128 - 1) / wg128);         // ~3 rounds of 512 resident workgroups
+            // ~3 workgroups per CU: enough for the dynamic scheduler to balance the tail, few enough that the epilogue
+            // and the reduction (S slabs of M x N floats) stay small (measured, tools/microbench_small.py: M = 8192
+            // rows best at S = 4, 16384 rows at S = 2-3, 1024-4096 rows at S = 8)
+            S = (int)((768 + wg128 / 2) / wg128);
+            if (S < 1) S = 1;
             if (S > 8) S = 8;
             while (S > 1 && nks / S < 24) --S;
         }
