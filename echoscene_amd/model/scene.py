@@ -162,7 +162,7 @@ class EchoToShape(object):
         return self._dec
 
     @torch.no_grad()
-    def rel2shape(self, data, ddim_eta=0.0, noise=None):
+    def rel2shape(self, data, ddim_eta=0.0, noise=None, sync=True):
         """echo2shape.py:484-525: one latent noise shared by all objects, 100-step DDIM (eta 0, no CFG),
         then VQ-VAE decode_no_quant -> SDF [O,1,64,64,64].  ``noise`` f32[1,C,D,H,W] replaces the
         reference's wall-clock seeded draw (``torch.manual_seed(int(time.time()))``, :502)."""
@@ -178,7 +178,7 @@ class EchoToShape(object):
         # ignores it (the GCN output overwrites the context, openai_model_3d.py:843-844)
         z = den.sample(self.uc_rel, self.triples, noise1=noise,
                        c=self.rel if self.df.conditioning_key == 'concat' else None)
-        self.gen_df = self._decoder().decode_no_quant(z)
+        self.gen_df = self._decoder().decode_no_quant(z, sync=sync)
         return self.gen_df
 
 
@@ -365,14 +365,34 @@ class Sg2ScDiffModel(_SceneModel):
         return self.ShapeDiff.rel2shape({'obj_cat': dec_objs, 'triples': dec_triples, 'c_s': c, 'uc_s': uc},
                                         noise=shape_noise)
 
+    def _layout_and_shapes(self, gen_shape, dec_objs, dec_triples, obj_embed_, latent, layout_noise, shape_noise):
+        """The two loops only share the setup (the reference runs them back to back, EchoScene.py:402-419): the shape
+        branch (100 DDIM steps + VQ-VAE decode, MFMA-bound) is enqueued on a side HIP stream, the layout loop (1000
+        latency-bound steps that keep a few CUs busy) on the caller's stream; joined before returning."""
+        if not gen_shape:
+            return None, self._layout(dec_triples, obj_embed_, latent, layout_noise)
+        uc = self._rel_s(obj_embed_)
+        c = self._rel_s(latent)
+        cur = torch.cuda.current_stream(obj_embed_.device)
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream(device=obj_embed_.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            sdf = self.ShapeDiff.rel2shape({'obj_cat': dec_objs, 'triples': dec_triples, 'c_s': c, 'uc_s': uc},
+                                           noise=shape_noise, sync=False)
+        boxes = self._layout(dec_triples, obj_embed_, latent, layout_noise)
+        cur.wait_stream(side)
+        sdf.record_stream(cur)
+        return sdf, boxes
+
     @torch.no_grad()
     def sample(self, dec_objs, dec_triplets, dec_text_feat, dec_rel_feat, gen_shape=False, layout_noise=None,
                shape_noise=None):
         """EchoScene.py:388-420."""
         oe, _, latent_m = self._setup(dec_objs, dec_triplets, dec_text_feat, dec_rel_feat,
                                       dec_objs, dec_triplets, dec_text_feat, dec_rel_feat)
-        boxes = self._layout(dec_triplets, oe, latent_m, layout_noise)
-        sdf = self._shapes(gen_shape, dec_objs, dec_triplets, oe, latent_m, shape_noise)
+        sdf, boxes = self._layout_and_shapes(gen_shape, dec_objs, dec_triplets, oe, latent_m, layout_noise, shape_noise)
         return {'shapes': sdf}, boxes
 
     def _edited(self, enc, dec, touched, added, gen_shape, layout_noise, shape_noise):
@@ -383,8 +403,7 @@ class Sg2ScDiffModel(_SceneModel):
                 latent[t] = latent_m[t]
         else:
             latent = latent_m
-        boxes = self._layout(dec[1], oe, latent, layout_noise)
-        sdf = self._shapes(gen_shape, dec[0], dec[1], oe, latent, shape_noise)
+        sdf, boxes = self._layout_and_shapes(gen_shape, dec[0], dec[1], oe, latent, layout_noise, shape_noise)
         keep = torch.ones(len(boxes['translations']), 1, device=oe.device)
         for t in touched:
             keep[t] = 0
@@ -415,8 +434,7 @@ class Sg2ScDiffModel(_SceneModel):
                 latent[t] = latent_m[t]
         else:
             latent = latent_m
-        boxes = self._layout(dec_triplets, oe, latent, layout_noise)
-        sdf = self._shapes(gen_shape, dec_objs, dec_triplets, oe, latent, shape_noise)
+        sdf, boxes = self._layout_and_shapes(gen_shape, dec_objs, dec_triplets, oe, latent, layout_noise, shape_noise)
         keep = torch.ones(len(boxes['translations']), 1, device=oe.device)
         for t in added:
             keep[t] = 0

@@ -232,7 +232,8 @@ class VQDecoder:
             self._plans = {key: dict(plan=b.finish(), z=z, sdf=sdf)}
         return self._plans[key]
 
-    def decode_no_quant(self, z):
+    def decode_no_quant(self, z, sync=True):
+        """``sync=False``: everything is only enqueued on the current stream (the caller orders consumers)."""
         z = z.to(self.device).float().contiguous()
         O = z.shape[0]
         zdims = tuple(z.shape[2:])
@@ -244,5 +245,6 @@ class VQDecoder:
             st['z'].copy_(z[i:i + n])
             st['plan'].run()
             out[i:i + n].copy_(st['sdf'])
-        torch.cuda.synchronize()
+        if sync:
+            torch.cuda.synchronize()
         return out
