@@ -71,8 +71,22 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, i
                 const float inv = 1.0f / (float)max(e1 - e0, 1);
                 for (int c4 = cl; c4 < w4; c4 += 16) {
                     f4 v = {0.f, 0.f, 0.f, 0.f};
-                    for (int e = e0; e < e1; ++e)        // stored order == scatter_add order of the reference
-                        v += *(const f4*)(base + (long)sg.ent_row[e] * sg.ld + sg.ent_off[e] + 4 * c4);
+                    // stored order == scatter_add order of the reference.  Entries are fetched 8 at a time (index pairs,
+                    // then rows) and added in order: the scene node has ~2*O incident edges, and one dependent
+                    // index -> row load pair per entry made this op 49 us (12 % of a layout step).
+                    for (int e = e0; e < e1; e += 8) {
+                        long off[8];
+                        f4 x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int ee = min(e + u, e1 - 1);
+                            off[u] = (long)sg.ent_row[ee] * sg.ld + sg.ent_off[ee];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = *(const f4*)(base + off[u] + 4 * c4);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (e + u < e1) v += x[u];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = row_ok ? v[e] / (float)max(e1 - e0, 1) : 0.f;
                     (void)inv;
