@@ -276,13 +276,31 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
         }
         return;
     }
-    if (m < a.M && n < a.N) {
+    const bool ok = m < a.M && n < a.N;
+    if (ok) {
         if (bias) s += bias[n];
         if (a.act == ES_ACT_RELU) s = fmaxf(s, 0.f);
         else if (a.act == ES_ACT_SILU) s = es_silu(s);
         if (a.res) s += a.res[(long)m * a.res_ld + n];
         if (a.res2) s += a.res2[(long)m * a.res2_ld + n];
         out[(long)m * a.out_ld + n] = s;
+    }
+    if (a.out2) {
+        // the 16 lanes of a row hold one GroupNorm32 group of the output (N = 512): two-pass statistics by shuffles
+        float t = ok ? s : 0.f;
+        float sum = t;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float mean = sum * (1.0f / 16.0f);
+        const float d = t - mean;
+        float sq = d * d;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
+        if (ok) {
+            float y = d * rsqrtf(sq * (1.0f / 16.0f) + a.gn2_eps) * a.gn2_gamma[n] + a.gn2_beta[n];
+            if (a.gn2_silu) y = es_silu(y);
+            a.out2[(long)m * a.out2_ld + n] = y;
+        }
     }
 }
 
@@ -399,6 +417,8 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
     ES_REQUIRE(nb == 1 || (a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT && !norm && !a->res && !a->res2),
                "es_linear_rows_f32: batched launch supports one direct segment, no norm prologue, no residuals");
     ES_REQUIRE(a->act != ES_ACT_GEGLU || (a->N % 16 == 0 && !a->res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
+    ES_REQUIRE(!a->out2 || (a->N == 512 && a->act != ES_ACT_GEGLU && nb == 1 && a->gn2_gamma && a->gn2_beta),
+               "es_linear_rows_f32: the GroupNorm32 second output needs N == 512 (N=%d), an affine, no GEGLU, no batching", a->N);
     dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT, nb);
     hipStream_t st = (hipStream_t)stream;
     switch (a->prologue) {

@@ -34,7 +34,9 @@ class LinearArgs(C.Structure):
                 ('wpack', C.c_void_p), ('bias', C.c_void_p), ('prologue', C.c_int32), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('eps', C.c_float), ('act', C.c_int32), ('res', C.c_void_p),
                 ('res_ld', C.c_int32), ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
-                ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32)]
+                ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32),
+                ('out2', C.c_void_p), ('out2_ld', C.c_int32), ('gn2_gamma', C.c_void_p), ('gn2_beta', C.c_void_p),
+                ('gn2_eps', C.c_float), ('gn2_silu', C.c_int32)]
 
 
 class UpdateArgs(C.Structure):

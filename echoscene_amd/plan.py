@@ -171,7 +171,8 @@ class Builder:
         self.ops.append(op)
 
     def linear(self, segs, pl, M, out, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
-               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0):
+               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0, gn_out=None):
+        """gn_out = (View out2, gamma, beta, eps, silu): GroupNorm32(+SiLU) of the output for the next layer (N == 512)."""
         a = LinearArgs()
         for i, s in enumerate(segs):
             a.seg[i] = s
@@ -191,6 +192,11 @@ class Builder:
         a.res2_ld = res2.ld if res2 is not None else 0
         a.out = out.ptr
         a.out_ld = out.ld
+        if gn_out is not None:
+            o2, g2, b2, e2, s2 = gn_out
+            a.out2, a.out2_ld = o2.ptr, o2.ld
+            a.gn2_gamma, a.gn2_beta, a.gn2_eps, a.gn2_silu = g2.data_ptr(), b2.data_ptr(), e2, int(bool(s2))
+            self.keep += [g2, b2]
         op = Op()
         op.kind, op.lane = hip.OP_LINEAR, (lane if self.use_lanes else 0)
         op.u.linear = a
@@ -376,6 +382,11 @@ class UNet1DWeights:
                 d['conv2'] = P(name + '.out_layers.3.weight', name + '.out_layers.3.bias')
                 if (name + '.skip_connection.weight') in sd:
                     d['skip'] = P(name + '.skip_connection.weight', name + '.skip_connection.bias')
+                    # out = conv2(silu(GN2(h1))) + skip(x): with the norm done by conv1's epilogue both are plain
+                    # products -> ONE op over the K-concatenation [h1n | x] with weights [W2 | Wskip]
+                    d['conv2skip'] = PackedLinear(torch.cat([centre_tap(sd[name + '.out_layers.3.weight']),
+                                                             centre_tap(sd[name + '.skip_connection.weight'])], 1),
+                                                  sd[name + '.out_layers.3.bias'] + sd[name + '.skip_connection.bias'], device)
                 emb_w.append(sd[name + '.emb_layers.1.weight'])
                 emb_b.append(sd[name + '.emb_layers.1.bias'])
                 self.emb_slices[name] = (off, it[2])
@@ -399,8 +410,9 @@ class UNet1DWeights:
                 d['ln1'] = (dv(tb + '.norm1.weight'), dv(tb + '.norm1.bias'))
                 d['ln3'] = (dv(tb + '.norm3.weight'), dv(tb + '.norm3.bias'))
                 # one token, one key: softmax == 1, so attention(x) = to_out(to_v(.)) exactly
-                d['v1'] = P(tb + '.attn1.to_v.weight', None)
-                d['o1'] = P(tb + '.attn1.to_out.0.weight', tb + '.attn1.to_out.0.bias')
+                # ... and the two linears fold into one matrix (fp64): to_out . to_v
+                d['vo1'] = PackedLinear((sd[tb + '.attn1.to_out.0.weight'].double() @ sd[tb + '.attn1.to_v.weight'].double()).float(),
+                                        sd[tb + '.attn1.to_out.0.bias'], device)
                 d['o2'] = (sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_out.0.bias'])
                 d['ff1'] = PackedLinear(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
                 d['ff2'] = P(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
@@ -463,6 +475,30 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
         cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
+    # GroupNorm32 of a 512-wide activation is computed by its PRODUCER (16 output columns per workgroup = one group):
+    # ``next_gn[name]`` = (consumer name, gamma, beta, eps, silu) of the norm that reads the output of item ``name``.
+    inp_, mid_, out_ = w.topo
+    order = [(f'input_blocks.{i}.{j}', it, False) for i, blk in enumerate(inp_) for j, it in enumerate(blk)]
+    order += [(f'middle_block.{j}', it, False) for j, it in enumerate(mid_)]
+    order += [(f'output_blocks.{i}.{j}', it, j == 0) for i, blk in enumerate(out_) for j, it in enumerate(blk)]
+    next_gn = {}
+    for (n0, it0, _), (n1, it1, cat1) in zip(order[:-1], order[1:]):
+        d1 = w.items[n1]
+        if it1[0] == 'res' and not cat1 and it1[1] == 512:
+            next_gn[n0] = (n1 + ':gn1', d1['gn1'][0], d1['gn1'][1], 1e-5, True)
+        elif it1[0] == 'attn' and it1[1] == 512:
+            next_gn[n0] = (n1 + ':gn', d1['gn'][0], d1['gn'][1], 1e-5 if w.concat else 1e-6, False)
+    pre = {}                                   # consumer key -> pre-normalised View
+
+    def gn_side(name, C):
+        """(gn_out tuple or None) for the op that produces the block-level output of item ``name``"""
+        g = next_gn.get(name)
+        if g is None or C != 512:
+            return None
+        v = View(b.buf(O, C))
+        pre[g[0]] = v
+        return (v, g[1], g[2], g[3], g[4])
+
     def run_block(name_prefix, blk, h_segs, hC):
         """h_segs: list of Views forming the (possibly concatenated) input; returns (View, C)."""
         for j, it in enumerate(blk):
@@ -471,16 +507,28 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
             kind = it[0]
             if kind == 'conv_in':
                 o = View(b.buf(O, mc))
-                b.linear([seg(v) for v in h_segs], d['conv'], O, o)
+                b.linear([seg(v) for v in h_segs], d['conv'], O, o, gn_out=gn_side(name, mc))
                 h_segs, hC = [o], mc
             elif kind == 'res':
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
                 h1 = View(b.buf(O, cout))
-                b.linear([seg(v) for v in h_segs], d['conv1'], O, h1, prologue=hip.PRO_GN_SILU,
-                         gamma=d['gn1'][0], beta=d['gn1'][1], eps=1e-5,
-                         res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout))
+                h1n = View(b.buf(O, cout)) if cout == 512 else None      # silu(GN2(h1)) from conv1's epilogue
+                gn2 = (h1n, d['gn2'][0], d['gn2'][1], 1e-5, True) if h1n is not None else None
+                if (name + ':gn1') in pre:
+                    b.linear([seg(pre[name + ':gn1'])], d['conv1'], O, h1,
+                             res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), gn_out=gn2)
+                else:
+                    b.linear([seg(v) for v in h_segs], d['conv1'], O, h1, prologue=hip.PRO_GN_SILU,
+                             gamma=d['gn1'][0], beta=d['gn1'][1], eps=1e-5,
+                             res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), gn_out=gn2)
+                if 'skip' in d and h1n is not None and len(h_segs) <= 2:
+                    o = View(b.buf(O, cout))
+                    b.linear([seg(h1n)] + [seg(v) for v in h_segs], d['conv2skip'], O, o, gn_out=gn_side(name, cout))
+                    h_segs, hC = [o], cout
+                    b.tags[name] = h_segs[0]
+                    continue
                 if 'skip' in d:
                     sk = View(b.buf(O, cout))
                     b.linear([seg(v) for v in h_segs], d['skip'], O, sk)
@@ -489,28 +537,37 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
                     assert len(h_segs) == 1
                     resv = h_segs[0]
                 o = View(b.buf(O, cout))
-                b.linear([seg(h1)], d['conv2'], O, o, prologue=hip.PRO_GN_SILU, gamma=d['gn2'][0],
-                         beta=d['gn2'][1], eps=1e-5, res=resv)
+                if h1n is not None:
+                    b.linear([seg(h1n)], d['conv2'], O, o, res=resv, gn_out=gn_side(name, cout))
+                else:
+                    b.linear([seg(h1)], d['conv2'], O, o, prologue=hip.PRO_GN_SILU, gamma=d['gn2'][0],
+                             beta=d['gn2'][1], eps=1e-5, res=resv)
                 h_segs, hC = [o], cout
             elif kind == 'attn' and w.concat:
                 C = it[1]
                 xin = h_segs[0]
                 o = View(b.buf(O, C))
-                b.linear([seg(xin)], d['av'], O, o, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1], eps=1e-5,
-                         res=xin)
+                if (name + ':gn') in pre:
+                    b.linear([seg(pre[name + ':gn'])], d['av'], O, o, res=xin, gn_out=gn_side(name, C))
+                else:
+                    b.linear([seg(xin)], d['av'], O, o, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1], eps=1e-5,
+                             res=xin)
                 h_segs, hC = [o], C
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
                 t0 = View(b.buf(O, C))
-                b.linear([seg(xin)], d['proj_in'], O, t0, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1],
-                         eps=1e-6)
-                v1 = View(b.buf(O, C))
-                b.linear([seg(t0)], d['v1'], O, v1, prologue=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5)
-                # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one key the second line adds the
-                # per-node vector to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
+                if (name + ':gn') in pre:
+                    b.linear([seg(pre[name + ':gn'])], d['proj_in'], O, t0)
+                else:
+                    b.linear([seg(xin)], d['proj_in'], O, t0, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1],
+                             eps=1e-6)
+                # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
+                # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
+                # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
                 t2 = View(b.buf(O, C))
-                b.linear([seg(v1)], d['o1'], O, t2, res=t0, res2=cavo[name])
+                b.linear([seg(t0)], d['vo1'], O, t2, prologue=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5,
+                         res=t0, res2=cavo[name])
                 b.tags[name + '.transformer_blocks.0:in'] = t0
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
                 gl = View(b.buf(O, 4 * C))                    # GEGLU applied in the ff1 epilogue
@@ -519,11 +576,11 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
                 b.linear([seg(gl)], d['ff2'], O, t3, res=t2)
                 b.tags[name + '.transformer_blocks.0:ff'] = t3
                 o = View(b.buf(O, C))
-                b.linear([seg(t3)], d['proj_out'], O, o, res=xin)
+                b.linear([seg(t3)], d['proj_out'], O, o, res=xin, gn_out=gn_side(name, C))
                 h_segs, hC = [o], C
             elif kind in ('down', 'up'):
                 o = View(b.buf(O, hC))
-                b.linear([seg(v) for v in h_segs], d['conv'], O, o)
+                b.linear([seg(v) for v in h_segs], d['conv'], O, o, gn_out=gn_side(name, hC))
                 h_segs = [o]
             b.tags[name] = h_segs[0]
         return h_segs, hC

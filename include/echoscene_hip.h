@@ -84,6 +84,15 @@ typedef struct es_linear_args {
     /* batched launch (grid.z = nbatch): batch z uses seg[0].ptr + z*a_bstride, the z-th packed weight image
      * (images of equal shape stored back to back), bias + z*N, out + z*out_bstride.  0/1 = single problem. */
     int32_t nbatch, a_bstride, out_bstride;
+    /* optional second output: GroupNorm32 (+SiLU) of the OUTPUT row for the NEXT layer, written as out2[M, N].  A
+     * workgroup owns 16 output columns of every row, which for N = 512 is exactly one of the 32 groups, so the
+     * consumer's norm prologue (every workgroup re-normalising the whole tile) moves into the producer's epilogue.
+     * Requires N == 512 (group size 16); gn2_gamma/gn2_beta [N] are the CONSUMER's affine.  NULL = off. */
+    float* out2;
+    int32_t out2_ld;
+    const float* gn2_gamma; const float* gn2_beta;
+    float gn2_eps;
+    int32_t gn2_silu;
 } es_linear_args;
 
 /* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
