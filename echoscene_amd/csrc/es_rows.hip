@@ -332,6 +332,13 @@ __global__ void k_ddim_update(const es_update_args a) {
 
 __global__ void k_step_inc(int32_t* step) { *step += 1; }
 
+__global__ void k_row_select(const es_rowsel_args a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float v = a.table[(long)(*a.step) * a.stride + i];
+    for (int r = blockIdx.y; r < a.rows; r += gridDim.y) a.out[(long)r * a.out_ld + i] = v;
+}
+
 // Box de-normalisation after the layout loop (helpers/util.py:542-568): [-1,1] -> [min,max] for sizes and
 // translations (in place, stats = {min_lhw[3], max_lhw[3], min_xyz[3], max_xyz[3], min_angle, max_angle}) and
 // (sin, cos) -> arctan2 in degrees-or-radians (scale).
@@ -430,6 +437,13 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
         case ES_PRO_GEGLU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GEGLU>, grid, dim3(NTHREAD), 0, st, *a); break;
         default: ES_REQUIRE(false, "es_linear_rows_f32: unknown prologue %d", a->prologue);
     }
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_row_select(const es_rowsel_args* a, es_stream stream) {
+    ES_REQUIRE(a->table && a->step && a->out && a->n > 0 && a->rows > 0, "es_row_select: bad args");
+    hipLaunchKernelGGL(k_row_select, dim3((a->n + 255) / 256, a->rows < 64 ? a->rows : 64), dim3(256), 0, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -65,6 +65,7 @@ static int dispatch(const es_op& op, hipStream_t s) {
             return es_latent_to_cl_f16(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s);
         case ES_OP_STEM: return es_shape_stem(&op.u.stem, s);
         case ES_OP_VQ: return es_vq_lookup(&op.u.vq, s);
+        case ES_OP_ROWSEL: return es_row_select(&op.u.rowsel, s);
         default: es_set_error("plan: unknown op kind %d", op.kind); return 3;
     }
 }

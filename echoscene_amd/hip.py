@@ -20,7 +20,7 @@ CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW, CONV_DOWN_DHW = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
 OP_VQ = 12
-OP_FORK, OP_JOIN = 13, 14
+OP_FORK, OP_JOIN, OP_ROWSEL = 13, 14, 15
 
 
 class Seg(C.Structure):
@@ -74,6 +74,11 @@ class GegluArgs(C.Structure):
     _fields_ = [('h_f32', C.c_void_p), ('M', C.c_int32), ('C4', C.c_int32), ('out_f16', C.c_void_p)]
 
 
+class RowSelArgs(C.Structure):
+    _fields_ = [('table', C.c_void_p), ('stride', C.c_int32), ('step', C.c_void_p), ('out', C.c_void_p),
+                ('out_ld', C.c_int32), ('rows', C.c_int32), ('n', C.c_int32)]
+
+
 class CopyArgs(C.Structure):
     _fields_ = [('dst', C.c_void_p), ('src', C.c_void_p), ('bytes', C.c_size_t), ('rows', C.c_int32),
                 ('dst_pitch', C.c_size_t), ('src_pitch', C.c_size_t)]
@@ -97,7 +102,7 @@ class VQArgs(C.Structure):
 class _OpU(C.Union):
     _fields_ = [('linear', LinearArgs), ('update', UpdateArgs), ('copy', CopyArgs), ('conv', ConvArgs),
                 ('gn', GNArgs), ('ln', LNArgs), ('attn', AttnArgs), ('geglu', GegluArgs), ('tocl', ToClArgs),
-                ('stem', StemArgs), ('vq', VQArgs)]
+                ('stem', StemArgs), ('vq', VQArgs), ('rowsel', RowSelArgs)]
 
 
 class Op(C.Structure):
@@ -112,6 +117,7 @@ EXPORTS = {
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),
     'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_box_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,

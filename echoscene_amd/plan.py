@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import hip
-from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, Op
+from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, RowSelArgs, Op
 
 
 class View:
@@ -220,6 +220,17 @@ class Builder:
         op.u.update = a
         self.ops.append(op)
 
+    def rowsel(self, table, step, out, rows=1):
+        """out[r, :n] = table[*step, :n] for r < rows (out: View; table: 2-D tensor [n_steps, n])"""
+        a = RowSelArgs()
+        a.table, a.stride, a.step = table.data_ptr(), table.shape[1], step.data_ptr()
+        a.out, a.out_ld, a.rows, a.n = out.ptr, out.ld, rows, table.shape[1]
+        op = Op()
+        op.kind, op.lane = hip.OP_ROWSEL, 0
+        op.u.rowsel = a
+        self.ops.append(op)
+        self.keep.append(table)
+
     def copy(self, dst, src, nbytes, rows=0, dst_pitch=0, src_pitch=0):
         """flat copy of nbytes, or (rows > 1) a 2-D copy of rows x nbytes with byte pitches"""
         a = CopyArgs()
@@ -344,6 +355,27 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
 # UNet1DModel -- the layout denoiser as a chain of fused row-linears
 # (reference denoise_net.py:773-806; block semantics :293-313, attention.py:172-245, 385-396)
 # ------------------------------------------------------------------------------------------------
+def time_tables(w, temb, t_lin, device):
+    """Timestep-dependent, node-independent products tabulated for every step of the schedule, on the HIP path:
+    emb = time_embed(temb[i]) [n, 4mc]; emb_all = all ResBlock emb_layers(silu(emb)) [n, sum cout];
+    t_lin(emb) [n, 64] (box_time_emb / shape_time_emb) or None."""
+    n, mc = temb.shape
+    b = Builder(device)
+    e1 = View(b.buf(n, 4 * mc))
+    b.linear([seg(View(temb))], w.te0, n, e1, act=hip.ACT_SILU)
+    emb = View(b.buf(n, 4 * mc))
+    b.linear([seg(e1)], w.te2, n, emb)
+    emb_all = b.buf(n, w.emb_all.N)
+    b.linear([seg(emb)], w.emb_all, n, View(emb_all), prologue=hip.PRO_SILU)
+    tl = None
+    if t_lin is not None:
+        tl = b.buf(n, t_lin.N)
+        b.linear([seg(emb)], t_lin, n, View(tl))
+    b.finish().run()
+    torch.cuda.synchronize()
+    return dict(emb=emb.t, emb_all=emb_all, t_lin=tl)
+
+
 class UNet1DWeights:
     def __init__(self, sd, net, device):
         """sd: state_dict of the UNet1DModel holder ``net`` (keys without prefix)."""
@@ -437,20 +469,30 @@ class UNet1DWeights:
         self.out_conv = P('out.2.weight', 'out.2.bias')
 
 
-def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
-    """One UNet1DModel.forward on x [O, in_ch] -> eps_out [O, out_ch]."""
+def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None):
+    """One UNet1DModel.forward on x [O, in_ch] -> eps_out [O, out_ch].
+    ``tables`` (time_tables): the time MLP / emb projections are read from per-schedule tables by the step counter
+    instead of being recomputed every step (all nodes share t)."""
     O, mc = g.O, w.mc
     E = 4 * mc
     gdim = 64
-    # timestep MLP (all nodes share t: the table row is broadcast with ld = 0)
-    e1 = View(b.buf(O, E))
-    b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
-    emb = View(b.buf(O, E))
-    b.linear([seg(e1)], w.te2, O, emb)
-    # side lane 1: all 22 ResBlock time projections (92 MB of weights) overlap the GCN chain
-    emb_all = b.buf(O, w.emb_all.N)
-    b.fork(1)
-    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU, lane=1)
+    emb_ld = w.emb_all.N
+    if tables is not None:
+        emb = None
+        emb_all = b.buf(1, w.emb_all.N)
+        b.rowsel(tables['emb_all'], step, View(emb_all))
+        emb_ld = 0                               # one row, broadcast over the nodes
+        b.fork(1)
+    else:
+        # timestep MLP (all nodes share t: the table row is broadcast with ld = 0)
+        e1 = View(b.buf(O, E))
+        b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
+        emb = View(b.buf(O, E))
+        b.linear([seg(e1)], w.te2, O, emb)
+        # side lane 1: all 22 ResBlock time projections (92 MB of weights) overlap the GCN chain
+        emb_all = b.buf(O, w.emb_all.N)
+        b.fork(1)
+        b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU, lane=1)
     # GCN input  [obj_embed | box_embeddings(x_t) | box_time_emb(emb)]   (denoise_net.py:758-771)
     Dobj = obj_embed_dev.shape[1] + gdim + (gdim if w.enable_t_emb else 0)
     objbuf = b.buf(O, Dobj)
@@ -458,10 +500,15 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
     objbuf[:, :oe_w].copy_(obj_embed_dev)        # constant over the loop: written once at plan build
     b.linear([seg(View(x))], w.box_emb, O, View(objbuf, col=oe_w, ld=Dobj, width=gdim))
     if w.enable_t_emb:
-        b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
+        if tables is not None:
+            b.rowsel(tables['t_lin'], step, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim), rows=O)
+        else:
+            b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
     pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
-    b.tags.update(emb=emb, ctx=ctx, gcn_in=View(objbuf))
+    b.tags.update(ctx=ctx, gcn_in=View(objbuf))
+    if emb is not None:
+        b.tags['emb'] = emb
     cavo = {}
     if not w.concat:
         # batched per-step side products
@@ -518,11 +565,11 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out):
                 gn2 = (h1n, d['gn2'][0], d['gn2'][1], 1e-5, True) if h1n is not None else None
                 if (name + ':gn1') in pre:
                     b.linear([seg(pre[name + ':gn1'])], d['conv1'], O, h1,
-                             res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), gn_out=gn2)
+                             res=View(emb_all, col=eo, ld=emb_ld, width=cout), gn_out=gn2)
                 else:
                     b.linear([seg(v) for v in h_segs], d['conv1'], O, h1, prologue=hip.PRO_GN_SILU,
                              gamma=d['gn1'][0], beta=d['gn1'][1], eps=1e-5,
-                             res=View(emb_all, col=eo, ld=w.emb_all.N, width=cout), gn_out=gn2)
+                             res=View(emb_all, col=eo, ld=emb_ld, width=cout), gn_out=gn2)
                 if 'skip' in d and h1n is not None and len(h_segs) <= 2:
                     o = View(b.buf(O, cout))
                     b.linear([seg(h1n)] + [seg(v) for v in h_segs], d['conv2skip'], O, o, gn_out=gn_side(name, cout))

@@ -228,7 +228,7 @@ class VolBuilderMixin:
         return self._push(hip.OP_STEM, 'stem', a)
 
 
-def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None, c_dev=None):
+def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None, c_dev=None, tables=None):
     """One UNet3DModel.forward: x f32 [Ol,3,D,H,W] (NCDHW) -> eps_out f32 [Ol,3,D,H,W].
 
     'concat' family (``w.concat``; c_dev f32 [Ol, V] = this rank's rows of c_s): the network input is the 5-channel
@@ -248,10 +248,12 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     V0 = D0 * H0 * W0
     f16 = torch.float16
     # ---- per-object (rows path) ----
-    e1 = View(b.buf(O, E))
-    b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
-    emb = View(b.buf(O, E))
-    b.linear([seg(e1)], w.te2, O, emb)
+    emb = None
+    if tables is None:
+        e1 = View(b.buf(O, E))
+        b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
+        emb = View(b.buf(O, E))
+        b.linear([seg(e1)], w.te2, O, emb)
     ucw = uc_dev.shape[1]
     Dobj = ucw + gdim + (gdim if w.enable_t_emb else 0)
     objbuf = b.buf(O, Dobj)
@@ -276,12 +278,22 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     b.split = len(b.ops)                       # <- all-gather point of the multi-GPU loop
     b.code_cols = (ucw, gdim)
     if w.enable_t_emb:
-        b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
+        if tables is not None:
+            b.rowsel(tables['t_lin'], step, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim), rows=O)
+        else:
+            b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
     pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
-    b.tags.update(emb=emb, ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
-    emb_all = b.buf(O, w.emb_all.N)
-    b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
+    b.tags.update(ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
+    emb_ld = w.emb_all.N
+    if tables is not None:                     # all objects share t: one table row, broadcast (rowvec_ld = 0)
+        emb_all = b.buf(1, w.emb_all.N)
+        b.rowsel(tables['emb_all'], step, View(emb_all))
+        emb_ld = 0
+    else:
+        b.tags['emb'] = emb
+        emb_all = b.buf(O, w.emb_all.N)
+        b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
     cavo, coff = {}, 0
     if w.concat:
         # GCN output rows of the local objects -> fifth input channel
@@ -334,7 +346,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 raw = b.buf(M, cin, dtype=f16) if 'skip' in d else None
                 b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
                 h1 = b.buf(M, cout)
-                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=w.emb_all.N, width=cout, row=lo), out_f32=h1)
+                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=lo if emb_ld else 0), out_f32=h1)
                 y2 = b.buf(M, cout, dtype=f16)
                 b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
                 o = b.buf(M, cout)

@@ -4,7 +4,7 @@ the native sampling loop.  They mirror ``EchoToLayout`` / ``EchoToShape`` of the
 import torch
 
 from . import hip
-from .plan import (Builder, GraphIndex, View, GCNWeights, UNet1DWeights, emit_gcn, emit_unet1d_step)
+from .plan import (Builder, GraphIndex, View, GCNWeights, UNet1DWeights, emit_gcn, emit_unet1d_step, time_tables)
 from .plan_vol import UNet3DWeights, emit_unet3d_step, VQWeights, emit_vq_decode
 from .schedules import LayoutSchedule, ShapeSchedule, timestep_embedding_table
 
@@ -45,6 +45,8 @@ class LayoutDenoiser:
         self.T = self.sched.time_num
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
+        # time MLP / emb projections / box_time_emb for every step of the schedule (node-independent)
+        self.tables = time_tables(self.w, self.temb, self.w.box_t, self.device)
         self._plans = {}
 
     def _plan_for(self, obj_embed, triples):
@@ -60,7 +62,7 @@ class LayoutDenoiser:
             step = b.buf(1, dtype=torch.int32, zero=True)
             noise = b.buf(self.T + 1, O, D)
             oe = b.dev(obj_embed)
-            objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, eps)
+            objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, eps, tables=self.tables)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDPM, x, eps, self.coef, step, noise=View(noise[1:].reshape(self.T, O * D), ld=O * D),
                      noise_stride=O * D, inc_step=True)
@@ -126,6 +128,7 @@ class ShapeDenoiser:
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
         self.rank, self.world, self.group = rank, world, group
+        self.tables = time_tables(self.w, self.temb, self.w.shape_t, self.device)
         self._plans = {}
 
     def _plan_for(self, uc, triples, c=None):
@@ -148,7 +151,7 @@ class ShapeDenoiser:
             step = b.buf(1, dtype=torch.int32, zero=True)
             ucd = b.dev(uc)
             objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi,
-                                      c_dev=c[lo:hi] if concat else None)
+                                      c_dev=c[lo:hi] if concat else None, tables=self.tables)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
             st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,

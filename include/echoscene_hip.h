@@ -253,8 +253,18 @@ int es_shape_stem(const es_stem_args* args, es_stream stream);
 enum {
     ES_OP_LINEAR = 1, ES_OP_DDPM = 2, ES_OP_DDIM = 3, ES_OP_COPY = 4, ES_OP_CONV = 5, ES_OP_GN = 6,
     ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_VQ = 12,
-    ES_OP_FORK = 13, ES_OP_JOIN = 14
+    ES_OP_FORK = 13, ES_OP_JOIN = 14, ES_OP_ROWSEL = 15
 };
+/* Row select: out[r, 0..n) = table[*step, 0..n) for r < rows.  The timestep-dependent but node-independent products of a
+ * denoiser (time MLP, all ResBlock emb projections, box/shape time embedding) are tabulated once per schedule
+ * [n_steps, n] and picked by the device-side step counter -- 4 launches and 92 MB of weights less per layout step. */
+typedef struct es_rowsel_args {
+    const float* table; int32_t stride;      /* floats between table rows */
+    const int32_t* step;
+    float* out; int32_t out_ld, rows, n;
+} es_rowsel_args;
+int es_row_select(const es_rowsel_args* args, es_stream stream);
+
 typedef struct es_copy_args {      /* device-to-device copy: flat (rows <= 1) or 2-D (rows x bytes with pitches) */
     void* dst; const void* src; size_t bytes;
     int32_t rows; size_t dst_pitch, src_pitch;
@@ -266,7 +276,7 @@ typedef struct es_op {
     union {
         es_linear_args linear; es_update_args update; es_copy_args copy; es_conv_args conv;
         es_gn_args gn; es_ln_args ln; es_attn_args attn; es_geglu_args geglu; es_tocl_args tocl;
-        es_stem_args stem; es_vq_args vq;
+        es_stem_args stem; es_vq_args vq; es_rowsel_args rowsel;
     } u;
 } es_op;
 

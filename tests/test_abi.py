@@ -40,6 +40,7 @@ def test_struct_sizes_match_header(L, tmp_path):
              'es_conv_args': hip.ConvArgs, 'es_gn_args': hip.GNArgs, 'es_ln_args': hip.LNArgs,
              'es_attn_args': hip.AttnArgs, 'es_geglu_args': hip.GegluArgs, 'es_copy_args': hip.CopyArgs,
              'es_tocl_args': hip.ToClArgs, 'es_stem_args': hip.StemArgs, 'es_vq_args': hip.VQArgs,
+             'es_rowsel_args': hip.RowSelArgs,
              'es_op': hip.Op}
     src = '#include <stdio.h>\n#include "echoscene_hip.h"\nint main(){' + ''.join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + 'return 0;}'
