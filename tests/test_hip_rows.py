@@ -297,3 +297,40 @@ def test_unet1d_concat_vs_reference_golden(dev, tag, mc, cd):
         den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(100), dev)
         x = den.sample(g['loop_obj_embed'], g['loop_triples'], synth.layout_noise(8, 8, 100, seed=9), n_steps=10)
         _close(x, g['loop_x10'], 2e-4)
+
+
+def test_linear_groupnorm_second_output_and_rowsel(dev):
+    """The producer-side GroupNorm32(+SiLU) output (N = 512: one group per 16-column workgroup) against torch, fed
+    through three K segments; and the device-step-indexed row select used for the per-schedule time tables."""
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg
+    rs = np.random.RandomState(5)
+    M, K, N = 27, 3 * 512, 512
+    X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32))
+    W = torch.from_numpy((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32))
+    R = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32))
+    ga = torch.from_numpy((1 + 0.1 * rs.standard_normal(N)).astype(np.float32))
+    be = torch.from_numpy((0.1 * rs.standard_normal(N)).astype(np.float32))
+    ref = F.linear(X, W, bias) + R
+    for silu in (False, True):
+        b = Builder(dev)
+        x = b.dev(X)
+        out, out2 = b.buf(M, N, zero=True), b.buf(M, N, zero=True)
+        b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
+                 PackedLinear(W, bias, dev), M, View(out), res=View(b.dev(R)),
+                 gn_out=(View(out2), b.dev(ga), b.dev(be), 1e-5, silu))
+        b.finish().run()
+        torch.cuda.synchronize()
+        _close(out.cpu(), ref, 2e-5)
+        y = F.group_norm(ref, 32, ga, be, 1e-5)
+        _close(out2.cpu(), F.silu(y) if silu else y, 5e-5)
+    # row select: out[r, :] = table[step, :]
+    b = Builder(dev)
+    table = b.dev(torch.from_numpy(rs.standard_normal((7, 300)).astype(np.float32)))
+    step = b.buf(1, dtype=torch.int32, zero=True)
+    step.fill_(4)
+    out = b.buf(5, 320, zero=True)
+    b.rowsel(table, step, View(out, col=8, ld=320, width=300), rows=5)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 8:308].cpu(), table[4].cpu().expand(5, 300)) and float(out[:, :8].abs().sum()) == 0.0
