@@ -966,7 +966,7 @@ __device__ __forceinline__ void ws_mma_rows(f4 (&acc)[MI][7], const h8 (&af)[MI]
 }
 
 template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0>
-__global__ __launch_bounds__(64 * (NC_ + NP_)) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
+__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
     constexpr int NS = 3;
     constexpr int WROWS = BM_ / (NC_ / 2);
     constexpr int MI = WROWS / 16;
@@ -1514,6 +1514,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
 #ifdef ES_CONV_ABLATION
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
@@ -1612,7 +1614,11 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         else hipLaunchKernelGGL((k_conv_mfma<256, 8, 3>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
-        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<128, 4, 0, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
+        static const char* ws128_env = getenv("ES_CONV_WS128");   // A/B switch: 1 = producer/consumer waves for 128-row tiles too
+        const bool ws128 = ws128_env && atoi(ws128_env) == 1;
+        if (lean && ws128 && upm) hipLaunchKernelGGL((k_conv_ws<128, 4, 2, true>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
+        else if (lean && ws128) hipLaunchKernelGGL((k_conv_ws<128, 4, 2>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
+        else if (lean && upm) hipLaunchKernelGGL((k_conv_lean<128, 4, 0, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
         else if (lean) hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_mfma<128, 4, 3>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
     } else {

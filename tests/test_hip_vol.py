@@ -331,3 +331,23 @@ def test_conv_down_dhw(dev):
     b.finish().run()
     torch.cuda.synchronize()
     assert _rel(out, _cl(ref)) < 1e-4
+
+
+@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'}])
+def test_conv_alternate_kernels(env):
+    """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
+    non-specialised k_conv_lean for 256-row tiles, the opt-in producer/consumer 128-row variant) must give the same
+    results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
+    (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae'
+    if 'ES_CONV_OLD' not in env:                 # the general kernel has no stride-2-in-depth mode (raises, by design)
+        sel += ' or test_conv_down_dhw'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
+                       env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
