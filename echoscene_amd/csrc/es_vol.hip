@@ -965,9 +965,37 @@ __device__ __forceinline__ void ws_mma_rows(f4 (&acc)[MI][7], const h8 (&af)[MI]
     }
 }
 
-template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0>
+// One consumer K step of the PIPE_ schedule: MFMAs of tile ks out of (af, bfr); every fragment register is refilled from
+// tile ks+1 (``nxt``: LDS base of its slot, ``more``: it exists) right after its last use.
+template <int MI, int ABL>
+__device__ __forceinline__ void ws_pipe_step(f4 (&acc)[MI][7], h8 (&af)[MI], h8 (&bfr)[7], const char* nxt, int fragA, int fragB, bool more) {
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfr[j], acc[0][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) af[0] = *(const h8*)(nxt + fragA);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+#pragma unroll
+        for (int i = 1; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) bfr[j] = *(const h8*)(nxt + fragB + j * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+#pragma unroll
+        for (int i = 1; i < MI; ++i) af[i] = *(const h8*)(nxt + fragA + i * 1024);
+    }
+}
+
+template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0, bool PIPE_ = false>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
-    constexpr int NS = 3;
+    // PIPE_: barrier ks means 'tile ks+1 has landed'; the consumers then refill each fragment register from tile ks+1 as
+    // soon as its last MFMA of tile ks is issued (row 0 first, then column by column), so no wave waits for LDS after a
+    // barrier.  Tile ks is completely in registers during step ks -> its slot is free one step earlier -> 4-slot ring,
+    // three tiles in flight.
+    constexpr int NS = PIPE_ ? 4 : 3;
     constexpr int WROWS = BM_ / (NC_ / 2);
     constexpr int MI = WROWS / 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -1110,12 +1138,35 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
                 }
             }
         };
-        stage_tile(0);
-        if (nloc > 1) stage_tile(1);
-        for (int ks = 0; ks < nloc; ++ks) {
-            if (ks + 1 < nloc) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of tile ks have landed
-            __builtin_amdgcn_s_barrier();        // tile ks visible to the consumers; slot (ks+2)%3 released by them
-            if (ks + 2 < nloc && !(ABL & 1)) stage_tile((ks + 2) % NS);
+        if constexpr (PIPE_) {
+            stage_tile(0);
+            if (nloc > 1) stage_tile(1);
+            if (nloc > 2) stage_tile(2);
+            if (nloc > 2) wait_vmcnt<2 * NLOAD>(); else if (nloc > 1) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();        // tile 0 visible
+            for (int ks = 0; ks < nloc; ++ks) {
+                if (ks + 2 < nloc) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();   // own pieces of tile ks+1 have landed
+                __builtin_amdgcn_s_barrier();    // tile ks+1 visible; tile ks-1's slot was released a step ago
+                if (ks + 3 < nloc && !(ABL & 1)) stage_tile((ks + 3) % NS);
+            }
+        } else {
+            stage_tile(0);
+            if (nloc > 1) stage_tile(1);
+            unsigned long long tw = 0, tb = 0, ti = 0;
+            for (int ks = 0; ks < nloc; ++ks) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                if constexpr ((ABL & 16) != 0) t0 = __builtin_readcyclecounter();
+                if (ks + 1 < nloc) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of tile ks have landed
+                if constexpr ((ABL & 16) != 0) t1 = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_barrier();        // tile ks visible to the consumers; slot (ks+2)%3 released by them
+                if constexpr ((ABL & 16) != 0) t2 = __builtin_readcyclecounter();
+                if (ks + 2 < nloc && !(ABL & 1)) stage_tile((ks + 2) % NS);
+                if constexpr ((ABL & 16) != 0) { t3 = __builtin_readcyclecounter(); tw += t1 - t0; tb += t2 - t1; ti += t3 - t2; }
+            }
+            if constexpr ((ABL & 16) != 0) {
+                if (lane == 0 && bx == 0 && by == 0 && bz == 0)
+                    printf("producer %d: per step vmcnt-wait %.0f  barrier %.0f  issue %.0f\n", pw, (double)tw / nloc, (double)tb / nloc, (double)ti / nloc);
+            }
         }
         f4 dummy[MI][7];
         conv_epilogue<BM_, NC_, false, true>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
@@ -1135,9 +1186,40 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     int ks = 0;
     h8 af[MI], bfr[7];
     const char* const As0 = smem, * const As1 = smem + STAGE_BYTES, * const As2 = smem + 2 * STAGE_BYTES;
+    if constexpr (PIPE_) {
+        const char* const As3 = smem + 3 * STAGE_BYTES;
+        __builtin_amdgcn_s_barrier();            // tile 0 visible
+        ws_read_frags<MI, ABL>(As0, fragA, fragB, af, bfr);
+        while (true) {
+            ws_pipe_step<MI, ABL>(acc, af, bfr, As1, fragA, fragB, ks + 1 < nloc); if (++ks >= nloc) break;
+            ws_pipe_step<MI, ABL>(acc, af, bfr, As2, fragA, fragB, ks + 1 < nloc); if (++ks >= nloc) break;
+            ws_pipe_step<MI, ABL>(acc, af, bfr, As3, fragA, fragB, ks + 1 < nloc); if (++ks >= nloc) break;
+            ws_pipe_step<MI, ABL>(acc, af, bfr, As0, fragA, fragB, ks + 1 < nloc); if (++ks >= nloc) break;
+        }
+    } else {
     // (A half-step stagger of the two consumer waves of a SIMD -- one in its MFMA phase while the other waits for LDS --
     //  needs the previous tile's fragments live across the barrier; under the 168-register cap the allocator spilled the
     //  accumulators, so both consumers of a SIMD run in phase.)
+    if constexpr ((ABL & 16) != 0) {
+        unsigned long long tb = 0, tc = 0;
+        for (; ks < nloc; ++ks) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            ws_read_frags<MI, ABL>(smem + (ks % 3) * STAGE_BYTES, fragA, fragB, af, bfr);
+            ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
+            asm volatile("s_nop 0" ::: "memory");
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            tb += t1 - t0; tc += t2 - t1;
+        }
+        const unsigned long long te0 = __builtin_readcyclecounter();
+        conv_epilogue<BM_, NC_, true, true>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        const unsigned long long te1 = __builtin_readcyclecounter();
+        if (lane == 0 && bx == 0 && by == 0 && bz == 0)
+            printf("consumer %d: per step barrier %.0f  reads+MFMA issue %.0f ; K loop total %.0f  epilogue %.0f ticks\n", wave,
+                   (double)tb / nloc, (double)tc / nloc, (double)(tb + tc), (double)(te1 - te0));
+        return;
+    } else {
     while (true) {
         __builtin_amdgcn_s_barrier(); ws_read_frags<MI, ABL>(As0, fragA, fragB, af, bfr); ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
         if (++ks >= nloc) break;
@@ -1145,6 +1227,8 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         if (++ks >= nloc) break;
         __builtin_amdgcn_s_barrier(); ws_read_frags<MI, ABL>(As2, fragA, fragB, af, bfr); ws_mma_rows<MI, 0, MI, ABL>(acc, af, bfr);
         if (++ks >= nloc) break;
+    }
+    }
     }
     conv_epilogue<BM_, NC_, true, true>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
@@ -1514,6 +1598,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
 #ifdef ES_CONV_ABLATION
@@ -1521,6 +1607,7 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
 #endif
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
@@ -1602,12 +1689,18 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             else if (wabl == 2) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 2>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (wabl == 8) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 8>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (wabl == 9) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 9>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else if (wabl == 16) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 16>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 10>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             ES_CHECK_HIP(hipGetLastError());
             return 0;
         }
 #endif
-        if (lean && ws && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+        static const char* pipe_env = getenv("ES_CONV_PIPE");     // A/B switch: 1 = refill-after-last-use consumer schedule
+        const bool pipe = pipe_env && atoi(pipe_env) == 1;        // (measured equal: the kernel is clock/power limited)
+        constexpr int LDSP = 4 * (256 * BK * 2 + BNP * BK * 2);
+        if (lean && ws && pipe && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
+        else if (lean && ws && pipe) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
+        else if (lean && ws && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         else if (lean && ws) hipLaunchKernelGGL((k_conv_ws<256, 8, 4>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         else if (lean && upm) hipLaunchKernelGGL((k_conv_lean<256, 8, 0, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);

@@ -333,7 +333,7 @@ def test_conv_down_dhw(dev):
     assert _rel(out, _cl(ref)) < 1e-4
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'}, {'ES_CONV_PIPE': '1'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
     non-specialised k_conv_lean for 256-row tiles, the opt-in producer/consumer 128-row variant) must give the same
