@@ -76,28 +76,29 @@ def layout_diffusion_kwargs(time_num=1000):
                     loss_iou=False, iou_type='obb', train_stats_file=None)
 
 
-def shape_unet_params(model_channels=224, concat=False):
+def shape_unet_params(model_channels=224, concat=False, mp=True):
     """config/sdfusion-txt2shape_mp.yaml; ``concat=True``: config/sdfusion-txt2shape_concat_mp.yaml (in_channels 5,
-    dims 4 = Conv3d with stride 2 / nearest x2 in all three axes, AttentionBlocks, no context)."""
+    dims 4 = Conv3d with stride 2 / nearest x2 in all three axes, AttentionBlocks, no context).  ``mp=False``: the
+    configs without echo message passing (sdfusion-txt2shape.yaml / sdfusion-txt2shape_concat.yaml, in_channels 3 / 4)."""
     if concat:
         return AttrDict(
-            image_size=16, in_channels=5, out_channels=3, model_channels=model_channels,
+            image_size=16, in_channels=5 if mp else 4, out_channels=3, model_channels=model_channels,
             num_res_blocks=2, attention_resolutions=[4, 2], channel_mult=[1, 2, 3], num_heads=8, dims=4,
             use_spatial_transformer=False, transformer_depth=1, context_dim=None, use_checkpoint=True,
-            legacy=False, messsage_passing=True, enable_t_emb=True)
+            legacy=False, messsage_passing=mp, enable_t_emb=mp)
     return AttrDict(
         image_size=16, in_channels=3, out_channels=3, model_channels=model_channels,
         num_res_blocks=2, attention_resolutions=[4, 2], channel_mult=[1, 2, 3], num_heads=8, dims=3,
         use_spatial_transformer=True, transformer_depth=1, context_dim=1280, use_checkpoint=True,
-        legacy=False, messsage_passing=True, enable_t_emb=True)
+        legacy=False, messsage_passing=mp, enable_t_emb=mp)
 
 
-def shape_df_conf(model_channels=224, concat=False):
+def shape_df_conf(model_channels=224, concat=False, mp=True):
     return AttrDict(
         model=AttrDict(params=AttrDict(linear_start=0.00085, linear_end=0.012,
                                        conditioning_key='concat' if concat else 'crossattn', timesteps=1000,
                                        scale_factor=0.18215)),
-        unet=AttrDict(params=shape_unet_params(model_channels, concat)))
+        unet=AttrDict(params=shape_unet_params(model_channels, concat, mp)))
 
 
 def vqvae_conf(ch=64):

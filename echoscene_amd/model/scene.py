@@ -177,7 +177,8 @@ class EchoToShape(object):
         # 'concat': c_s is a constant fourth input channel (echo2shape.py:234-235, network.py:26-28); 'crossattn' + mp
         # ignores it (the GCN output overwrites the context, openai_model_3d.py:843-844)
         z = den.sample(self.uc_rel, self.triples, noise1=noise,
-                       c=self.rel if self.df.conditioning_key == 'concat' else None)
+                       c=self.rel if (self.df.conditioning_key == 'concat' or
+                                      not self.df.diffusion_net.messsage_passing) else None)
         self.gen_df = self._decoder().decode_no_quant(z, sync=sync)
         return self.gen_df
 

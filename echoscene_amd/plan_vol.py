@@ -57,19 +57,19 @@ class UNet3DWeights:
         self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
         self.heads = net.num_heads
         self.concat = bool(getattr(net, 'concat', False))
-        if not self.mp:
-            raise NotImplementedError('shape denoiser without message passing (config full.yaml) is not built yet')
         dv = lambda k: sd[k].detach().float().contiguous().to(device)
         PL = lambda w, b: PackedLinear(sd[w], sd[b] if b else None, device)
         PC = lambda w, b: PackedConv(sd[w], sd[b] if b else None, device)
         self.te0 = PL('time_embed.0.weight', 'time_embed.0.bias')
         self.te2 = PL('time_embed.2.weight', 'time_embed.2.bias')
-        self.stem = [dv('shape_embeddings.0.weight'), dv('shape_embeddings.0.bias'),
-                     dv('shape_embeddings.2.weight'), dv('shape_embeddings.2.bias')]
-        self.stem_lin = PL('shape_embeddings.5.weight', 'shape_embeddings.5.bias')
-        self.shape_t = PL('shape_time_emb.weight', 'shape_time_emb.bias') if net.enable_t_emb else None
-        self.pred_table = sd['pred_embeddings.weight'].detach().float().cpu()
-        self.gcn = GCNWeights(sd, 'shape_code_graph_cov', device)
+        self.shape_t = None
+        if self.mp:
+            self.stem = [dv('shape_embeddings.0.weight'), dv('shape_embeddings.0.bias'),
+                         dv('shape_embeddings.2.weight'), dv('shape_embeddings.2.bias')]
+            self.stem_lin = PL('shape_embeddings.5.weight', 'shape_embeddings.5.bias')
+            self.shape_t = PL('shape_time_emb.weight', 'shape_time_emb.bias') if net.enable_t_emb else None
+            self.pred_table = sd['pred_embeddings.weight'].detach().float().cpu()
+            self.gcn = GCNWeights(sd, 'shape_code_graph_cov', device)
         inp, mid, out = net.topo
         names = [(f'input_blocks.{i}.{j}', it) for i, blk in enumerate(inp) for j, it in enumerate(blk)]
         names += [(f'middle_block.{j}', it) for j, it in enumerate(mid)]
@@ -254,59 +254,93 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
         b.linear([seg(View(temb, ld=0, width=mc), step=step, step_stride=mc)], w.te0, O, e1, act=hip.ACT_SILU)
         emb = View(b.buf(O, E))
         b.linear([seg(e1)], w.te2, O, emb)
-    ucw = uc_dev.shape[1]
-    Dobj = ucw + gdim + (gdim if w.enable_t_emb else 0)
-    objbuf = b.buf(O, Dobj)
-    objbuf[:, :ucw].copy_(uc_dev)
-    code512 = b.buf(Ol, 512)
+    row0 = lo                                  # first local row inside the per-object row buffers
     xc = None
-    if w.concat:
-        assert c_dev is not None and ucw == V0 and tuple(c_dev.shape) == (Ol, V0), 'concat: uc_s / c_s must be [O, D*H*W]'
-        xc = b.buf(Ol, 5, V0)
-        xc[:, 3].copy_(c_dev)                  # constant over the loop: written once at plan build
-        b.copy(xc.data_ptr(), x.data_ptr(), 3 * V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=3 * V0 * 4)
-        b.stem(xc, w.stem, b.buf(Ol, 32 * 512), code512, Ol, cin=4, ostride=5 * V0)
-        b.xc = xc
-    else:
-        b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
-    if Ol == Ofull:
-        b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
-        b.codes_local = None
-    else:
-        b.codes_local = b.buf(Ol, gdim)
-        b.linear([seg(View(code512))], w.stem_lin, Ol, View(b.codes_local))
-    b.split = len(b.ops)                       # <- all-gather point of the multi-GPU loop
-    b.code_cols = (ucw, gdim)
-    if w.enable_t_emb:
-        if tables is not None:
-            b.rowsel(tables['t_lin'], step, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim), rows=O)
-        else:
-            b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
-    pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
-    ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
-    b.tags.update(ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
-    emb_ld = w.emb_all.N
-    if tables is not None:                     # all objects share t: one table row, broadcast (rowvec_ld = 0)
-        emb_all = b.buf(1, w.emb_all.N)
-        b.rowsel(tables['emb_all'], step, View(emb_all))
-        emb_ld = 0
-    else:
-        b.tags['emb'] = emb
-        emb_all = b.buf(O, w.emb_all.N)
-        b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
     cavo, coff = {}, 0
-    if w.concat:
-        # GCN output rows of the local objects -> fifth input channel
-        assert ctx.width == V0
-        b.copy(xc[:, 4].data_ptr(), ctx.ptr + lo * ctx.ld * 4, V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=ctx.ld * 4)
+    if w.mp:
+        ucw = uc_dev.shape[1]
+        Dobj = ucw + gdim + (gdim if w.enable_t_emb else 0)
+        objbuf = b.buf(O, Dobj)
+        objbuf[:, :ucw].copy_(uc_dev)
+        code512 = b.buf(Ol, 512)
+        if w.concat:
+            assert c_dev is not None and ucw == V0 and tuple(c_dev.shape) == (Ol, V0), 'concat: uc_s / c_s must be [O, D*H*W]'
+            xc = b.buf(Ol, 5, V0)
+            xc[:, 3].copy_(c_dev)                  # constant over the loop: written once at plan build
+            b.copy(xc.data_ptr(), x.data_ptr(), 3 * V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=3 * V0 * 4)
+            b.stem(xc, w.stem, b.buf(Ol, 32 * 512), code512, Ol, cin=4, ostride=5 * V0)
+            b.xc = xc
+        else:
+            b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
+        if Ol == Ofull:
+            b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
+            b.codes_local = None
+        else:
+            b.codes_local = b.buf(Ol, gdim)
+            b.linear([seg(View(code512))], w.stem_lin, Ol, View(b.codes_local))
+        b.split = len(b.ops)                       # <- all-gather point of the multi-GPU loop
+        b.code_cols = (ucw, gdim)
+        if w.enable_t_emb:
+            if tables is not None:
+                b.rowsel(tables['t_lin'], step, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim), rows=O)
+            else:
+                b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
+        pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
+        ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
+        b.tags.update(ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
+        emb_ld = w.emb_all.N
+        if tables is not None:                     # all objects share t: one table row, broadcast (rowvec_ld = 0)
+            emb_all = b.buf(1, w.emb_all.N)
+            b.rowsel(tables['emb_all'], step, View(emb_all))
+            emb_ld = 0
+        else:
+            b.tags['emb'] = emb
+            emb_all = b.buf(O, w.emb_all.N)
+            b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
+        if w.concat:
+            # GCN output rows of the local objects -> fifth input channel
+            assert ctx.width == V0
+            b.copy(xc[:, 4].data_ptr(), ctx.ptr + lo * ctx.ld * 4, V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=ctx.ld * 4)
+        else:
+            cav = b.buf(O, w.cav_all.N)
+            b.linear([seg(ctx)], w.cav_all, O, View(cav))
+            for name, (k, Cc) in w.ca.items():
+                o = View(b.buf(O, Cc))
+                b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
+                cavo[name] = o
+                coff += Cc
     else:
-        cav = b.buf(O, w.cav_all.N)
-        b.linear([seg(ctx)], w.cav_all, O, View(cav))
-        for name, (k, Cc) in w.ca.items():
-            o = View(b.buf(O, Cc))
-            b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
-            cavo[name] = o
-            coff += Cc
+        # No echo message passing (sdfusion-txt2shape.yaml / sdfusion-txt2shape_concat.yaml): objects are independent and
+        # c_s (c_dev, this rank's rows) is the one cross-attention key ('crossattn') or the fourth input channel
+        # ('concat').  The per-object row buffers hold the local objects only; nothing is exchanged between ranks.
+        assert c_dev is not None, 'shape denoiser without message passing needs the conditioning c_s'
+        O, row0, objbuf = Ol, 0, None
+        b.split, b.codes_local, b.code_cols = 0, None, None
+        emb_ld = w.emb_all.N
+        if tables is not None:
+            emb_all = b.buf(1, w.emb_all.N)
+            b.rowsel(tables['emb_all'], step, View(emb_all))
+            emb_ld = 0
+        else:
+            b.tags['emb'] = emb
+            emb_all = b.buf(O, w.emb_all.N)
+            b.linear([seg(emb)], w.emb_all, O, View(emb_all), prologue=hip.PRO_SILU)
+        if w.concat:
+            assert tuple(c_dev.shape) == (Ol, V0), 'concat: c_s must be [O, D*H*W]'
+            xc = b.buf(Ol, 4, V0)
+            xc[:, 3].copy_(c_dev)
+            b.copy(xc.data_ptr(), x.data_ptr(), 3 * V0 * 4, rows=Ol, dst_pitch=4 * V0 * 4, src_pitch=3 * V0 * 4)
+            b.xc = xc
+        else:
+            ctx = View(b.dev(c_dev))
+            b.cdev = ctx.t                       # refreshed by the caller for every sample
+            cav = b.buf(O, w.cav_all.N)
+            b.linear([seg(ctx)], w.cav_all, O, View(cav))
+            for name, (k, Cc) in w.ca.items():
+                o = View(b.buf(O, Cc))
+                b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
+                cavo[name] = o
+                coff += Cc
 
     # ---- volume path ----
     state = dict(h=None, C=0, dims=dims, last_op=None, h16=None)
@@ -346,7 +380,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 raw = b.buf(M, cin, dtype=f16) if 'skip' in d else None
                 b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
                 h1 = b.buf(M, cout)
-                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=lo if emb_ld else 0), out_f32=h1)
+                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=row0 if emb_ld else 0), out_f32=h1)
                 y2 = b.buf(M, cout, dtype=f16)
                 b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
                 o = b.buf(M, cout)
@@ -384,7 +418,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
                 t2 = b.buf(M, Cc)
-                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, row=lo), res=t0, out_f32=t2)
+                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, row=row0), res=t0, out_f32=t2)
                 l3 = b.buf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
                 gg = b.buf(M, 4 * Cc, dtype=f16)

@@ -136,9 +136,11 @@ class ShapeDenoiser:
         uc = uc.reshape(uc.shape[0], -1)
         O = uc.shape[0]
         concat = self.w.concat
-        if concat:
+        need_c = concat or not self.w.mp        # c_s is unused only by 'crossattn' WITH message passing
+        if need_c:
             if c is None:
-                raise ValueError("'concat' shape denoiser needs the conditioning c_s [O, 4096] (echo2shape.py:234-235)")
+                raise ValueError("this shape denoiser needs the conditioning c_s (concat: [O, 4096], echo2shape.py:234-235; "
+                                 "no message passing: the cross-attention key [O, 1, context_dim])")
             c = c.reshape(O, -1).to(self.device).float()
         key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
         st = self._plans.get(key)
@@ -151,11 +153,12 @@ class ShapeDenoiser:
             step = b.buf(1, dtype=torch.int32, zero=True)
             ucd = b.dev(uc)
             objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi,
-                                      c_dev=c[lo:hi] if concat else None, tables=self.tables)
+                                      c_dev=c[lo:hi] if need_c else None, tables=self.tables)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
             st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
-                      codes_local=b.codes_local, code_cols=b.code_cols, xc=getattr(b, 'xc', None))
+                      codes_local=b.codes_local, code_cols=b.code_cols, xc=getattr(b, 'xc', None),
+                      cdev=getattr(b, 'cdev', None))
 
             def sub(ops):
                 b2 = Builder(self.device)
@@ -164,13 +167,16 @@ class ShapeDenoiser:
                 return b2.finish()
             st['plan'] = b.finish()
             st['eps_plan'] = sub(b.ops[:n_eps_ops])
-            if self.world > 1:
+            if self.world > 1 and self.w.mp:
                 st['stem_plan'] = sub(b.ops[:b.split])
                 st['main_plan'] = sub(b.ops[b.split:])
             self._plans = {key: st}
-        st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
+        if st['objbuf'] is not None:
+            st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
         if concat:
             st['xc'][:, 3].copy_(c[st['lo']:st['hi']])
+        elif st['cdev'] is not None:
+            st['cdev'].copy_(c[st['lo']:st['hi']])
         return st
 
     # -- shard backend protocol of parallel.sharded_ddim_loop ------------------------------------------------
@@ -205,9 +211,12 @@ class ShapeDenoiser:
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
         st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
-        if self.world == 1:
+        if self.world == 1 or not self.w.mp:
             st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
-            return st['x'].clone()
+            if self.world == 1:
+                return st['x'].clone()
+            from .parallel import all_gather_rows         # no message passing: ranks only meet at the end
+            return all_gather_rows(st['x'], st['O'], self.world, self.group).clone()
         self._cur, self._use_graph = st, use_graph
         return sharded_ddim_loop(self, st['O'], n_steps, self.world, self.group).clone()
 

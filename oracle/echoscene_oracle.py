@@ -444,7 +444,7 @@ def ddim_step(x, e_t, a_t, a_prev, sqrt_1m_at):
 
 
 def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, enable_t_emb=True,
-                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None, c_concat=None):
+                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None, c_concat=None, context=None):
     """rel2shape's DDIM loop (echo2shape.py:484-521, ddim.py:127-181): one noise tensor shared by
     all objects, 'elif True' branch (single UNet call, no CFG), eta 0."""
     ac = shape_alphas_cumprod(linear_start, linear_end)
@@ -457,7 +457,8 @@ def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, e
         index = total - 1 - i
         step = int(ts[index])
         t_ = torch.full((O,), step, dtype=torch.long)
-        e = unet3d_forward(sd, x, uc_s, triples, t_, None, heads, enable_t_emb, nm, c_concat=c_concat)
+        # ``context`` (c_s) only matters without message passing: the GCN output overwrites it otherwise
+        e = unet3d_forward(sd, x, uc_s, triples, t_, context, heads, enable_t_emb, nm, c_concat=c_concat)
         x = ddim_step(x, e, a[index], a_prev[index], s1m[index])
         if trace is not None:
             trace.append(x.clone())

@@ -360,6 +360,40 @@ def case_vqvae():
              sdf_sum=sdf.double().sum(), sdf_abs=sdf.double().abs().sum(), cfg=np.array([ch, ne]))
 
 
+def case_nomp():
+    """Shape denoisers WITHOUT echo message passing (config/sdfusion-txt2shape.yaml, sdfusion-txt2shape_concat.yaml):
+    objects independent, c_s is the cross-attention key / the concat channel.  eps + 4-step DDIM loop, tiny widths."""
+    from model.networks.diffusion_shape.network import DiffusionUNet
+    from model.networks.diffusion_shape.echo2shape import EchoToShape
+    from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+    for fam in ('crossattn', 'concat'):
+        p = escfg.shape_unet_params(32, concat=(fam == 'concat'), mp=False)
+        if fam == 'crossattn':
+            p['context_dim'] = 64
+        net = DiffusionUNet(p, vq_conf=None, conditioning_key=fam)
+        fill(net, 'unet3d_nomp_%s.' % fam)
+        O = 3
+        objs, triples = synth.synthetic_graph(O, seed=16)
+        x = rnd((O, 3, 16, 16, 16), 171)
+        uc = rnd((O, 1, 64), 172)
+        c = rnd((O, 1, 64), 173) if fam == 'crossattn' else rnd((O, 1, 16, 16, 16), 173)
+        t = torch.full((O,), 401, dtype=torch.long)
+        with torch.no_grad():
+            eps = net(x, uc, triples, t, **({'c_crossattn': [c]} if fam == 'crossattn' else {'c_concat': [c]}))
+        shim = _ShapeShim()
+        shim.df = shim.df_module = net
+        EchoToShape.register_schedule(shim, timesteps=1000, linear_start=0.00085, linear_end=0.012)
+        shim.apply_model = lambda *a, **k: EchoToShape.apply_model(shim, *a, **k)
+        DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+        noise1 = synth.shape_noise(seed=7)
+        with torch.no_grad():
+            z, _ = DDIMSampler(shim).sample(S=4, batch_size=O, shape=(3, 16, 16, 16), conditioning=c,
+                                            x_T=noise1.repeat(O, 1, 1, 1, 1), verbose=False,
+                                            unconditional_guidance_scale=3., unconditional_conditioning=uc,
+                                            triplet=triples, eta=0.0)
+        save('unet3d_nomp_' + fam, x=x, uc_s=uc, c_s=c, triples=triples, t=t, eps=eps, z_final=z)
+
+
 def case_scene_e2e_concat():
     """Same as case_scene_e2e for the 'concat' family (config/full_concat_mp.yaml equivalent, tiny widths)."""
     case_scene_e2e(concat=True)
@@ -440,7 +474,7 @@ def case_scene_e2e(concat=False):
     save('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny', **out)
 
 
-CASES = dict(concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat)

@@ -351,3 +351,23 @@ def test_conv_alternate_kernels(env):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
                        env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('fam', ['crossattn', 'concat'])
+def test_unet3d_without_message_passing_vs_reference_golden(dev, fam):
+    """Shape denoisers of the configs without echo message passing (objects independent, c_s = key / concat channel)."""
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    g = load_golden('unet3d_nomp_' + fam)
+    p = escfg.shape_unet_params(32, concat=(fam == 'concat'), mp=False)
+    if fam == 'crossattn':
+        p['context_dim'] = 64
+    df = DiffusionUNet(p, conditioning_key=fam)
+    synth.seeded_fill_(df, prefix='unet3d_nomp_%s.' % fam)
+    den = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=100, device=dev)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    e = _rel(den.eps(g['x'], g['uc_s'], g['triples'], iteration=it, c=g['c_s']), g['eps'])
+    den4 = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=4, device=dev)
+    ez = _rel(den4.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), c=g['c_s']), g['z_final'])
+    print('unet3d no-mp %s: eps rel err %.3e, 4-step DDIM rel err %.3e' % (fam, e, ez))
+    assert e < 2e-2 and ez < 2e-2

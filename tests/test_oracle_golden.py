@@ -202,3 +202,19 @@ def test_unet3d_concat(tag, mc):
     if tag == 'tiny':
         z = orc.shape_sample_loop(sd, g['uc_s'], g['triples'], synth.shape_noise(seed=7), S=4, c_concat=g['c_s'])
         _close(z, g['z_final'], 2e-4)
+
+
+@pytest.mark.parametrize('fam', ['crossattn', 'concat'])
+def test_unet3d_without_message_passing(fam):
+    """config/sdfusion-txt2shape.yaml / sdfusion-txt2shape_concat.yaml: no GCN, c_s is the key / the concat channel."""
+    g = load_golden('unet3d_nomp_' + fam)
+    p = escfg.shape_unet_params(32, concat=(fam == 'concat'), mp=False)
+    if fam == 'crossattn':
+        p['context_dim'] = 64
+    df = DiffusionUNet(p, conditioning_key=fam)
+    sd = {k[len('diffusion_net.'):]: v for k, v in seeded_state_dict(df, 'unet3d_nomp_%s.' % fam).items()}
+    kw = dict(c_concat=g['c_s']) if fam == 'concat' else dict(context=g['c_s'])
+    eps = orc.unet3d_forward(sd, g['x'], g['uc_s'], g['triples'], g['t'], **kw)
+    _close(eps, g['eps'], 5e-5)
+    z = orc.shape_sample_loop(sd, g['uc_s'], g['triples'], synth.shape_noise(seed=7), S=4, **kw)
+    _close(z, g['z_final'], 2e-4)
