@@ -136,3 +136,53 @@ def test_chamfer_vs_oracle(B, n, m):
     ((d1 * w1.cuda()).sum() + (d2 * w2.cuda()).sum()).backward()
     g1, g2 = orc.chamfer_backward(a, b, w1, w2, i1, i2)
     assert torch.allclose(ac.grad.cpu(), g1, atol=2e-4, rtol=1e-4) and torch.allclose(bc.grad.cpu(), g2, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('O', [2, 5])
+def test_small_and_odd_graphs_vs_oracle(O):
+    """Edge sizes: the smallest scene graph (one object + the scene node, a single triple) and an odd object count --
+    both loops against the CPU oracle (tiny widths)."""
+    from echoscene_amd.model.unet import UNet1DModel, DiffusionUNet
+    from echoscene_amd.samplers import LayoutDenoiser, ShapeDenoiser
+    from oracle import echoscene_oracle as orc
+    dev = torch.device('cuda')
+    objs, triples = synth.synthetic_graph(O, seed=21)
+    assert triples.shape[0] >= 1
+    kw = dict(escfg.layout_denoiser_kwargs(128))
+    kw['concat_dim'] = kw['crossattn_dim'] = 128
+    net = UNet1DModel(**kw)
+    synth.seeded_fill_(net, prefix='edge.layout.')
+    oe = torch.randn(O, 640, generator=torch.Generator().manual_seed(3))
+    noise = synth.layout_noise(O, 8, 100, seed=11)
+    x = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(100), dev).sample(oe, triples, noise, n_steps=12).cpu()
+    ref = orc.layout_sample_loop({k: v.detach() for k, v in net.state_dict().items()}, oe, triples, noise, 100, n_steps=12)
+    assert (x - ref).abs().max().item() < 2e-4
+    p = escfg.shape_unet_params(32)
+    p['context_dim'] = 64
+    df = DiffusionUNet(p)
+    synth.seeded_fill_(df, prefix='edge.shape.')
+    uc = torch.randn(O, 1, 64, generator=torch.Generator().manual_seed(4))
+    z = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=4, device=dev).sample(uc, triples, synth.shape_noise(seed=7)).cpu()
+    zref = orc.shape_sample_loop({k[len('diffusion_net.'):]: v.detach() for k, v in df.state_dict().items()}, uc, triples,
+                                 synth.shape_noise(seed=7), S=4)
+    assert _rel(z, zref) < 2e-2
+
+
+def test_collated_batch_equals_single_scenes():
+    """Batch mode (bench.py --scaling weak, BASELINE configs[4]): scenes collated into one block-diagonal graph as the
+    reference's collate_fn does give, per scene, the result of sampling that scene alone (no cross-scene edges)."""
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    dev = torch.device('cuda')
+    p = escfg.shape_unet_params(32)
+    p['context_dim'] = 64
+    df = DiffusionUNet(p)
+    synth.seeded_fill_(df, prefix='batch.shape.')
+    graphs = [synth.synthetic_graph(n, seed=30 + i) for i, n in enumerate((4, 3))]
+    ucs = [torch.randn(n, 1, 64, generator=torch.Generator().manual_seed(40 + i)) for i, n in enumerate((4, 3))]
+    noise1 = synth.shape_noise(seed=7)
+    den = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=4, device=dev)
+    singles = [den.sample(u, g[1], noise1).cpu() for g, u in zip(graphs, ucs)]
+    _, tri_all = synth.collate_graphs(graphs)
+    zb = den.sample(torch.cat(ucs), tri_all, noise1).cpu()
+    assert _rel(zb, torch.cat(singles)) < 2e-3      # tile sizes depend on the object count: fp16-operand rounding noise
