@@ -176,12 +176,8 @@ extern "C" int es_sampler_run(es_plan* p, int32_t* step, int first_step, int n_s
     ES_REQUIRE(p != nullptr && step != nullptr && n_steps >= 0, "es_sampler_run: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (use_graph) if (int rc = es_plan_capture(p, stream)) return rc;
-    // step counter lives on the device; a 4-byte async copy from a value captured by-value
-    static thread_local int32_t h_first[64];
-    static thread_local int h_slot = 0;
-    int32_t* hv = &h_first[h_slot++ & 63];
-    *hv = first_step;
-    ES_CHECK_HIP(hipMemcpyAsync(step, hv, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // step counter lives on the device; set by value (no host buffer whose lifetime an async copy would depend on)
+    ES_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)step, first_step, 1, s));
     for (int i = 0; i < n_steps; ++i) {
         if (use_graph) ES_CHECK_HIP(hipGraphLaunch(p->exec, s));
         else if (int rc = es_plan_run(p, stream)) return rc;
