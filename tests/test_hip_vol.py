@@ -371,3 +371,25 @@ def test_unet3d_without_message_passing_vs_reference_golden(dev, fam):
     ez = _rel(den4.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), c=g['c_s']), g['z_final'])
     print('unet3d no-mp %s: eps rel err %.3e, 4-step DDIM rel err %.3e' % (fam, e, ez))
     assert e < 2e-2 and ez < 2e-2
+
+
+def test_shards_without_message_passing(dev, monkeypatch):
+    """No echo message passing: ranks never exchange anything during the loop; each shard's latents == the rows of the
+    unsharded run (the final all-gather is replaced by a recorder)."""
+    from echoscene_amd import parallel
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    g = load_golden('unet3d_nomp_crossattn')
+    p = escfg.shape_unet_params(32, mp=False)
+    p['context_dim'] = 64
+    df = DiffusionUNet(p, conditioning_key='crossattn')
+    synth.seeded_fill_(df, prefix='unet3d_nomp_crossattn.')
+    noise1 = synth.shape_noise(seed=7)
+    mk = lambda r, w: ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=4, device=dev, rank=r, world=w)
+    z_ref = mk(0, 1).sample(g['uc_s'], g['triples'], noise1, c=g['c_s'])
+    got = []
+    monkeypatch.setattr(parallel, 'all_gather_rows', lambda local, n, world, group=None: got.append(local.clone()) or local)
+    for r in range(2):
+        mk(r, 2).sample(g['uc_s'], g['triples'], noise1, c=g['c_s'])
+    z = torch.cat(got, 0)
+    assert z.shape == z_ref.shape and _rel(z, z_ref) < 2e-3
