@@ -47,3 +47,13 @@ den = diff.ShapeDiff._denoiser()
 z = timed('shape loop (100 DDIM steps)', lambda: den.sample(uc[0], args[1], noise1=torch.randn(1, 3, 16, 16, 16, device='cuda'),
                                                              c=uc[1] if a.concat else None))
 sdf = timed('VQ-VAE decode', lambda: diff.ShapeDiff._decoder().decode_no_quant(z))
+
+# ---- a NEW scene graph of the same size: plans are rebuilt and graphs re-captured ----
+objs2, triples2 = synth.synthetic_graph(O, seed=10)
+tf2, rf2 = synth.synthetic_features(O, triples2.shape[0], seed=10)
+args2 = (objs2.cuda(), triples2.cuda(), tf2.cuda(), rf2.cuda())
+for i in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d = m.sample_box_and_shape(*args2, gen_shape=True)
+    torch.cuda.synchronize()
+    print('new graph, call %d: %.3f s' % (i, time.perf_counter() - t0), flush=True)
