@@ -186,3 +186,44 @@ def test_collated_batch_equals_single_scenes():
     _, tri_all = synth.collate_graphs(graphs)
     zb = den.sample(torch.cat(ucs), tri_all, noise1).cpu()
     assert _rel(zb, torch.cat(singles)) < 2e-3      # tile sizes depend on the object count: fp16-operand rounding noise
+
+
+def test_full_size_permutation_equivariance():
+    """Size-independent property at BASELINE.json's full size (32-node graph, shipped widths): relabelling the objects
+    (rows of x / obj_embed permuted, triple endpoints renamed, triple order kept) permutes the outputs of both
+    denoisers -- exercises the gather / segmented-mean indexing and the per-object independence of every volume kernel
+    at O = 32, where no CPU oracle run is affordable."""
+    from echoscene_amd.model.unet import UNet1DModel, DiffusionUNet
+    from echoscene_amd.samplers import LayoutDenoiser, ShapeDenoiser
+    dev = torch.device('cuda')
+    O = 32
+    objs, triples = synth.synthetic_graph(O, seed=100)
+    gen = torch.Generator().manual_seed(77)
+    perm = torch.randperm(O, generator=gen)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(O)
+    tri_p = triples.clone()
+    tri_p[:, 0], tri_p[:, 2] = inv[triples[:, 0]], inv[triples[:, 2]]
+    # layout denoiser, full width
+    net = UNet1DModel(**escfg.layout_denoiser_kwargs(512))
+    synth.seeded_fill_(net, prefix='perm.layout.')
+    den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(1000), dev)
+    x = torch.randn(O, 8, generator=gen)
+    oe = torch.randn(O, 640, generator=gen)
+    e0 = den.eps(x, oe, triples, iteration=400).cpu()
+    e1 = den.eps(x[perm], oe[perm], tri_p, iteration=400).cpu()
+    assert torch.isfinite(e0).all() and (e1 - e0[perm]).abs().max().item() < 1e-5 * max(1.0, e0.abs().max().item())
+    del den, net
+    # shape denoiser, full width
+    conf = escfg.shape_df_conf(224)
+    df = DiffusionUNet(conf.unet.params, conditioning_key='crossattn')
+    synth.seeded_fill_(df, prefix='perm.shape.')
+    sden = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev)
+    xs = torch.randn(O, 3, 16, 16, 16, generator=gen)
+    uc = torch.randn(O, 1, 1280, generator=gen)
+    s0 = sden.eps(xs, uc, triples, iteration=40).cpu()
+    s1 = sden.eps(xs[perm], uc[perm], tri_p, iteration=40).cpu()
+    assert torch.isfinite(s0).all()
+    assert _rel(s1, s0[perm]) < 1e-5, 'objects are not independent / indexing depends on the labelling'
+    s2 = sden.eps(xs, uc, triples, iteration=40).cpu()
+    assert torch.equal(s0, s2), 'the full-size step is not deterministic'
