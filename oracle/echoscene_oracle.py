@@ -15,6 +15,9 @@ in the build container, fills its modules with ``echoscene_amd.synth.seeded_tens
 weights and stores inputs/outputs under ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` checks every function below against those vectors.
 (The reference has no tests or golden vectors of its own -- SURVEY.md section 4.)
+Exceptions, stated here as required: ``chamfer_forward/backward`` restate a CUDA extension that cannot
+be built in this image -> parity UNPINNED for those two functions; ``descale_box_params`` / ``sincos2arctan`` are pinned like
+the rest (golden ``box_post`` from the reference's helpers/util.py).
 
 Everything is driven by a flat ``state_dict`` (name -> tensor) with the reference's
 key names, so the network topology is *inferred from the keys* -- independently of

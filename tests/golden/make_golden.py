@@ -360,6 +360,22 @@ def case_vqvae():
              sdf_sum=sdf.double().sum(), sdf_abs=sdf.double().abs().sum(), cfg=np.array([ch, ne]))
 
 
+def case_box_post():
+    """the reference's own helpers/util.py descale_box_params / postprocess_sincos2arctan on random boxes."""
+    import tempfile
+    from helpers.util import descale_box_params, postprocess_sincos2arctan
+    rs = np.random.RandomState(0)
+    boxes = torch.from_numpy(rs.uniform(-1.2, 1.2, (33, 6)).astype(np.float32))
+    sc = torch.from_numpy(rs.standard_normal((33, 2)).astype(np.float32))
+    stats = np.concatenate([rs.uniform(0.1, 0.5, 3), rs.uniform(1.0, 3.0, 3), rs.uniform(-4, -2, 3), rs.uniform(2, 4, 3),
+                            [-np.pi, np.pi]])
+    f = os.path.join(tempfile.mkdtemp(prefix='golden_box_'), 'stats.txt')
+    np.savetxt(f, stats)
+    out = descale_box_params(boxes.clone(), file=f)
+    ang = postprocess_sincos2arctan(sc)
+    save('box_post', boxes=boxes, sincos=sc, stats=torch.from_numpy(stats), boxes_out=out, angle=ang)
+
+
 def case_nomp():
     """Shape denoisers WITHOUT echo message passing (config/sdfusion-txt2shape.yaml, sdfusion-txt2shape_concat.yaml):
     objects independent, c_s is the cross-attention key / the concat channel.  eps + 4-step DDIM loop, tiny widths."""
@@ -474,7 +490,7 @@ def case_scene_e2e(concat=False):
     save('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny', **out)
 
 
-CASES = dict(nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat)

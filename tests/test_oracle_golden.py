@@ -218,3 +218,11 @@ def test_unet3d_without_message_passing(fam):
     _close(eps, g['eps'], 5e-5)
     z = orc.shape_sample_loop(sd, g['uc_s'], g['triples'], synth.shape_noise(seed=7), S=4, **kw)
     _close(z, g['z_final'], 2e-4)
+
+
+def test_box_postprocess_helpers_vs_reference():
+    """descale_box_params / postprocess_sincos2arctan restated in the oracle vs the reference's own helpers."""
+    g = load_golden('box_post')
+    out = orc.descale_box_params(g['boxes'].clone(), g['stats'].numpy())
+    _close(torch.as_tensor(out), g['boxes_out'], 1e-6)
+    _close(torch.as_tensor(orc.sincos2arctan(g['sincos'])).reshape(-1, 1), g['angle'], 1e-6)
