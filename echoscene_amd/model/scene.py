@@ -268,10 +268,16 @@ class _SceneModel(nn.Module):
         Returns obj_embed_ (uc), latent_obj_vecs after splicing (c), device tensors."""
         from ..plan import Builder, GraphIndex, GCNWeights, View, emit_gcn
         dev = _hip_device(_dev(self))
-        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
         if self._setup_w is None:
-            self._setup_w = (GCNWeights(sd, 'gconv_net_ec', dev), GCNWeights(sd, 'gconv_net_manipulation', dev))
-        w_ec, w_man = self._setup_w
+            # packed GCN weights + the three embedding tables the glue reads; dropped by invalidate()
+            sd = {k: v.detach().cpu() for k, v in nn.Module.state_dict(self).items()
+                  if k.startswith(('gconv_net_ec.', 'gconv_net_manipulation.', 'obj_embeddings_ec.', 'pred_embeddings_ec.',
+                                   'pred_embeddings_man_dc.'))}
+            self._setup_w = (GCNWeights(sd, 'gconv_net_ec', dev), GCNWeights(sd, 'gconv_net_manipulation', dev),
+                             {k: sd[k + '.weight'] for k in ('obj_embeddings_ec', 'pred_embeddings_ec',
+                                                             'pred_embeddings_man_dc')})
+        w_ec, w_man, tabs = self._setup_w
+        sd = {k + '.weight': v for k, v in tabs.items()}
         g = self.embedding_dim
 
         def embed(objs, triples, text, rel, ptab):
@@ -299,8 +305,10 @@ class _SceneModel(nn.Module):
             for ad in added_rows:
                 rows.insert(ad, torch.zeros(1, D, device=dev))
             latent = torch.cat(rows, 0)
+        # the reference walks the node index upwards and draws for every index that is IN the list (EchoScene.py:428-435):
+        # ascending order, one draw per distinct node, out-of-range entries never match
         change = torch.zeros(Od, g)
-        for i in change_rows:
+        for i in sorted({int(r) for r in change_rows if 0 <= int(r) < Od}):
             change[i] = torch.from_numpy(np.random.normal(0, 1, g)).float()
         man_in = torch.cat([latent, change.to(dev), dec_oe.to(dev)], 1).contiguous()
         b2 = Builder(dev)
@@ -401,13 +409,15 @@ class Sg2ScDiffModel(_SceneModel):
         if not self.replace_all_latent:
             latent = latent.clone()
             for t in sorted(touched):                       # take original nodes when untouched (:440-448)
-                latent[t] = latent_m[t]
+                if 0 <= int(t) < latent.shape[0]:
+                    latent[t] = latent_m[t]
         else:
             latent = latent_m
         sdf, boxes = self._layout_and_shapes(gen_shape, dec[0], dec[1], oe, latent, layout_noise, shape_noise)
         keep = torch.ones(len(boxes['translations']), 1, device=oe.device)
         for t in touched:
-            keep[t] = 0
+            if 0 <= int(t) < keep.shape[0]:
+                keep[int(t)] = 0
         return keep, {'shapes': sdf}, boxes
 
     @torch.no_grad()
@@ -478,11 +488,16 @@ class Sg2BoxDiffModel(_SceneModel):
         if not self.replace_all_latent:
             latent = latent.clone()
             for t in sorted(touched):
-                latent[t] = latent_m[t]
+                if 0 <= int(t) < latent.shape[0]:
+                    latent[t] = latent_m[t]
         else:
             latent = latent_m
         boxes = self._layout(dec_triples, oe, latent, layout_noise)
-        keep = [0 if i in touched else 1 for i in range(len(boxes['translations']))]
+        # f32 [O,1] tensor on the model's device (EchoLayout.py:342-348); only the _with_additions variant returns a list
+        keep = torch.ones(len(boxes['translations']), 1, device=oe.device)
+        for t in touched:
+            if 0 <= int(t) < keep.shape[0]:
+                keep[int(t)] = 0
         return keep, boxes
 
     @torch.no_grad()
@@ -490,8 +505,8 @@ class Sg2BoxDiffModel(_SceneModel):
                                    dec_text_feat, dec_rel_feat, missing_nodes, layout_noise=None):
         added = [m + i for i, m in enumerate(missing_nodes)]
         oe, latent, latent_m = self._setup(enc_objs, enc_triples, enc_text_feat, enc_rel_feat, dec_objs, dec_triples,
-                                           dec_text_feat, dec_rel_feat, change_rows=list(missing_nodes),
-                                           added_rows=added, manip_pred_table='pred_embeddings_man_dc')
+                                           dec_text_feat, dec_rel_feat, change_rows=added,   # sic: nodes_added here,
+                                           added_rows=added, manip_pred_table='pred_embeddings_man_dc')   # EchoLayout.py:367-372
         if not self.replace_all_latent:
             latent = latent.clone()
             for t in sorted(added):

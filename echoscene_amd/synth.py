@@ -101,6 +101,21 @@ def collate_graphs(graphs):
     return torch.cat(objs), torch.cat(tris)
 
 
+def remove_nodes(objs, triples, nodes):
+    """The graph without ``nodes`` (editing tests: the encoder side of sample_with_additions sees the scene before the
+    objects were added).  Triples touching a removed node are dropped, the remaining indices are compacted.
+    Returns objs', triples', kept node indices, kept triple indices (to slice the CLIP features)."""
+    O = objs.numel()
+    drop = set(int(n) for n in nodes)
+    keep_idx = [i for i in range(O) if i not in drop]
+    remap = {old: new for new, old in enumerate(keep_idx)}
+    tri = triples.tolist()
+    keep_tri = [j for j, (s, p, o) in enumerate(tri) if s not in drop and o not in drop]
+    new_tri = [(remap[tri[j][0]], tri[j][1], remap[tri[j][2]]) for j in keep_tri]
+    return (objs[keep_idx], torch.tensor(new_tri, dtype=torch.int64).reshape(-1, 3),
+            torch.tensor(keep_idx, dtype=torch.int64), torch.tensor(keep_tri, dtype=torch.int64))
+
+
 def layout_noise(num_nodes, box_dim, n_steps, seed=7):
     """Pre-generated noise for loop A: row 0 is x_T, row 1+i is the draw consumed by
     loop iteration i (t = n_steps-1-i), matching the RNG call order of

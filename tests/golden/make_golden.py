@@ -141,7 +141,7 @@ def case_unet1d_tiny():
     save('unet1d_tiny', box=box, obj_embed=oe, triples=triples, t=t, eps=eps.squeeze(-1))
 
 
-def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise):
+def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=False):
     """Runs the reference's own DiffusionPoint / GaussianDiffusion.p_sample_loop_sg with an
     injected noise_fn; optionally truncated to the first n_steps iterations."""
     from model.networks.diffusion_layout.diffusion_ddpm import DiffusionPoint
@@ -160,7 +160,7 @@ def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise):
     gd = df.diffusion
     traj = []
     with torch.no_grad():
-        if n_steps == time_num:
+        if n_steps == time_num and not force_traj:
             x = df.gen_samples_sg((O, 8), 'cpu', oe, triples, condition=None, noise_fn=noise_fn,
                                   clip_denoised=False)
         else:
@@ -341,6 +341,59 @@ def case_concat():
         save('unet3d_concat_' + tag, **out)
 
 
+def case_layout_traj_full():
+    """VERDICT r1 #1 / SURVEY 8(c): the benchmarked layout configuration (BASELINE configs[1]): full width, O=32, the
+    reference's own p_sample_sg for all 1000 ancestral steps; the whole trajectory is stored ([1000,32,8] f32 = 1 MB)."""
+    net, kw = _unet1d(512, 1280)
+    fill(net, 'unet1d_full.')
+    noise = synth.layout_noise(32, 8, 1000, seed=7)
+    oe, triples, x, traj, _ = _layout_loop(net, kw, 32, 5, 1000, 1000, noise, force_traj=True)
+    save('layout_traj_full', obj_embed=oe, triples=triples, traj=torch.stack(traj), x_final=x)
+
+
+def case_shape_traj_full():
+    """VERDICT r1 #1 / SURVEY 8(c): the benchmarked shape configuration: model_channels 224, the reference's own
+    DDIMSampler for all 100 steps (eta 0) at O=4, then the reference VQ-VAE decode_no_quant at full size (8192 codes).
+    Stored: z after 1/2/5/10/20/50/100 steps, per-step mean|z| and rms for all steps, the VQ indices, the occupancy
+    sdf<0.02 as a packed bit mask (full 64^3 resolution) and a ::2 sub-sample of the SDF."""
+    import time
+    from model.networks.diffusion_shape.echo2shape import EchoToShape
+    from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+    net = _unet3d(224, 1280)
+    fill(net, 'unet3d_full.')
+    shim = _ShapeShim()
+    shim.df = shim.df_module = net
+    EchoToShape.register_schedule(shim, timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    shim.apply_model = lambda *a, **k: EchoToShape.apply_model(shim, *a, **k)
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    O = 4
+    objs, triples = synth.synthetic_graph(O, seed=18)
+    uc = rnd((O, 1, 1280), 182)
+    noise1 = synth.shape_noise(seed=7)
+    t0 = time.time()
+    with torch.no_grad():
+        z, inter = DDIMSampler(shim).sample(S=100, batch_size=O, shape=(3, 16, 16, 16), conditioning=uc,
+                                            x_T=noise1.repeat(O, 1, 1, 1, 1), verbose=False, log_every_t=1,
+                                            unconditional_guidance_scale=3., unconditional_conditioning=uc,
+                                            triplet=triples, eta=0.0)
+    print('100 DDIM steps: %.0f s' % (time.time() - t0))
+    xs = inter['x_inter']            # [x_T, after step 1, ..., after step 100]
+    assert len(xs) == 101 and torch.equal(xs[-1], z)
+    keep = (1, 2, 5, 10, 20, 50, 100)
+    vq = _vqvae(64, 8192)
+    fill(vq, 'vqvae_full.')
+    with torch.no_grad():
+        _, _, (_, _, idx) = vq.quantize(z, is_voxel=True)
+        sdf = vq.decode_no_quant(z)
+    occ = np.packbits((sdf.numpy() < 0.02).reshape(-1))
+    save('shape_traj_full', uc_s=uc, triples=triples, steps=np.array(keep),
+         z_steps=torch.stack([xs[k] for k in keep]),
+         z_mean_abs=np.array([float(x.abs().mean()) for x in xs]),
+         z_rms=np.array([float(x.pow(2).mean().sqrt()) for x in xs]),
+         vq_idx=idx.reshape(-1), occ_bits=occ, sdf_sub=sdf[:, :, ::2, ::2, ::2],
+         sdf_sum=sdf.double().sum(), sdf_abs=sdf.double().abs().sum())
+
+
 def _vqvae(ch, n_embed):
     from model.networks.vqvae_networks.network import VQVAE
     p = escfg.vqvae_conf(ch).model.params
@@ -408,6 +461,180 @@ def case_nomp():
                                             unconditional_guidance_scale=3., unconditional_conditioning=uc,
                                             triplet=triples, eta=0.0)
         save('unet3d_nomp_' + fam, x=x, uc_s=uc, c_s=c, triples=triples, t=t, eps=eps, z_final=z)
+
+
+class _SGDiffHarness:
+    """The reference's own SGDiff on CPU (SURVEY.md 8(c) recipe) with both loops' noise injected; shared by the
+    end-to-end and the editing cases."""
+
+    def __init__(self, typ, concat, O=8, graph_seed=9):
+        import tempfile
+        self.tmp = tempfile.mkdtemp(prefix='golden_e2e_')
+        vq = _vqvae(32, 64)
+        fill(vq, 'e2e.vqvae.')
+        vq_path = os.path.join(self.tmp, 'vq.pth')
+        torch.save(vq.state_dict(), vq_path)
+        opt = escfg.tiny_diff_opt(device='cpu', logs_dir=self.tmp, vq_ckpt=vq_path, concat=concat)
+        opt.misc.debug = 0
+        import model.networks.diffusion_shape.echo2shape as e2s
+        e2s.init_mesh_renderer = lambda **k: None
+        from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+        DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+        from model.SGDiff import SGDiff
+        m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
+                   gconv_pooling='avg', with_angles=True, clip=True, separated=False)
+        synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), seed=0, prefix='e2e.diff.')
+        if typ == 'echoscene':
+            fill(m.diff.ShapeDiff.df, 'e2e.shape_df.')
+            m.diff.ShapeDiff.ddim_steps = 4
+        m.eval()
+        self.m, self.typ, self.O = m, typ, O
+        self.objs, self.triples = synth.synthetic_graph(O, seed=graph_seed)
+        self.tf, self.rf = synth.synthetic_features(O, self.triples.shape[0], seed=graph_seed)
+        self.noise = synth.layout_noise(O, 8, 100, seed=7)
+        self.noise1 = synth.shape_noise(seed=7)
+
+    def call(self, fn):
+        """run fn() with the layout loop's noise_fn and rel2shape's torch.randn replaced by the seeded tensors"""
+        import model.networks.diffusion_layout.diffusion_ddpm as dd
+        calls = {'n': 0}
+        noise, noise1 = self.noise, self.noise1
+        _orig_gen = dd.DiffusionPoint.gen_samples_sg
+
+        def noise_fn(size, dtype, device):
+            i = calls['n']
+            calls['n'] += 1
+            return noise[i].clone()
+
+        def gen(self_, shape, device, obj_embed, triples=None, condition=None, noise_fn_=None, clip_denoised=True,
+                keep_running=False, **kw):
+            return _orig_gen(self_, shape, device, obj_embed, triples, condition=condition, noise_fn=noise_fn,
+                             clip_denoised=clip_denoised, keep_running=keep_running)
+        dd.DiffusionPoint.gen_samples_sg = gen
+        _randn = torch.randn
+
+        def randn(*a, **k):
+            size = k.get('size', a[0] if len(a) == 1 and not isinstance(a[0], int) else a)
+            if tuple(size) == (1, 3, 16, 16, 16):
+                return noise1.clone()
+            return _randn(*a, **k)
+        torch.randn = randn
+        try:
+            with torch.no_grad():
+                r = fn()
+        finally:
+            torch.randn = _randn
+            dd.DiffusionPoint.gen_samples_sg = _orig_gen
+        assert calls['n'] == 101, calls
+        return r
+
+
+def case_scene_edit():
+    """SURVEY 8(f1) / VERDICT r1 #2: the reference's own sample_boxes_and_shape_with_changes / _with_additions
+    (EchoScene.py:422-532, EchoLayout.py:309-401) for echoscene ('crossattn' and 'concat' families, gen_shape=True) and
+    echolayout, tiny widths, numpy RNG seeded right before each call (the 64-d change noise, EchoScene.py:428-435).
+    Two manipulated / two missing nodes so that the row bookkeeping (missing[i]+i, nodes_added vs missing_nodes) shows.
+    Also stored: the conditioning the manipulator produced (LayoutDiff.rel = relation_cond), because the shipped
+    'crossattn'+mp denoisers overwrite their context and would hide a wrong manipulator input."""
+    out = {}
+    manipulated = [5, 2]                 # unsorted on purpose
+    missing = [2, 4]                     # -> nodes_added = [2, 5]
+    for fam, typ, concat in (('sc', 'echoscene', False), ('cat', 'echoscene', True), ('lay', 'echolayout', False)):
+        h = _SGDiffHarness(typ, concat)
+        m = h.m
+        dec = (h.objs, h.triples, h.tf, h.rf)
+        # changes: same graph on both sides, two nodes get change noise
+        np.random.seed(123)
+        r = h.call(lambda: m.sample_boxes_and_shape_with_changes(*dec, *dec, manipulated, **(
+            {} if typ == 'echolayout' else {'gen_shape': True})))
+        keep, d = r
+        out['%s_chg_keep' % fam] = keep
+        out['%s_chg_rel' % fam] = m.diff.LayoutDiff.rel
+        for k, v in d.items():
+            if v is not None:
+                out['%s_chg_%s' % (fam, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+                if k == 'shapes':
+                    out['%s_chg_shapes_abs' % fam] = v.double().abs().sum()
+        # additions: the encoder sees the graph without the two missing nodes
+        added = [mi + i for i, mi in enumerate(missing)]
+        eo, et, keep_idx, keep_tri = synth.remove_nodes(h.objs, h.triples, added)
+        enc = (eo, et, h.tf[keep_idx], h.rf[keep_tri])
+        np.random.seed(321)
+        r = h.call(lambda: m.sample_boxes_and_shape_with_additions(*enc, *dec, missing, **(
+            {} if typ == 'echolayout' else {'gen_shape': True})))
+        if typ == 'echolayout':
+            d = r                       # sic: the facade drops ``keep`` (SGDiff.py:113-115)
+        else:
+            keep, d = r
+            out['%s_add_keep' % fam] = keep
+        out['%s_add_rel' % fam] = m.diff.LayoutDiff.rel
+        for k, v in d.items():
+            if v is not None:
+                out['%s_add_%s' % (fam, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+                if k == 'shapes':
+                    out['%s_add_shapes_abs' % fam] = v.double().abs().sum()
+        out.update(objs=h.objs, triples=h.triples)
+    out.update(manipulated=np.array(manipulated), missing=np.array(missing))
+    save('scene_edit_tiny', **out)
+
+
+def case_temb():
+    """a8: the reference's timestep_embedding (ldm_diffusion_util.py:174-194) for both schedules: t = 999..0 at dim 512
+    (layout) and the 100 DDIM timesteps at dim 224 (shape) -- pins the product's host tables bit for bit."""
+    from model.networks.diffusion_shape.ldm_diffusion_util import timestep_embedding
+    t1 = torch.arange(999, -1, -7, dtype=torch.int64)          # every 7th step (143 rows) keeps the fixture small
+    t2 = torch.from_numpy((np.arange(0, 1000, 10) + 1)[::-1].copy())
+    save('temb_tables', t_layout=t1, emb_layout=timestep_embedding(t1, 512, repeat_only=False),
+         t_shape=t2, emb_shape=timestep_embedding(t2, 224, repeat_only=False))
+
+
+def case_manifest():
+    """checkpoint-key manifest of the reference's own SGDiff built from its REAL shipped YAMLs
+    (config/full_mp.yaml, full.yaml, full_concat_mp.yaml -> echoscene; box.yaml, box_no_iou.yaml -> echolayout),
+    separated False/True: every state_dict key with its shape for the three checkpoint sections of SURVEY 3.3
+    ('diff' module keys, 'shape_df', 'vqvae').  Stored with the parsed config VALUES (numbers / names only, nested
+    df_cfg / vq_cfg resolved) so that the consumer can construct its mirror without the reference tree."""
+    import gzip
+    import json
+    import tempfile
+    import yaml
+    tmp = tempfile.mkdtemp(prefix='golden_manifest_')
+    vq = _vqvae(64, 8192)
+    vq_path = os.path.join(tmp, 'vq.pth')
+    torch.save(vq.state_dict(), vq_path)
+    import model.networks.diffusion_shape.echo2shape as e2s
+    e2s.init_mesh_renderer = lambda **k: None
+    from model.SGDiff import SGDiff
+    out = {}
+    for cfg_name, typ in (('full_mp', 'echoscene'), ('full', 'echoscene'), ('full_concat_mp', 'echoscene'),
+                          ('box', 'echolayout'), ('box_no_iou', 'echolayout')):
+        with open(os.path.join('..', 'config', cfg_name + '.yaml')) as f:
+            raw = yaml.safe_load(f)
+        plain = json.loads(json.dumps(raw))
+        if 'shape_branch' in plain:
+            for k in ('df_cfg', 'vq_cfg'):
+                with open(plain['shape_branch'][k]) as f:
+                    plain['shape_branch'][k] = yaml.safe_load(f)
+        for separated in (False, True):
+            opt = escfg.to_plain(json.loads(json.dumps(plain)))
+            opt.hyper.device = 'cpu'
+            opt.hyper.logs_dir = opt.hyper.results_dir = tmp
+            opt.hyper.isTrain = False
+            if 'shape_branch' in opt:
+                opt.shape_branch.vq_ckpt = vq_path
+            m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
+                       gconv_pooling='avg', with_angles=True, clip=True, separated=separated)
+            ent = {'diff': {k: list(v.shape) for k, v in torch.nn.Module.state_dict(m.diff).items()}}
+            if typ == 'echoscene':
+                ent['shape_df'] = {k: list(v.shape) for k, v in m.diff.ShapeDiff.df.state_dict().items()}
+                ent['vqvae'] = {k: list(v.shape) for k, v in m.diff.ShapeDiff.vqvae.state_dict().items()}
+            out['%s|%s|sep%d' % (cfg_name, typ, int(separated))] = ent
+            print(cfg_name, typ, separated, {k: len(v) for k, v in ent.items()})
+        out['config|' + cfg_name] = plain
+    path = os.path.join(HERE, 'key_manifest.json.gz')
+    with gzip.open(path, 'wt') as f:
+        json.dump(out, f, sort_keys=True)
+    print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
 
 
 def case_scene_e2e_concat():
@@ -493,7 +720,9 @@ def case_scene_e2e(concat=False):
 CASES = dict(box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
-             scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat)
+             scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,
+             layout_traj_full=case_layout_traj_full, shape_traj_full=case_shape_traj_full,
+             scene_edit=case_scene_edit, temb=case_temb, manifest=case_manifest)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -80,23 +80,98 @@ def test_sgdiff_api_end_to_end_vs_reference_golden(typ, concat):
         assert 'shapes' not in d
 
 
-def test_sgdiff_editing_variants_run():
-    """sample_boxes_and_shape_with_changes / _with_additions: return structure and the keep mask
-    (EchoScene.py:422-532); numerics of the loops are covered above (the loops are identical)."""
+def _build_sgdiff(typ, concat):
     from model.SGDiff import SGDiff
+    m = SGDiff(typ, escfg.tiny_diff_opt('cuda', concat=concat), synth.VOCAB, replace_latent=False, with_changes=True,
+               residual=True, gconv_pooling='avg', with_angles=True, clip=True, separated=False)
+    synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), prefix='e2e.diff.')
+    if typ == 'echoscene':
+        synth.seeded_fill_(m.diff.ShapeDiff.df, prefix='e2e.shape_df.')
+        synth.seeded_fill_(m.diff.ShapeDiff.vqvae, prefix='e2e.vqvae.')
+        m.diff.ShapeDiff.ddim_steps = 4
+    m.diff.optimizer_ini()
+    m.cuda()
+    m.eval()
+    return m
+
+
+def _check_sdf(got_full, ref_sub, what):
+    got, ref = got_full[:, :, ::4, ::4, ::4].cpu(), ref_sub
+    scale = ref.abs().max().item()
+    bad = ((got - ref).abs() > 2e-2 * scale).float().mean().item()
+    med = (got - ref).abs().median().item() / scale
+    print('%s SDF vs reference: %.3f%% of samples outside 2e-2, median rel err %.2e' % (what, 100 * bad, med))
+    assert bad < 0.03 and med < 2e-3
+
+
+@pytest.mark.parametrize('fam,typ,concat', [('lay', 'echolayout', False), ('sc', 'echoscene', False), ('cat', 'echoscene', True)])
+def test_sgdiff_editing_vs_reference_golden(fam, typ, concat):
+    """sample_boxes_and_shape_with_changes / _with_additions vs the reference's own calls
+    (EchoScene.py:422-532, EchoLayout.py:309-401; goldens: tests/golden/make_golden.py case_scene_edit): numpy RNG seeded on
+    both sides for the 64-d change noise, unsorted ``manipulated_nodes``, two missing nodes.  Compared: the keep mask
+    (type, shape, values exactly), the manipulator's conditioning (LayoutDiff.rel, 1e-4), boxes (1e-4), SDFs (fp16 path)."""
+    g = load_golden('scene_edit_tiny')
+    objs, triples = g['objs'], g['triples']
+    O = objs.shape[0]
+    tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
+    manipulated, missing = [int(v) for v in g['manipulated']], [int(v) for v in g['missing']]
+    m = _build_sgdiff(typ, concat)
+    kw = dict(layout_noise=synth.layout_noise(O, 8, 100, seed=7))
+    if typ == 'echoscene':
+        kw.update(shape_noise=synth.shape_noise(seed=7), gen_shape=True)
+    dec = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
+    # ---- changes
+    np.random.seed(123)
+    keep, d = m.sample_boxes_and_shape_with_changes(*dec, *dec, manipulated, **kw)
+    assert torch.is_tensor(keep) and keep.is_cuda and keep.dtype == torch.float32 and tuple(keep.shape) == (O, 1)
+    assert torch.equal(keep.cpu(), g[fam + '_chg_keep'])
+    assert _rel(m.diff.LayoutDiff.rel, g[fam + '_chg_rel']) < 1e-4
+    for k in ('sizes', 'translations', 'angles'):
+        assert _rel(d[k], g['%s_chg_%s' % (fam, k)]) < 1e-4, k
+    if typ == 'echoscene':
+        _check_sdf(d['shapes'], g[fam + '_chg_shapes'], fam + ' with_changes')
+    # ---- additions (the encoder sees the graph without the added nodes)
+    added = [mi + i for i, mi in enumerate(missing)]
+    eo, et, keep_idx, keep_tri = synth.remove_nodes(objs, triples, added)
+    enc = (eo.cuda(), et.cuda(), tf[keep_idx].cuda(), rf[keep_tri].cuda())
+    np.random.seed(321)
+    r = m.sample_boxes_and_shape_with_additions(*enc, *dec, missing, **kw)
+    rel = m.diff.LayoutDiff.rel.clone()
+    if typ == 'echolayout':
+        d = r                                   # the facade drops keep here (SGDiff.py:113-115)
+        assert isinstance(d, dict)
+    else:
+        keep, d = r
+        assert torch.is_tensor(keep) and keep.is_cuda and tuple(keep.shape) == (O, 1)
+        assert torch.equal(keep.cpu(), g[fam + '_add_keep'])
+    assert _rel(rel, g[fam + '_add_rel']) < 1e-4
+    for k in ('sizes', 'translations', 'angles'):
+        assert _rel(d[k], g['%s_add_%s' % (fam, k)]) < 1e-4, k
+    if typ == 'echoscene':
+        _check_sdf(d['shapes'], g[fam + '_add_shapes'], fam + ' with_additions')
+    else:
+        # the model-level call returns keep as a python list (EchoLayout.py:394-401)
+        k2, _ = m.diff.sampleBoxes_with_additions(*enc, *dec, missing, layout_noise=kw['layout_noise'])
+        assert isinstance(k2, list) and k2 == [0 if i in added else 1 for i in range(O)]
+
+
+def test_sgdiff_editing_index_edge_cases():
+    """duplicates and out-of-range entries of manipulated_nodes behave like the reference's ``i in list`` tests:
+    one draw per distinct in-range node, the others are ignored (no IndexError)."""
     O = 6
     objs, triples = synth.synthetic_graph(O, seed=4)
     tf, rf = synth.synthetic_features(O, triples.shape[0], seed=4)
-    m = SGDiff('echolayout', escfg.tiny_diff_opt('cuda'), synth.VOCAB, residual=True, with_angles=True)
-    synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), prefix='edit.')
-    m.cuda().eval()
-    keep, d = m.sample_boxes_and_shape_with_changes(objs, triples, tf, rf, objs, triples, tf, rf, [1, 3])
-    assert keep == [1, 0, 1, 0, 1, 1] and tuple(d['translations'].shape) == (O, 3)
-    # additions: decoder graph has one more node (inserted at index 2)
-    objs2, triples2 = synth.synthetic_graph(O + 1, seed=5)
-    tf2, rf2 = synth.synthetic_features(O + 1, triples2.shape[0], seed=5)
-    d2 = m.sample_boxes_and_shape_with_additions(objs, triples, tf, rf, objs2, triples2, tf2, rf2, [2])
-    assert tuple(d2['sizes'].shape) == (O + 1, 3) and torch.isfinite(d2['sizes']).all()
+    m = _build_sgdiff('echolayout', False)
+    a = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
+    noise = synth.layout_noise(O, 8, 100, seed=3)
+    np.random.seed(5)
+    keep1, d1 = m.sample_boxes_and_shape_with_changes(*a, *a, [3, 1], layout_noise=noise)
+    rel1 = m.diff.LayoutDiff.rel.clone()
+    np.random.seed(5)
+    keep2, d2 = m.sample_boxes_and_shape_with_changes(*a, *a, [1, 3, 3, 17], layout_noise=noise)
+    assert torch.equal(keep1, keep2) and keep1.flatten().tolist() == [1, 0, 1, 0, 1, 1]
+    assert torch.equal(rel1, m.diff.LayoutDiff.rel)
+    assert torch.equal(d1['sizes'], d2['sizes'])
 
 
 def test_box_postprocess_matches_reference_helpers():
@@ -227,3 +302,42 @@ def test_full_size_permutation_equivariance():
     assert _rel(s1, s0[perm]) < 1e-5, 'objects are not independent / indexing depends on the labelling'
     s2 = sden.eps(xs, uc, triples, iteration=40).cpu()
     assert torch.equal(s0, s2), 'the full-size step is not deterministic'
+
+
+def test_chamfer_exact_lattice_fixtures():
+    """SURVEY 8(f4) pin: integer-exact fixtures (tests/golden/make_chamfer_lattice.py) -- every
+    dx*dx+dy*dy+dz*dz is exact in fp32, so dist / idx / grads must be BIT-identical to the int64 ground truth, including
+    the first-minimum rule across the reference's 512-point tile seam (chamfer.cu:14-16,118-131) and this kernel's
+    2048-point LDS tile; n, m are not multiples of 256 / 2048."""
+    import ctypes as C
+    import os
+    from conftest import GOLDEN
+    from echoscene_amd import hip
+    from echoscene_amd.chamfer import chamferDist
+    d = np.load(os.path.join(GOLDEN, 'chamfer_lattice.npz'))
+    sc = float(d['scale'])
+    for tag in 'abc':
+        x1 = torch.from_numpy(d[tag + '_xyz1'].astype(np.float32) * sc).cuda()
+        x2 = torch.from_numpy(d[tag + '_xyz2'].astype(np.float32) * sc).cuda()
+        B, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+        d1, d2 = torch.zeros(B, n, device='cuda'), torch.zeros(B, m, device='cuda')
+        i1 = torch.zeros(B, n, dtype=torch.int32, device='cuda')
+        i2 = torch.zeros(B, m, dtype=torch.int32, device='cuda')
+        p = lambda t: C.c_void_p(t.data_ptr())
+        hip.check(hip.lib().es_chamfer_forward(p(x1), p(x2), B, n, m, p(d1), p(i1), p(d2), p(i2), hip.current_stream()),
+                  'es_chamfer_forward')
+        torch.cuda.synchronize()
+        assert torch.equal(d1.cpu(), torch.from_numpy(d[tag + '_dist1'])), tag
+        assert torch.equal(d2.cpu(), torch.from_numpy(d[tag + '_dist2'])), tag
+        assert torch.equal(i1.cpu(), torch.from_numpy(d[tag + '_idx1'])), tag
+        assert torch.equal(i2.cpu(), torch.from_numpy(d[tag + '_idx2'])), tag
+        if tag == 'a':
+            assert int(i1[0, 3]) == 100          # the planted duplicate: first copy wins over 511/512/700/2047/2048/2100
+        # backward through the autograd wrapper the reference's consistency_check.py uses
+        a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        o1, o2 = chamferDist()(a, b)
+        g1 = torch.from_numpy(d[tag + '_g1'].astype(np.float32) * 0.25).cuda()
+        g2 = torch.from_numpy(d[tag + '_g2'].astype(np.float32) * 0.25).cuda()
+        torch.autograd.backward([o1, o2], [g1, g2])
+        assert torch.equal(a.grad.cpu(), torch.from_numpy(d[tag + '_grad1'])), tag
+        assert torch.equal(b.grad.cpu(), torch.from_numpy(d[tag + '_grad2'])), tag
