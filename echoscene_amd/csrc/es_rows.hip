@@ -128,14 +128,12 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, i
 // 16-lane row group (GroupNorm group = gs/4 adjacent lanes; LayerNorm = all 16), the normalised tile is written to LDS
 // once.  No dependent LDS walks, no per-element global loads of the affine (gamma/beta sit in LDS).
 template <int PRO>
-__device__ __forceinline__ void stage_norm(const es_linear_args& a, Smem& sm, int m0, int tid) {
+__device__ __forceinline__ void stage_norm_load(const es_linear_args& a, int m0, int tid, f4 (&v)[16]) {
     const int r = tid >> 4, cl = tid & 15;
     const int m = m0 + r;
-    const bool row_ok = m < a.M;
-    const int mc = row_ok ? m : a.M - 1;
-    const int K = a.K, nu = K >> 6;                      // K % 64 == 0 (host-checked)
+    const int mc = m < a.M ? m : a.M - 1;
+    const int nu = a.K >> 6;                             // K % 64 == 0 (host-checked)
     const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0;
-    f4 v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         if (u < nu) {
@@ -145,6 +143,14 @@ __device__ __forceinline__ void stage_norm(const es_linear_args& a, Smem& sm, in
             v[u] = *(const f4*)(seg_base(sg) + (long)mc * sg.ld + (c0 - cb) + 4 * cl);
         }
     }
+}
+
+template <int PRO>
+__device__ __forceinline__ void stage_norm(const es_linear_args& a, Smem& sm, int m0, int tid, f4 (&v)[16]) {
+    const int r = tid >> 4, cl = tid & 15;
+    const int m = m0 + r;
+    const bool row_ok = m < a.M;
+    const int K = a.K, nu = K >> 6;
     if (PRO == ES_PRO_LN) {
         float s = 0.f;
 #pragma unroll
@@ -210,6 +216,22 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, q = lane >> 4;
 
+    // (0) Epilogue operands (bias, residuals, the affine of the second GroupNorm output) depend only on the output
+    // coordinates: issued FIRST so that their latency overlaps the weight stream, the staging and the product instead
+    // of adding one more dependent L2/HBM round trip after the reduction (launches here are ~5 us of pure latency).
+    const int ml = tid >> 4, nl = tid & 15;              // 32 x 16 outputs, one per thread
+    const int m_e = m0 + ml, n_e = nt * 16 + nl;
+    const bool geglu = a.act == ES_ACT_GEGLU;
+    const float* bias = a.bias ? a.bias + (long)bz * a.N : nullptr;
+    const bool ok_e = m_e < a.M && n_e < a.N;
+    const int nres = geglu ? nt * 8 + nl : n_e;          // column of the residual / output
+    const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
+    float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f, e_g2 = 0.f, e_b2 = 0.f;
+    if (bias && n_e < a.N) e_bias = bias[n_e];
+    if (a.res && ok_res) e_res = a.res[(long)m_e * a.res_ld + nres];
+    if (a.res2 && ok_res) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
+    if (a.out2 && ok_e) { e_g2 = a.gn2_gamma[n_e]; e_b2 = a.gn2_beta[n_e]; }
+
     for (int kc0 = 0; kc0 < Kp; kc0 += KC) {
         const int kc = min(KC, Kp - kc0);
         const int nkb = kc >> 4;
@@ -223,12 +245,19 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
         // (2) stage the activation chunk with its prologue applied
         if (kc0 > 0) __syncthreads();
         if (PRO == ES_PRO_GN || PRO == ES_PRO_GN_SILU || PRO == ES_PRO_LN) {
-            for (int c = tid * 4; c < a.K; c += NTHREAD * 4) {       // affine -> LDS (K <= KC, single chunk)
-                *(f4*)&sm.gb[0][c] = *(const f4*)&a.gamma[c];
-                *(f4*)&sm.gb[1][c] = *(const f4*)&a.beta[c];
-            }
+            // affine (one float4 per thread: K <= KC, single chunk) and the activation rows are fetched in ONE round
+            // trip; the affine goes through LDS because every row needs all of it
+            const int c = tid * 4;
+            f4 gv = {0.f, 0.f, 0.f, 0.f};
+            const bool isg = c < a.K, isb = !isg && c - NTHREAD * 2 >= 0 && c - NTHREAD * 2 < a.K;
+            if (isg) gv = *(const f4*)&a.gamma[c];
+            else if (isb) gv = *(const f4*)&a.beta[c - NTHREAD * 2];
+            f4 v[16];
+            stage_norm_load<PRO>(a, m0, tid, v);
+            if (isg) *(f4*)&sm.gb[0][c] = gv;
+            else if (isb) *(f4*)&sm.gb[1][c - NTHREAD * 2] = gv;
             __syncthreads();
-            stage_norm<PRO>(a, sm, m0, tid);
+            stage_norm<PRO>(a, sm, m0, tid, v);
         } else {
             stage_chunk<PRO>(a, sm, m0, kc0, kc, tid);
         }
@@ -254,35 +283,32 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
     *(f4*)&red[(wave * 2 + 0) * 256 + lane * 4] = acc0;
     *(f4*)&red[(wave * 2 + 1) * 256 + lane * 4] = acc1;
     __syncthreads();
-    const int ml = tid >> 4, nl = tid & 15;              // 32 x 16 outputs
     const int mt = ml >> 4, row = ml & 15;
     // D layout of mfma 16x16: lane = (row>>2)*16 + col holds D[row][col] in register row&3
     const int off = mt * 256 + ((row >> 2) * 16 + nl) * 4 + (row & 3);
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) s += red[w * 512 + off];
-    const int m = m0 + ml, n = nt * 16 + nl;
-    const float* bias = a.bias ? a.bias + (long)bz * a.N : nullptr;
+    const int m = m_e, n = n_e;
     float* out = a.out + (long)bz * a.out_bstride;
-    if (a.act == ES_ACT_GEGLU) {
+    if (geglu) {
         // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt + nl, lane nl + 8 its gate
-        float sb = s + ((bias && n < a.N) ? bias[n] : 0.f);
+        float sb = s + e_bias;
         const float gate = __shfl_xor(sb, 8, 16);
-        if (m < a.M && nl < 8 && n < a.N) {
-            const int no = nt * 8 + nl;
+        if (ok_res) {
             float v = sb * es_gelu(gate);
-            if (a.res) v += a.res[(long)m * a.res_ld + no];
-            out[(long)m * a.out_ld + no] = v;
+            if (a.res) v += e_res;
+            out[(long)m * a.out_ld + nres] = v;
         }
         return;
     }
-    const bool ok = m < a.M && n < a.N;
+    const bool ok = ok_e;
     if (ok) {
-        if (bias) s += bias[n];
+        if (bias) s += e_bias;
         if (a.act == ES_ACT_RELU) s = fmaxf(s, 0.f);
         else if (a.act == ES_ACT_SILU) s = es_silu(s);
-        if (a.res) s += a.res[(long)m * a.res_ld + n];
-        if (a.res2) s += a.res2[(long)m * a.res2_ld + n];
+        if (a.res) s += e_res;
+        if (a.res2) s += e_res2;
         out[(long)m * a.out_ld + n] = s;
     }
     if (a.out2) {
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a)
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
         if (ok) {
-            float y = d * rsqrtf(sq * (1.0f / 16.0f) + a.gn2_eps) * a.gn2_gamma[n] + a.gn2_beta[n];
+            float y = d * rsqrtf(sq * (1.0f / 16.0f) + a.gn2_eps) * e_g2 + e_b2;
             if (a.gn2_silu) y = es_silu(y);
             a.out2[(long)m * a.out2_ld + n] = y;
         }

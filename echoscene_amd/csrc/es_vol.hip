@@ -301,14 +301,17 @@ struct ConvGeom {
 // ---------------------------------------------------------------------------------------------
 // LOWREG: k_conv_ws runs 12 waves per CU (168 VGPRs): the 7 float4 items per lane are processed one at a time instead of
 // all in flight (fully unrolled the epilogue spilled 100 registers there and cost more than the K loop gained).
-template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
+// EPI_: -1 = a.epilogue decides at run time (general kernels); ES_EPI_NONE / ES_EPI_GEGLU = compiled for that epilogue only
+// (k_conv_ws: with both paths in one function the register allocator spilled 150-250 dwords at the 168-register cap).
+template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false, int EPI_ = -1>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
 __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvGeom& g, f4 (&acc)[BM_ / (NW_ / 2) / 16][7],
                                               char* smem, long M, long m0, int n0, int wave, int lane, int S, int bz,
                                               int ncdhw) {
     constexpr int WROWS = BM_ / (NW_ / 2), MI = WROWS / 16;
+    const bool geglu_epi = EPI_ < 0 ? a.epilogue == ES_EPI_GEGLU : EPI_ == ES_EPI_GEGLU;
     if constexpr (!ACTIVE) {
         __syncthreads();
-        if (a.epilogue == ES_EPI_GEGLU)
+        if (geglu_epi)
             for (int i = 0; i < MI; ++i) { __syncthreads(); __syncthreads(); }
         return;
     }
@@ -318,7 +321,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
     const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
     float* part = S > 1 ? (float*)a.workspace + (long)bz * M * a.N : nullptr;   // [S][M][N] partial sums
-    if (a.epilogue == ES_EPI_GEGLU) {
+    if (geglu_epi) {
         // wave wn = 0 holds 112 value columns, its partner wn = 1 the matching 112 gate columns (tile-interleaved
         // weight packing): both transpose their slab into LDS, the value wave combines and stores f16 [M, 4C].
         const float* vslab = (const float*)smem + (wave & ~1) * (16 * 116);    // value slab (wn = 0 wave of the pair)
@@ -352,6 +355,90 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
         }
         return;
     }
+    if constexpr (LOWREG) {
+        // The host routes a launch to k_conv_ws only when ws_epilogue_ok() holds (vector-aligned N / leading dimensions,
+        // channels-last output, 32-bit element offsets: a uniform 64-bit base + one VGPR keeps the address registers out
+        // of the 168-register budget); there is no scalar fall-back in this instantiation.
+        {
+            // k_conv_ws (168-register cap).  The first version walked the 7 float4 items of a slab one at a time and paid
+            // one dependent bias / per-object vector / RESIDUAL load latency per item: 28 serial round trips per tile,
+            // ~25 us of the ~30 us fixed cost of a 256-row tile (fit over Cin, profiles/r01_notes.md).  Now a lane owns ONE
+            // column quad for the whole tile (56 of 64 lanes: 2 rows x 28 quads per pass, 8 passes per 16-row slab), so
+            // bias and the per-object vector are loaded once, and the 8 residual quads of a slab are fetched together,
+            // those of slab i+1 while slab i is combined and stored (from the second slab on, when the accumulators
+            // already released leave the registers for it).
+            const int vsh = g.lw + g.lh + g.ld;
+            const int c4 = lane % 28, rsub = lane / 28;
+            const int n = n0 + wn * 112 + c4 * 4;
+            const bool n_ok = lane < 56 && n < a.N;
+            const long mw0 = m0 + wm * WROWS;
+            const int rows_left = (int)((M - mw0) < (long)WROWS ? (M - mw0 > 0 ? M - mw0 : 0) : (long)WROWS);   // valid rows of this wave
+            const bool one_obj = rows_left > 0 && (mw0 >> vsh) == ((mw0 + rows_left - 1) >> vsh);
+            f4 bias4 = {0.f, 0.f, 0.f, 0.f}, rv4 = {0.f, 0.f, 0.f, 0.f};
+            if (!part && a.bias && n_ok) bias4 = *(const f4*)&a.bias[n];
+            if (!part && a.rowvec && n_ok && one_obj) rv4 = *(const f4*)&a.rowvec[(mw0 >> vsh) * a.rowvec_ld + n];
+            const bool use_res = a.res && !part;
+            const unsigned ld = (unsigned)a.out_ld;
+            const unsigned off0 = (unsigned)(mw0 + rsub) * ld + (unsigned)n;            // element offset of (row rsub, column n)
+            const unsigned poff0 = (unsigned)(mw0 + rsub) * (unsigned)a.N + (unsigned)n;
+            auto write_slab = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
+            };
+            auto load_res = [&](int i, f4 (&rr)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int r = i * 16 + rsub + 2 * t;
+                    rr[t] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (use_res && n_ok && r < rows_left) rr[t] = *(const f4*)&a.res[off0 + (unsigned)(i * 16 + 2 * t) * ld];
+                }
+            };
+            auto combine = [&](int i, const f4 (&rr)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = rsub + 2 * t, r = i * 16 + row;
+                    if (n_ok && r < rows_left) {
+                        f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
+                        if (part) {
+                            *(f4*)&part[poff0 + (unsigned)(i * 16 + 2 * t) * (unsigned)a.N] = v;
+                        } else {
+                            const unsigned off = off0 + (unsigned)(i * 16 + 2 * t) * ld;
+                            if (a.bias) v += bias4;
+                            if (a.rowvec) v += one_obj ? rv4 : *(const f4*)&a.rowvec[((mw0 + r) >> vsh) * a.rowvec_ld + n];
+                            if (a.res) v += rr[t];
+                            if (a.out_f32) *(f4*)&a.out_f32[off] = v;
+                            if (a.out_f16) {
+                                h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                *(h4*)((_Float16*)a.out_f16 + off) = hv;
+                            }
+                        }
+                    }
+                }
+            };
+            f4 rbuf[2][8];
+            write_slab(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_res(0, rbuf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): own slab writes visible to own wave
+                __builtin_amdgcn_wave_barrier();
+                if (i >= 1 && i + 1 < MI) load_res(i + 1, rbuf[(i + 1) & 1]);       // two slabs already released
+                __builtin_amdgcn_sched_barrier(0);
+                combine(i, rbuf[i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();
+                if (i + 1 < MI) write_slab(i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0 && MI > 1) load_res(1, rbuf[1]);                            // behind slab 1's LDS writes
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         if (vec_ok) {
@@ -362,7 +449,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
             __builtin_amdgcn_wave_barrier();
             // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
-#pragma unroll LOWREG ? 1 : 7
+#pragma unroll 7
             for (int t = 0; t < 7; ++t) {
                 const int idx = lane + 64 * t;
                 const int row = idx / 28, c4 = idx - row * 28;
@@ -989,7 +1076,7 @@ __device__ __forceinline__ void ws_pipe_step(f4 (&acc)[MI][7], h8 (&af)[MI], h8 
     }
 }
 
-template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0, bool PIPE_ = false>
+template <int BM_, int NC_, int NP_, bool UP_ = false, int ABL = 0, bool PIPE_ = false, int EPI_ = ES_EPI_NONE>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
     // PIPE_: barrier ks means 'tile ks+1 has landed'; the consumers then refill each fragment register from tile ks+1 as
     // soon as its last MFMA of tile ks is issued (row 0 first, then column by column), so no wave waits for LDS after a
@@ -1169,7 +1256,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
             }
         }
         f4 dummy[MI][7];
-        conv_epilogue<BM_, NC_, false, true>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        conv_epilogue<BM_, NC_, false, true, EPI_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
         return;
     }
 
@@ -1213,7 +1300,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
             tb += t1 - t0; tc += t2 - t1;
         }
         const unsigned long long te0 = __builtin_readcyclecounter();
-        conv_epilogue<BM_, NC_, true, true>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
         const unsigned long long te1 = __builtin_readcyclecounter();
         if (lane == 0 && bx == 0 && by == 0 && bz == 0)
             printf("consumer %d: per step barrier %.0f  reads+MFMA issue %.0f ; K loop total %.0f  epilogue %.0f ticks\n", wave,
@@ -1230,7 +1317,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     }
     }
     }
-    conv_epilogue<BM_, NC_, true, true>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+    conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1598,6 +1685,7 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 0, false, ES_EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
@@ -1680,7 +1768,10 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         if (done) { ES_CHECK_HIP(hipGetLastError()); return 0; }
 #endif
         static const char* ws_env = getenv("ES_CONV_WS");         // A/B switch: 0 = no warp specialisation
-        const bool ws = !(ws_env && atoi(ws_env) == 0);
+        // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
+        const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
+                                    M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
+        const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
 #ifdef ES_CONV_ABLATION
         static const char* wabl_env = getenv("ES_WS_ABL");
         const int wabl = wabl_env ? atoi(wabl_env) : 0;
@@ -1698,7 +1789,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         static const char* pipe_env = getenv("ES_CONV_PIPE");     // A/B switch: 1 = refill-after-last-use consumer schedule
         const bool pipe = pipe_env && atoi(pipe_env) == 1;        // (measured equal: the kernel is clock/power limited)
         constexpr int LDSP = 4 * (256 * BK * 2 + BNP * BK * 2);
-        if (lean && ws && pipe && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
+        const bool geglu = a->epilogue == ES_EPI_GEGLU;
+        if (lean && ws && geglu && !upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+        else if (lean && ws && pipe && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
         else if (lean && ws && pipe) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
         else if (lean && ws && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         else if (lean && ws) hipLaunchKernelGGL((k_conv_ws<256, 8, 4>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
@@ -1708,7 +1801,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
         static const char* ws128_env = getenv("ES_CONV_WS128");   // A/B switch: 1 = producer/consumer waves for 128-row tiles too
-        const bool ws128 = ws128_env && atoi(ws128_env) == 1;
+        const bool ws128 = ws128_env && atoi(ws128_env) == 1 && a->epilogue == ES_EPI_NONE && !ncdhw && a->N % 4 == 0 &&
+                           a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) && M * (long)a->out_ld < (1L << 30) &&
+                           M * (long)a->N < (1L << 30);
         if (lean && ws128 && upm) hipLaunchKernelGGL((k_conv_ws<128, 4, 2, true>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
         else if (lean && ws128) hipLaunchKernelGGL((k_conv_ws<128, 4, 2>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
         else if (lean && upm) hipLaunchKernelGGL((k_conv_lean<128, 4, 0, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
