@@ -1321,6 +1321,267 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_ws3: k_conv_ws with the activation (A) tile SHARED by the three kw taps of a (channel chunk, kd, kh) group.
+//
+// Why (profiles/r02_notes.md): GRBM_GUI_ACTIVE / wall shows the chip at 1.97 GHz under this kernel on random data (2.4 GHz on
+// zeros) and a constant ~690k cycles per launch; SQ_VALU_MFMA_BUSY is 49 % of them (= exactly 16 cycles per MFMA): the K
+// step costs ~1500 cycles for 896 cycles of MFMA, so the loop is NOT matrix-pipe (or clock) bound.  Round 1's ablation
+// already held the answer: the LDS-DMA alone needs as long as the MFMAs alone (0.465 us per K step each), and two thirds of it is
+// the A tile -- 256 separate 64-byte row segments per K step, priced per cache line touched (2.2x a contiguous B piece).
+// With K ordered (chunk, kd, kh, kw) the three kw taps read the SAME 256 voxels shifted by one voxel = one row of the LDS
+// tile (tiles start on a W boundary), so the tile is fetched once per group and the consumers read their fragments at row
+// offset kw; the rows whose neighbour lies across the W boundary are zeroed in registers (one v_cndmask per fragment register,
+// two of three steps).  A traffic / 3, total LDS-DMA pieces per K step 8 -> 5.3 per producer wave.
+//
+//   LDS: 3 B slots (tile ks % 3) + 3 A slots (group j % 3), 96 KB as before.
+//   producer, step ks: wait(own pieces of B(ks) -- A(group of ks) is older) -> barrier -> issue A(j) if its first step is
+//     3 (groups of one tap: 2) steps ahead, then B(ks+2).
+//   consumer, step ks: barrier -> fragments (A at row offset kw) -> boundary select -> 28 MFMAs.
+// Groups of ONE tap (1x1x1 / linear launches, the fused 1x1 skip phase, strided / up-sampling modes whose taps are not a row
+// shift) take the same code with kw = 0.  Split-K cuts at group boundaries.
+// ---------------------------------------------------------------------------------------------
+template <int N_> __device__ __forceinline__ void ws3_wait(int n) {
+    if (n >= 2 * N_) wait_vmcnt<2 * N_>(); else if (n >= N_) wait_vmcnt<N_>(); else wait_vmcnt<0>();
+}
+
+template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE>
+__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws3(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    constexpr int WROWS = BM_ / (NC_ / 2);
+    constexpr int MI = WROWS / 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2;
+    constexpr int B_BASE = 0, A_BASE = 3 * B_BYTES;               // B slots first: row -1 of A slot 0 stays inside the allocation
+    constexpr int APIECES = BM_ / 16, BPIECES = BNP / 16;          // 1 KiB pieces per tile
+    constexpr int NA = APIECES / NP_, NB = BPIECES / NP_;          // per producer wave
+    static_assert(APIECES % NP_ == 0 && BPIECES % NP_ == 0 && NA == NB, "pieces must divide evenly over the producer waves");
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_mfma)
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = L % (int)gridDim.x;
+        const int t = L / (int)gridDim.x;
+        by = t % (int)gridDim.y;
+        bz = t / (int)gridDim.y;
+    }
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
+    // ---- K decomposition: phase 0 = the conv (kch0 chunks x ntap taps, groups of gsz0 steps), phase 1 = fused 1x1 skip ----
+    const int kch0 = a.Cin >> 5, kch2 = a.a2 ? (a.Cin2 >> 5) : 0;
+    const int ntap = a.taps;
+    const bool kw3 = !UP_ && a.mode == ES_CONV_SAME && ntap == 27 && g.W <= BM_;
+    const int gsz0 = kw3 ? 3 : 1;
+    const int gpc = ntap / gsz0;                 // groups per channel chunk (phase 0)
+    const int G0 = kch0 * gpc, GT = G0 + kch2;
+    const int nks0 = kch0 * ntap;
+    const int S = gridDim.z;
+    const int gb = (int)((long)GT * bz / S), ge = (int)((long)GT * (bz + 1) / S);
+    const int ks_begin = gb <= G0 ? gb * gsz0 : nks0 + (gb - G0);
+    const int ks_end = ge <= G0 ? ge * gsz0 : nks0 + (ge - G0);
+    const int nloc = ks_end - ks_begin, ngl = ge - gb;
+
+    if (wave >= NC_) {
+        // =============================== producer ===============================
+        const int pw = wave - NC_;
+        int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
+        bool a_ok[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (pw + NP_ * j) * 64 + lane;    // 16-B slot of the A tile: row = p >> 2, physical chunk = p & 3
+            const int row = p >> 2;
+            a_lc[j] = (p & 3) ^ f_swz(row);
+            const long m = m0 + row;
+            a_ok[j] = m < M;
+            const long mm = a_ok[j] ? m : 0;
+            a_w[j] = (int)(mm & (g.W - 1));
+            a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
+            a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+            a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
+        }
+        // ---- A cursor: next group to fetch ----
+        int A_phase = gb >= G0 && kch2 ? 1 : 0;
+        int A_c = A_phase ? gb - G0 : gb / gpc;
+        int A_t = A_phase ? 0 : (gb % gpc) * gsz0 + (gsz0 == 3 ? 1 : 0);     // tap whose shift addresses the group (kw = 0)
+        int A_first = 0, jA = 0;                                               // local first K step / local index of that group
+        unsigned voff[NA], msk[NA];
+        int upm[NA][3], upp[NA][3];
+        int dtab = 0;
+        __amdgpu_buffer_rsrc_t rA, rB;
+        auto set_phase_A = [&]() __attribute__((always_inline)) {
+            const _Float16* Ag = (const _Float16*)(A_phase ? a.a2 : a.a);
+            const int Cin = A_phase ? a.Cin2 : a.Cin;
+            const bool down = !A_phase && (a.mode == ES_CONV_DOWN_HW || a.mode == ES_CONV_DOWN_DHW);
+            const bool downd = !A_phase && a.mode == ES_CONV_DOWN_DHW;
+            const int Dsrc = downd ? 2 * g.D : g.D;
+            const int Hi = A_phase ? g.H : g.Hi, Wi = A_phase ? g.W : g.Wi;
+            const int nt = A_phase ? 1 : ntap;
+            const bool updhw = UP_ && a.mode == ES_CONV_UP_DHW;
+            const int Di = updhw ? g.D / 2 : g.D;
+            const int bias = nt == 27 ? ((Hi + 1) * Wi + 1) * Cin * 2 : 0;      // bytes; largest negative tap shift
+            rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ag - bias), (short)0, (int)OOB, 0x00020000);
+            {
+                const int t = lane < 27 ? lane : 13;
+                const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+                dtab = nt == 27 ? ((kd * Hi + kh) * Wi + kw) * Cin * 2 + bias : 0;
+                if (UP_) dtab = nt == 27 ? (updhw ? 0 : kd * Hi * Wi * Cin * 2) + bias : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int ch = down ? 2 * a_h[j] : a_h[j];
+                const int cw = down ? 2 * a_w[j] : a_w[j];
+                const int cd = downd ? 2 * a_d[j] : a_d[j];
+                voff[j] = (unsigned)(((((long)a_o[j] * Dsrc + cd) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+                if (UP_) {
+                    const int sd = updhw ? a_d[j] >> 1 : a_d[j];
+                    voff[j] = (unsigned)(((((long)a_o[j] * Di + sd) * Hi + (a_h[j] >> 1)) * Wi + (a_w[j] >> 1)) * Cin * 2 + a_lc[j] * 16);
+                    const int SD = Hi * Wi * Cin * 2, SH = Wi * Cin * 2, SW = Cin * 2;
+                    upm[j][0] = (updhw && !(a_d[j] & 1)) ? -SD : 0; upp[j][0] = (updhw && (a_d[j] & 1)) ? SD : 0;
+                    upm[j][1] = !(a_h[j] & 1) ? -SH : 0;            upp[j][1] = (a_h[j] & 1) ? SH : 0;
+                    upm[j][2] = !(a_w[j] & 1) ? -SW : 0;            upp[j][2] = (a_w[j] & 1) ? SW : 0;
+                }
+                unsigned m = 0;
+                if (nt == 1) {
+                    m = a_ok[j] ? 1u : 0u;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 27; ++t) {
+                        const int id = cd + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
+                        const bool ok = a_ok[j] && id >= 0 && id < Dsrc && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
+                        m |= (ok ? 1u : 0u) << t;
+                    }
+                }
+                msk[j] = m;
+            }
+        };
+        set_phase_A();
+        auto issue_A = [&]() __attribute__((always_inline)) {
+            const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, A_t) + (unsigned)A_c * 64u;
+            const unsigned sbit = 1u << A_t;
+            int ukd = 0, ukh = 0, ukw = 0;
+            if (UP_) { ukd = A_t / 9 - 1; ukh = (A_t / 3) % 3 - 1; ukw = A_t % 3 - 1; }
+            char* dst = smem + A_BASE + (jA % 3) * A_BYTES;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                unsigned vs = voff[j];
+                if (UP_) {
+                    vs += (unsigned)(ukd < 0 ? upm[j][0] : ukd > 0 ? upp[j][0] : 0);
+                    vs += (unsigned)(ukh < 0 ? upm[j][1] : ukh > 0 ? upp[j][1] : 0);
+                    vs += (unsigned)(ukw < 0 ? upm[j][2] : ukw > 0 ? upp[j][2] : 0);
+                }
+                const unsigned vo = (msk[j] & sbit) ? vs : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (pw + NP_ * j) * 1024), 16, (int)vo, (int)sA, 0, 0);
+            }
+            ++jA;
+            if (!A_phase) {
+                A_first += gsz0;
+                A_t += gsz0;
+                if (A_t >= ntap) {
+                    A_t = gsz0 == 3 ? 1 : 0;
+                    if (++A_c == kch0 && kch2) { A_phase = 1; A_c = 0; A_t = 0; set_phase_A(); }
+                }
+            } else {
+                A_first += 1;
+                ++A_c;
+            }
+        };
+        // ---- B cursor: next weight tile ----
+        int B_phase = ks_begin >= nks0 && kch2 ? 1 : 0;
+        unsigned B_off = (unsigned)(B_phase ? ks_begin - nks0 : ks_begin) * (unsigned)B_BYTES;
+        int B_left = B_phase ? 0x7fffffff : nks0 - ks_begin;                  // steps until the phase switch
+        auto set_phase_B = [&]() __attribute__((always_inline)) {
+            const _Float16* Wg = (const _Float16*)(B_phase ? a.w2 : a.w);
+            const long nks_ph = B_phase ? (long)kch2 : (long)nks0;
+            rB = __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + ((long)by * nks_ph) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+        };
+        set_phase_B();
+        const unsigned voffB = (unsigned)lane * 16u;
+        auto issue_B = [&](int kb) __attribute__((always_inline)) {
+            char* dst = smem + B_BASE + (kb % 3) * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = pw + NP_ * j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + q * 1024), 16, (int)voffB, (int)(B_off + (unsigned)q * 1024u), 0, 0);
+            }
+            B_off += (unsigned)B_BYTES;
+            if (--B_left == 0 && kch2) { B_phase = 1; B_off = 0; B_left = 0x7fffffff; set_phase_B(); }
+        };
+        // groups whose fetch step lies before step 0, then the first two weight tiles
+        while (jA < ngl && A_first - ((!A_phase && gsz0 == 3) ? 3 : 2) < 0) issue_A();
+        if (nloc > 0) issue_B(0);
+        if (nloc > 1) issue_B(1);
+        int nprev = nloc > 1 ? NB : 0;            // pieces this wave issued after those of tile 0
+        for (int ks = 0; ks < nloc; ++ks) {
+            ws3_wait<NB>(nprev);                 // own pieces of B(ks) and of everything older (A of this group) have landed
+            __builtin_amdgcn_s_barrier();        // tile ks visible; the consumers are done with step ks - 1
+            nprev = 0;
+            if (jA < ngl && A_first - ((!A_phase && gsz0 == 3) ? 3 : 2) <= ks) { issue_A(); nprev += NA; }
+            if (ks + 2 < nloc) { issue_B(ks + 2); nprev += NB; }
+        }
+        f4 dummy[MI][7];
+        conv_epilogue<BM_, NC_, false, true, EPI_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        return;
+    }
+
+    // =============================== consumer ===============================
+    const int wm = wave >> 1, wn = wave & 1;
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+    const int row0 = wm * WROWS + i16;
+    const int fragA0 = A_BASE + row0 * 64 + ((q ^ f_swz(row0)) << 4);
+    const int fragAm = A_BASE + (row0 - 1) * 64 + ((q ^ f_swz(row0 - 1)) << 4);
+    const int fragAp = A_BASE + (row0 + 1) * 64 + ((q ^ f_swz(row0 + 1)) << 4);
+    const int fragB = B_BASE + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    unsigned zlm = 0, zrm = 0;                   // bit i: this lane's row of MFMA row tile i sits on the left / right W boundary
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int w = (row0 + i * 16) & (g.W - 1);
+        zlm |= (w == 0 ? 1u : 0u) << i;
+        zrm |= (w == g.W - 1 ? 1u : 0u) << i;
+    }
+    int gsz = (gb >= G0) ? 1 : gsz0, gleft = (gb >= G0) ? 0x7fffffff : G0 - gb;
+    int r = 0;
+    int sB = 0, sA = 0;                          // byte offsets of the current B / A slot
+    for (int ks = 0; ks < nloc; ++ks) {
+        __builtin_amdgcn_s_barrier();
+        const int kw = gsz == 3 ? r - 1 : 0;
+        const int va = (kw < 0 ? fragAm : kw > 0 ? fragAp : fragA0) + sA;
+        const int vb = fragB + sB;
+        h8 af[MI], bfr[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bfr[j] = *(const h8*)(smem + vb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(smem + va + i * 1024);
+        if (kw != 0) {
+            const unsigned zm = kw < 0 ? zlm : zrm;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if ((zm >> i) & 1u) af[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        sB = sB == 2 * B_BYTES ? 0 : sB + B_BYTES;
+        if (++r == gsz) {
+            r = 0;
+            sA = sA == 2 * A_BYTES ? 0 : sA + A_BYTES;
+            if (--gleft == 0) gsz = 1;
+        }
+    }
+    conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Self-attention, flash style, fp16 MFMA.  One workgroup = 64 query rows of one (batch, head);
 // 4 waves x 16 rows.  K tile [64 keys][dp], V tile transposed [dp][64 keys] in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -1686,6 +1947,9 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 0, false, ES_EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws3<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256 + 64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws3<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256 + 64));
+        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws3<256, 8, 4, false, ES_EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256 + 64));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * BK * 2 + BNP * BK * 2)));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
@@ -1740,7 +2004,10 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const bool lean = (!upm || (!a->a2 && a->taps == 27)) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
                       !(old_env && atoi(old_env) == 1) && dbgf == 0;
     ES_REQUIRE(lean || a->mode != ES_CONV_DOWN_DHW, "es_conv_mfma_f16: DOWN_DHW needs the lean kernel (tensor < 2 GiB, ES_CONV_OLD unset)");
-    if (wg256 >= 256 && (S == 1 || split256) && !no256) {
+    static const char* f256_env = getenv("ES_CONV_FORCE256");  // test switch: 256-row tiles (the ws kernels) for any problem size
+    const bool force256 = f256_env && atoi(f256_env) == 1;
+    if (force256 && a->splitk < 0 && !split256) S = 1;
+    if ((wg256 >= 256 || force256) && (S == 1 || split256) && !no256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
 #ifdef ES_CONV_ABLATION      /* tools/microbench_conv.py: build with -DES_CONV_ABLATION, select with ES_LEAN_ABL=<bits> */
         static const char* abl_env = getenv("ES_LEAN_ABL");
@@ -1790,7 +2057,14 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         const bool pipe = pipe_env && atoi(pipe_env) == 1;        // (measured equal: the kernel is clock/power limited)
         constexpr int LDSP = 4 * (256 * BK * 2 + BNP * BK * 2);
         const bool geglu = a->epilogue == ES_EPI_GEGLU;
-        if (lean && ws && geglu && !upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+        static const char* kw3_env = getenv("ES_CONV_KW3");       // A/B switch: 0 = k_conv_ws (one A tile per tap)
+        const bool kw3 = !(kw3_env && atoi(kw3_env) == 0);
+        constexpr int LDS3 = LDS256 + 64;                         // + the row past the last A slot a shifted read may touch
+        if (lean && ws && kw3 && (!geglu || !upm)) {
+            if (geglu) hipLaunchKernelGGL((k_conv_ws3<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS3, st, *a, g, ncdhw);
+            else if (upm) hipLaunchKernelGGL((k_conv_ws3<256, 8, 4, true>), grid, dim3(768), LDS3, st, *a, g, ncdhw);
+            else hipLaunchKernelGGL((k_conv_ws3<256, 8, 4>), grid, dim3(768), LDS3, st, *a, g, ncdhw);
+        } else if (lean && ws && geglu && !upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         else if (lean && ws && pipe && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
         else if (lean && ws && pipe) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, 0, true>), grid, dim3(768), LDSP, st, *a, g, ncdhw);
         else if (lean && ws && upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);

@@ -138,6 +138,11 @@ EXPORTS = {
                                      C.c_void_p, C.c_void_p]),
     'es_chamfer_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'es_marching_cubes_workspace': (C.c_size_t, [C.c_int, C.c_int]),
+    'es_marching_cubes_count': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    'es_marching_cubes_emit': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'es_plan_create': (C.c_void_p, [C.POINTER(Op), C.c_int]),
     'es_plan_destroy': (None, [C.c_void_p]),
     'es_plan_num_ops': (C.c_int, [C.c_void_p]),

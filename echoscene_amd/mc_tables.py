@@ -1,0 +1,126 @@
+"""Marching-cubes case table (Lorensen & Cline 1987) generated from its defining rule.
+
+The reference turns the decoded SDFs into meshes with the third-party PyMCubes (``mcubes.marching_cubes(sdf_i, level)``,
+model/diff_utils/util_3d.py:194-236, level 0.02; the package is not in this image and the reference pins no version).  PyMCubes
+walks the grid with the classic cube numbering (corners v0..v7, edges e0..e11 as below, also used by P. Bourke's
+"Polygonising a scalar field") and a 256-row triangle table.  That table is data of a third party and is NOT copied here:
+the rows are derived at import time from the rule that defines them --
+
+  * a cube corner is "inside" when its value is < level (bit m of the case index);
+  * every cube edge whose endpoints differ carries one vertex;
+  * on every cube face the vertices are joined by segments; a face with four vertices (two inside corners on a diagonal) is
+    resolved by cutting off each INSIDE corner (consistent on both cubes sharing the face -> watertight surfaces);
+  * the segments chain into closed loops; each loop is oriented so that its normal points to the inside (< level) side -- the
+    orientation of the published table's first row, {0, 8, 3} -- and is fanned into triangles from the first vertex whose
+    diagonals do not lie inside a cube face.
+
+Vertex positions (and therefore the vertex multiset of a mesh) do not depend on the table at all; the triangle count per case
+depends only on the loops; only the choice of diagonals inside a loop is a free convention.
+"""
+import numpy as np
+
+CORNERS = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], dtype=np.int64)
+EDGES = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+# faces as corner cycles
+FACES = [(0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
+# cube edge e -> (corner offset of the grid point that owns it, axis)
+EDGE_OWNER = []
+for _a, _b in EDGES:
+    _lo = np.minimum(CORNERS[_a], CORNERS[_b])
+    EDGE_OWNER.append((int(_lo[0]), int(_lo[1]), int(_lo[2]), int(np.nonzero(CORNERS[_a] != CORNERS[_b])[0][0])))
+
+
+def _edge_of(a, b):
+    for e, (p, q) in enumerate(EDGES):
+        if (p, q) == (a, b) or (p, q) == (b, a):
+            return e
+    raise KeyError((a, b))
+
+
+def _case_loops(case):
+    inside = [(case >> m) & 1 for m in range(8)]
+    nbr = {}                                            # edge -> the (two) edges it is joined to
+
+    def join(e0, e1):
+        nbr.setdefault(e0, []).append(e1)
+        nbr.setdefault(e1, []).append(e0)
+
+    for f in FACES:
+        cross = [i for i in range(4) if inside[f[i]] != inside[f[(i + 1) % 4]]]      # face edge i = (f[i], f[i+1])
+        fe = [_edge_of(f[i], f[(i + 1) % 4]) for i in range(4)]
+        if len(cross) == 2:
+            join(fe[cross[0]], fe[cross[1]])
+        elif len(cross) == 4:
+            for i in range(4):                          # cut off every inside corner: its two face edges are joined
+                if inside[f[i]]:
+                    join(fe[(i - 1) % 4], fe[i])
+    loops, seen = [], set()
+    for e0 in sorted(nbr):
+        if e0 in seen:
+            continue
+        loop, prev, cur = [e0], None, e0
+        seen.add(e0)
+        while True:
+            a, b = nbr[cur]
+            nxt = a if a != prev else b
+            if len(loop) > 1 and nxt == e0:
+                break
+            if nxt in seen and nxt != e0:               # two-edge degenerate cycle cannot occur on a cube
+                raise AssertionError(case)
+            loop.append(nxt)
+            seen.add(nxt)
+            prev, cur = cur, nxt
+            if len(loop) > 12:
+                raise AssertionError(case)
+        loops.append(loop)
+    return loops, inside
+
+
+def _midpoint(e):
+    a, b = EDGES[e]
+    return (CORNERS[a] + CORNERS[b]) / 2.0
+
+
+def build_tri_table():
+    """int8 [256, 16]: up to five triangles (edge indices), -1 padded."""
+    tab = -np.ones((256, 16), dtype=np.int8)
+    for case in range(256):
+        loops, inside = _case_loops(case)
+        tris = []
+        for loop in loops:
+            # orientation: the first segment loop[0] -> loop[1] lies on one cube face with outward normal n.  The polygon
+            # continues into the cube (-n side), and its normal N must point to the inside (< level) side, i.e. have a
+            # positive component along u = (inside endpoint of loop[0]) - (vertex on loop[0]).  For a counter-clockwise
+            # loop about N the polygon interior is on the side N x d of the segment d, so N x d ~ -n  <=>  N ~ n x d ... the
+            # sign test below is exact (all three vectors are axis aligned or lie in the face plane).
+            e0, e1 = loop[0], loop[1]
+            f = next(fc for fc in FACES if {e0, e1} <= {_edge_of(fc[i], fc[(i + 1) % 4]) for i in range(4)})
+            n = CORNERS[list(f)].mean(0) - 0.5
+            d = _midpoint(e1) - _midpoint(e0)
+            a_in = EDGES[e0][0] if inside[EDGES[e0][0]] else EDGES[e0][1]
+            u = CORNERS[a_in] - _midpoint(e0)
+            if np.dot(np.cross(n, d), u) < 0:
+                loop = loop[::-1]
+            # fan apex: avoid diagonals that join two vertices of the same cube face (they would lie in that face and
+            # coincide with the neighbour cell's diagonal -> an edge shared by four triangles); first minimiser wins
+            n_l = len(loop)
+            face_sets = [{_edge_of(fc[i], fc[(i + 1) % 4]) for i in range(4)} for fc in FACES]
+            cost = [sum(any({loop[a], loop[(a + i) % n_l]} <= fs for fs in face_sets) for i in range(2, n_l - 1))
+                    for a in range(n_l)]
+            a0 = int(np.argmin(cost))
+            loop = loop[a0:] + loop[:a0]
+            for i in range(1, n_l - 1):
+                tris += [loop[0], loop[i], loop[i + 1]]
+        assert len(tris) <= 15, (case, tris)
+        tab[case, :len(tris)] = tris
+    return tab
+
+
+_TRI = None
+
+
+def tri_table():
+    global _TRI
+    if _TRI is None:
+        _TRI = build_tri_table()
+    return _TRI

@@ -299,6 +299,24 @@ int es_chamfer_backward(const float* xyz1, const float* xyz2, int batch, int n, 
                         const float* graddist2, const int32_t* idx1, const int32_t* idx2, float* gradxyz1,
                         float* gradxyz2, es_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Marching cubes (SDF -> indexed triangle mesh): what eval_3dfront.py does right after the sampling path through
+ * sdf_to_mesh (model/diff_utils/util_3d.py:194-236: mcubes.marching_cubes(sdf_i, level), PyMCubes, level 0.02).
+ * sdf [O, n, n, n] fp32, array axes (i, j, k) = vertex coordinates (x, y, z) in grid units; inside = value < level.
+ * tri_table: int8 [256][16] device table (echoscene_amd/mc_tables.py).  Two calls, because the mesh sizes are data dependent:
+ *   count: counts[2*o] = vertices, counts[2*o+1] = triangles of object o (device int32[2*O]); `workspace`
+ *          (es_marching_cubes_workspace bytes) carries the block scans to
+ *   emit : verts [sum V, 3] fp32 and faces [sum T, 3] int32 (vertex ids local to the object), object o written at row
+ *          vert_offset[o] / tri_offset[o] (device int64[O]).  Vertices are shared between cubes (one per crossing
+ *          grid edge), output order = grid order (deterministic, no atomics).
+ * ---------------------------------------------------------------------------------------- */
+size_t es_marching_cubes_workspace(int O, int n);
+int es_marching_cubes_count(const float* sdf, int O, int n, float level, const int8_t* tri_table, void* workspace,
+                            int32_t* counts, es_stream stream);
+int es_marching_cubes_emit(const float* sdf, int O, int n, float level, const int8_t* tri_table, void* workspace,
+                           const int64_t* vert_offset, const int64_t* tri_offset, float* verts, int32_t* faces,
+                           es_stream stream);
+
 /* library-wide one-off device allocations (zero page); call once outside stream capture */
 int es_init(void);
 /* The sampling loops.  `step` is the device scalar the plan's ops read; it is set to first_step,

@@ -333,19 +333,61 @@ def test_conv_down_dhw(dev):
     assert _rel(out, _cl(ref)) < 1e-4
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'}, {'ES_CONV_PIPE': '1'}])
+@pytest.mark.parametrize('O,dims,Cin,N,skipC', [(16, (16, 16, 16), 64, 224, 0), (32, (16, 8, 8), 96, 448, 32),
+                                                 (33, (8, 4, 4), 64, 224, 0)])
+def test_conv_ws3_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
+    """The dominant kernel on launches shaped like the shipped ones (>= 256 tiles of 256 rows, W = 16 / 8 / 4, ragged last
+    tile, bias + per-object vector + fp32 residual + both outputs, fused 1x1 skip phase) against F.conv3d on the same
+    fp16-rounded operands: the A tile shared by the three kw taps (k_conv_ws3) must reproduce every tap incl. the W
+    boundary zeroing."""
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    D, H, W = dims
+    V = D * H * W
+    if O * V < 256 * 256:
+        import os
+        if os.environ.get('ES_CONV_FORCE256') != '1':
+            pytest.skip('needs ES_CONV_FORCE256=1 to reach the 256-row kernels at this size (run by test_conv_alternate_kernels)')
+    x = _rnd((O, Cin) + dims, 1).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3), 2) / np.sqrt(Cin * 27)).half().float()
+    bias = _rnd((N,), 3)
+    rowv = _rnd((O, N), 4)
+    res = _rnd((O * V, N), 5)
+    ref = F.conv3d(x, wt, bias, padding=1)
+    b = Builder(dev)
+    skip = None
+    if skipC:
+        xs = _rnd((O, skipC) + dims, 6).half().float()
+        ws = (_rnd((N, skipC), 7) / np.sqrt(skipC)).half().float()
+        ref = ref + F.conv3d(xs, ws[:, :, None, None, None])
+        skip = (b.dev(_cl(xs), torch.float16), PackedConv(ws, None, dev))
+    ref = _cl(ref) + rowv.repeat_interleave(V, 0) + res
+    out = b.buf(O * V, N, zero=True)
+    out16 = b.buf(O * V, N, dtype=torch.float16, zero=True)
+    b.conv(b.dev(_cl(x), torch.float16), PackedConv(wt, bias, dev), O, dims, rowvec=View(b.dev(rowv)), res=b.dev(res),
+           out_f32=out, out_f16=out16, skip=skip)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-4
+    assert _rel(out16, ref) < 2e-3
+
+
+@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'},
+                                 {'ES_CONV_FORCE256': '1'}, {'ES_CONV_FORCE256': '1', 'ES_CONV_KW3': '0'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
     non-specialised k_conv_lean for 256-row tiles, the opt-in producer/consumer 128-row variant) must give the same
     results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
-    (the switches are read once per process)."""
+    (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
+    1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
+    tiles: k_conv_ws3 (A tile shared by the three kw taps) by default, k_conv_ws with ES_CONV_KW3=0."""
     import os
     import subprocess
     import sys
     e = dict(os.environ)
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae'
+    sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae or test_conv_ws3'
     if 'ES_CONV_OLD' not in env:                 # the general kernel has no stride-2-in-depth mode (raises, by design)
         sel += ' or test_conv_down_dhw'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
