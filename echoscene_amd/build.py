@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libechoscene_hip.so')
 SOURCES = ['es_runtime.hip', 'es_rows.hip', 'es_vol.hip', 'es_chamfer.hip', 'es_mc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
-    os.environ.get('ES_BUILD_FLAGS', '').split()      # e.g. -DES_CONV_ABLATION for tools/microbench_conv.py
+    os.environ.get('ES_BUILD_FLAGS', '').split()
 
 
 def _stale():

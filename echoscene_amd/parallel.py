@@ -14,21 +14,27 @@ import torch
 
 
 def partition(num_objects, world, rank):
-    """Contiguous block partition with equal padded block size.  Returns (lo, hi, block)."""
+    """Contiguous block partition with equal padded block size.  Returns (lo, hi, block).  With more ranks than blocks the
+    trailing ranks get lo == hi (no objects): they run no voxel work but must still join every collective."""
     block = (num_objects + world - 1) // world
     lo = min(rank * block, num_objects)
     hi = min(lo + block, num_objects)
     return lo, hi, block
 
 
-def all_gather_rows(local, num_rows, world, group=None):
-    """All-gather row blocks of a [rows_local, C] tensor into [num_rows, C] (blocks padded to equal size)."""
+def all_gather_rows(local, num_rows, world, group=None, out=None):
+    """All-gather row blocks of a [rows_local, C] tensor into [num_rows, C] (blocks padded to equal size).
+    ``out`` ([world * block, C], pre-allocated) with ``local`` already a full zero-padded block makes the call
+    allocation-free (the per-step echo exchange)."""
     import torch.distributed as dist
     block = (num_rows + world - 1) // world
     C = local.shape[1:]
-    pad = torch.zeros((block,) + tuple(C), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    out = torch.empty((world * block,) + tuple(C), dtype=local.dtype, device=local.device)
+    if out is not None and local.shape[0] == block:
+        pad = local
+    else:
+        pad = torch.zeros((block,) + tuple(C), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        out = torch.empty((world * block,) + tuple(C), dtype=local.dtype, device=local.device)
     if local.is_cuda and dist.get_backend(group) != 'nccl':
         # test-only path (several ranks sharing one GPU under gloo): stage through host memory
         outc = torch.empty(out.shape, dtype=out.dtype)
@@ -46,10 +52,17 @@ def sharded_ddim_loop(backend, num_objects, n_steps, world, group=None):
         codes_local(i)        -> [O_local, 64] conv-pool codes of this rank's current latents
         step(i, codes_all)    -> advance this rank's latents by DDIM iteration i given all objects' codes
         latents_local()       -> [O_local, C, D, H, W]
-    Returns the full latents [O, C, D, H, W] on every rank."""
+        gather_buffers()      -> optional: pre-allocated (send block, receive buffer) of the exchange
+    Per step on the HIP path: one captured graph (stem), one RCCL all-gather of [block, 64] floats per rank, one captured
+    graph (everything else) -- no allocation, no torch op in between.  Returns the full latents [O, C, D, H, W] on every
+    rank.  A rank without objects (more ranks than objects) still joins every collective."""
+    bufs = backend.gather_buffers() if (world > 1 and hasattr(backend, 'gather_buffers')) else None
     for i in range(n_steps):
         cl = backend.codes_local(i)
-        ca = all_gather_rows(cl, num_objects, world, group) if world > 1 else cl
+        if world > 1:
+            ca = all_gather_rows(cl, num_objects, world, group, out=bufs[1] if bufs else None)
+        else:
+            ca = cl
         backend.step(i, ca)
     zl = backend.latents_local()
     return all_gather_rows(zl, num_objects, world, group) if world > 1 else zl

@@ -447,8 +447,13 @@ class UNet1DWeights:
                                         sd[tb + '.attn1.to_out.0.bias'], device)
                 d['o2'] = (sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_out.0.bias'])
                 d['ff1'] = PackedLinear(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
-                d['ff2'] = P(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
-                d['proj_out'] = P(name + '.proj_out.weight', name + '.proj_out.bias')
+                # x_out = proj_out(ff2(g) + b2 + t2) + x_in is linear in (g, t2): ONE op over the K-concatenation [g | t2] with
+                # [Wpo.Wff2 | Wpo] (folded in fp64) -- one dependent launch less per transformer block
+                Wpo = centre_tap(sd[name + '.proj_out.weight']).double()
+                Wf2 = sd[tb + '.ff.net.2.weight'].double()
+                d['ff2po'] = PackedLinear(torch.cat([Wpo @ Wf2, Wpo], 1).float(),
+                                          (Wpo @ sd[tb + '.ff.net.2.bias'].double() + sd[name + '.proj_out.bias'].double()).float(),
+                                          device)
                 self.ca[name] = (len(ca_v), it[1])
                 ca_v.append(sd[tb + '.attn2.to_v.weight'])
             elif kind == 'down':
@@ -619,11 +624,8 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
                 gl = View(b.buf(O, 4 * C))                    # GEGLU applied in the ff1 epilogue
                 b.linear([seg(t2)], d['ff1'], O, gl, prologue=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5)
-                t3 = View(b.buf(O, C))
-                b.linear([seg(gl)], d['ff2'], O, t3, res=t2)
-                b.tags[name + '.transformer_blocks.0:ff'] = t3
                 o = View(b.buf(O, C))
-                b.linear([seg(t3)], d['proj_out'], O, o, res=xin, gn_out=gn_side(name, C))
+                b.linear([seg(gl), seg(t2)], d['ff2po'], O, o, res=xin, gn_out=gn_side(name, C))
                 h_segs, hC = [o], C
             elif kind in ('down', 'up'):
                 o = View(b.buf(O, hC))

@@ -162,6 +162,7 @@ class VolBuilderMixin:
         a.out_f16 = out_f16.data_ptr() if out_f16 is not None else None
         a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
         a.epilogue = epilogue
+        a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
         if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
@@ -190,6 +191,7 @@ class VolBuilderMixin:
         a.stats = st.data_ptr()
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
+        a.O_hint = int(getattr(self, 'o_hint', 0) or 0)
         self.keep += [gamma, beta]
         return self._push(hip.OP_GN, 'gn', a)
 
@@ -228,7 +230,8 @@ class VolBuilderMixin:
         return self._push(hip.OP_STEM, 'stem', a)
 
 
-def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None, c_dev=None, tables=None):
+def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16), lo=0, hi=None, c_dev=None, tables=None,
+                     gather_rows=None):
     """One UNet3DModel.forward: x f32 [Ol,3,D,H,W] (NCDHW) -> eps_out f32 [Ol,3,D,H,W].
 
     'concat' family (``w.concat``; c_dev f32 [Ol, V] = this rank's rows of c_s): the network input is the 5-channel
@@ -275,11 +278,21 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
         if Ol == Ofull:
             b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
             b.codes_local = None
+            b.codes_all = None
         else:
-            b.codes_local = b.buf(Ol, gdim)
+            # sharded: this rank's codes go to the (zero-padded, equal-size) send block of the echo all-gather; the gathered
+            # [world * block, 64] buffer is copied into the GCN input by the first op after the exchange -- no torch op and
+            # no allocation between the two graph launches of a step
+            nrows = gather_rows or Ofull
+            blk = max(Ol, getattr(b, 'shard_block', Ol))
+            b.codes_local = b.buf(blk, gdim, zero=True)
             b.linear([seg(View(code512))], w.stem_lin, Ol, View(b.codes_local))
+            b.codes_all = b.buf(max(nrows, Ofull), gdim, zero=True)
         b.split = len(b.ops)                       # <- all-gather point of the multi-GPU loop
         b.code_cols = (ucw, gdim)
+        if b.codes_all is not None:
+            b.copy(objbuf.data_ptr() + ucw * 4, b.codes_all.data_ptr(), gdim * 4, rows=Ofull, dst_pitch=Dobj * 4,
+                   src_pitch=gdim * 4)
         if w.enable_t_emb:
             if tables is not None:
                 b.rowsel(tables['t_lin'], step, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim), rows=O)
@@ -315,7 +328,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
         # ('concat').  The per-object row buffers hold the local objects only; nothing is exchanged between ranks.
         assert c_dev is not None, 'shape denoiser without message passing needs the conditioning c_s'
         O, row0, objbuf = Ol, 0, None
-        b.split, b.codes_local, b.code_cols = 0, None, None
+        b.split, b.codes_local, b.code_cols, b.codes_all = 0, None, None, None
         emb_ld = w.emb_all.N
         if tables is not None:
             emb_all = b.buf(1, w.emb_all.N)

@@ -113,7 +113,7 @@ class ShapeDenoiser:
     step as one hipGraph; world > 1 splits each step at the echo all-gather."""
 
     def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
-                 group=None):
+                 group=None, deterministic=True):
         self.device = device or torch.device('cuda')
         self.df = df
         net = df.diffusion_net
@@ -128,6 +128,9 @@ class ShapeDenoiser:
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
         self.rank, self.world, self.group = rank, world, group
+        # deterministic: a shard reproduces the unsharded run bit for bit (split-K factors and GroupNorm partial-sum tiles are
+        # chosen from the GLOBAL object count); False lets every rank tune them to its local share (faster at few objects)
+        self.deterministic = deterministic
         self.tables = time_tables(self.w, self.temb, self.w.shape_t, self.device)
         self._plans = {}
 
@@ -145,19 +148,32 @@ class ShapeDenoiser:
         key = (O, triples.shape[0], hash(triples.detach().cpu().numpy().tobytes()))
         st = self._plans.get(key)
         if st is None:
-            lo, hi, _ = partition(O, self.world, self.rank)
+            lo, hi, block = partition(O, self.world, self.rank)
+            if hi == lo:
+                # more ranks than object blocks: this rank owns nothing.  It runs no kernels but keeps joining the
+                # collectives of the loop (a rank that raised here would leave the others blocked in the all-gather).
+                z = lambda *sh: torch.zeros(*sh, device=self.device)
+                st = dict(empty=True, x=z(0, *self.z_shape), eps=z(0, *self.z_shape), lo=lo, hi=hi, O=O,
+                          codes_local=z(block, 64), codes_all=z(block * self.world, 64), objbuf=None, cdev=None, xc=None)
+                self._plans = {key: st}
+                return st
             g = GraphIndex(triples, O, self.device)
             b = Builder(self.device)
+            b.shard_block = block
+            if self.world > 1 and self.deterministic:
+                b.o_hint = O       # split-K / partial-sum tiling as in the unsharded run -> bit-identical latents
             x = b.buf(hi - lo, *self.z_shape)
             eps = b.buf(hi - lo, *self.z_shape)
             step = b.buf(1, dtype=torch.int32, zero=True)
             ucd = b.dev(uc)
             objbuf = emit_unet3d_step(b, self.w, g, x, ucd, self.temb, step, eps, dims=self.z_shape[1:], lo=lo, hi=hi,
-                                      c_dev=c[lo:hi] if need_c else None, tables=self.tables)
+                                      c_dev=c[lo:hi] if need_c else None, tables=self.tables,
+                                      gather_rows=block * self.world)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
             st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
-                      codes_local=b.codes_local, code_cols=b.code_cols, xc=getattr(b, 'xc', None),
+                      codes_local=b.codes_local, codes_all=getattr(b, 'codes_all', None), code_cols=b.code_cols,
+                      xc=getattr(b, 'xc', None),
                       cdev=getattr(b, 'cdev', None))
 
             def sub(ops):
@@ -171,6 +187,8 @@ class ShapeDenoiser:
                 st['stem_plan'] = sub(b.ops[:b.split])
                 st['main_plan'] = sub(b.ops[b.split:])
             self._plans = {key: st}
+        if st.get('empty'):
+            return st
         if st['objbuf'] is not None:
             st['objbuf'][:, :st['ucw']].copy_(uc.to(self.device))
         if concat:
@@ -182,13 +200,22 @@ class ShapeDenoiser:
     # -- shard backend protocol of parallel.sharded_ddim_loop ------------------------------------------------
     def codes_local(self, i):
         st = self._cur
-        st['stem_plan'].run()
+        if not st.get('empty'):
+            st['stem_plan'].sample(st['step'], int(i), 1, use_graph=self._use_graph)     # captured like the main part
         return st['codes_local']
+
+    def gather_buffers(self):
+        """(send block [block, 64], receive buffer [world * block, 64]) of the per-step echo all-gather: pre-allocated, the
+        stem plan writes the first, the main plan's first op reads the second."""
+        st = self._cur
+        return st['codes_local'], st['codes_all']
 
     def step(self, i, codes_all):
         st = self._cur
-        c0, cw = st['code_cols']
-        st['objbuf'][:, c0:c0 + cw].copy_(codes_all)
+        if st.get('empty'):
+            return
+        if codes_all.data_ptr() != st['codes_all'].data_ptr():      # single-process emulations hand in their own tensor
+            st['codes_all'][:codes_all.shape[0]].copy_(codes_all)
         st['main_plan'].sample(st['step'], int(i), 1, use_graph=self._use_graph)
 
     def latents_local(self):
@@ -211,6 +238,12 @@ class ShapeDenoiser:
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
         st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
+        if st.get('empty'):
+            from .parallel import all_gather_rows, sharded_ddim_loop as loop
+            if not self.w.mp:
+                return all_gather_rows(st['x'], st['O'], self.world, self.group).clone()
+            self._cur, self._use_graph = st, use_graph
+            return loop(self, st['O'], n_steps, self.world, self.group).clone()
         if self.world == 1 or not self.w.mp:
             st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
             if self.world == 1:

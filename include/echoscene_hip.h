@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 1
+#define ES_ABI_VERSION 2
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -173,6 +173,9 @@ typedef struct es_conv_args {
                                  cannot fill 256 CUs otherwise).  -1: let the library choose.            */
     int32_t out_ld;           /* leading dimension of both outputs and of res (>= N);
                                  out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
+    int32_t O_hint;           /* 0, or the object count of the WHOLE problem when this launch is one shard of it
+                                 (multi-GPU object sharding): the split-K factor is then chosen as for the whole problem,
+                                 so that the fp32 partial sums -- and the result -- are bit-identical to the unsharded run */
     int32_t epilogue;         /* ES_EPI_NONE, or ES_EPI_GEGLU: GEGLU (attention.py:39-46) fused into the FeedForward
                                  proj: the weight rows are packed tile-interleaved (per 224-column tile: 112 value
                                  rows c0..c0+111, then their 112 gate rows 4C+c0..), N = 8C, the only output is
@@ -197,6 +200,7 @@ typedef struct es_gn_args {
     float* stats;                    /* scratch, O*ceil(V/8)*groups*2 floats (per-tile partials)  */
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
+    int32_t O_hint;                  /* 0, or the object count of the whole problem (sharding): partial-sum tiling as unsharded */
 } es_gn_args;
 /* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
  * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats, apply. */

@@ -252,36 +252,36 @@ def test_unet3d_full_eps_vs_reference_golden(dev):
     assert e < 2e-2
 
 
-def test_two_object_shards_equal_unsharded(dev):
-    """The multi-GPU decomposition on one GPU: two shards (world=2) stepped with a simulated all-gather give the
-    latents of the unsharded run.  Every kernel treats objects independently; tile sizes / K splits adapt to the
-    LOCAL object count, so the fp32 summation order (not the arithmetic) may differ; a last-bit fp32 difference can
-    flip the fp16 rounding of an MFMA operand (2^-11 relative on that element), hence 2e-3 (measured 5e-4 after 4 steps)."""
-    g = load_golden('ddim_tiny')
-    noise1 = synth.shape_noise(seed=7)
-    z_ref = _shape(dev, 32, 64, 'unet3d_tiny.', 4).sample(g['uc_s'], g['triples'], noise1)
+@pytest.mark.parametrize('mc,ctx,prefix,world', [(32, 64, 'unet3d_tiny.', 2), (224, 1280, 'unet3d_full.', 4)])
+def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world):
+    """the sharded result must equal the single-GPU result BIT FOR BIT.  The multi-GPU decomposition
+    on one GPU: ``world`` shards stepped with a simulated all-gather.  Every kernel treats objects independently; what used
+    to differ was the fp32 summation order, because split-K factors and GroupNorm partial-sum tiles were picked from the
+    LOCAL object count -- shards now pass the global count (es_conv_args.O_hint / es_gn_args.O_hint) and all conv kernels
+    cut split-K ranges in the same places, so the tile size chosen per launch no longer matters."""
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
-    p = escfg.shape_unet_params(32)
-    p['context_dim'] = 64
+    O = 4
+    objs, triples = synth.synthetic_graph(O, seed=6)
+    uc = _rnd((O, 1, ctx), 52)
+    noise1 = synth.shape_noise(seed=7)
+    p = escfg.shape_unet_params(mc)
+    p['context_dim'] = ctx
     df = DiffusionUNet(p)
-    synth.seeded_fill_(df, prefix='unet3d_tiny.')
-    shards = [ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=4, device=dev, rank=r, world=2)
-              for r in range(2)]
-    sts = []
+    synth.seeded_fill_(df, prefix=prefix)
+    mpar = escfg.shape_df_conf().model.params
+    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev).sample(uc, triples, noise1)
+    shards = [ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, rank=r, world=world) for r in range(world)]
     for sh in shards:
-        st = sh._plan_for(g['uc_s'], g['triples'])
+        st = sh._plan_for(uc, triples)
         st['x'].copy_(noise1.to(dev).expand(st['hi'] - st['lo'], 3, 16, 16, 16))
         sh._cur, sh._use_graph = st, True
-        sts.append(st)
     for i in range(4):
-        codes = torch.cat([sh.codes_local(i).clone() for sh in shards], 0)
+        codes = torch.cat([sh.codes_local(i)[:sh._cur['hi'] - sh._cur['lo']].clone() for sh in shards], 0)
         for sh in shards:
             sh.step(i, codes)
     z = torch.cat([sh.latents_local() for sh in shards], 0)
-    e = _rel(z, z_ref)
-    print('two shards vs unsharded: rel err %.3e' % e)
-    assert e < 2e-3
+    assert torch.equal(z, z_ref), 'max abs diff %.3e' % (z - z_ref).abs().max().item()
 
 
 # ---- SURVEY.md section 8(f) rank 2: 'concat'-conditioned shape denoiser (sdfusion-txt2shape_concat_mp.yaml) ----
@@ -335,11 +335,11 @@ def test_conv_down_dhw(dev):
 
 @pytest.mark.parametrize('O,dims,Cin,N,skipC', [(16, (16, 16, 16), 64, 224, 0), (32, (16, 8, 8), 96, 448, 32),
                                                  (33, (8, 4, 4), 64, 224, 0)])
-def test_conv_ws3_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
+def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     """The dominant kernel on launches shaped like the shipped ones (>= 256 tiles of 256 rows, W = 16 / 8 / 4, ragged last
     tile, bias + per-object vector + fp32 residual + both outputs, fused 1x1 skip phase) against F.conv3d on the same
-    fp16-rounded operands: the A tile shared by the three kw taps (k_conv_ws3) must reproduce every tap incl. the W
-    boundary zeroing."""
+    fp16-rounded operands (k_conv_ws: producer / consumer waves, two K units per barrier, odd unit counts, the
+    lane-owned-column epilogue with residual prefetch)."""
     from echoscene_amd.plan import Builder, View
     from echoscene_amd.plan_vol import PackedConv
     D, H, W = dims
@@ -372,22 +372,22 @@ def test_conv_ws3_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_WS128': '1'},
-                                 {'ES_CONV_FORCE256': '1'}, {'ES_CONV_FORCE256': '1', 'ES_CONV_KW3': '0'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_FORCE256': '1'},
+                                 {'ES_CONV_FORCE256': '1', 'ES_CONV_UPS': '1'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
-    non-specialised k_conv_lean for 256-row tiles, the opt-in producer/consumer 128-row variant) must give the same
+    non-specialised k_conv_lean for 256-row tiles) must give the same
     results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
     (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
     1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
-    tiles: k_conv_ws3 (A tile shared by the three kw taps) by default, k_conv_ws with ES_CONV_KW3=0."""
+    tiles: k_conv_ws with two K units per barrier by default, one per barrier with ES_CONV_UPS=1."""
     import os
     import subprocess
     import sys
     e = dict(os.environ)
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae or test_conv_ws3'
+    sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae or test_conv_ws_at'
     if 'ES_CONV_OLD' not in env:                 # the general kernel has no stride-2-in-depth mode (raises, by design)
         sel += ' or test_conv_down_dhw'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],

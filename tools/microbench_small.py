@@ -1,6 +1,6 @@
 """Small-M regime of k_conv_mfma (few objects per GPU when a scene is sharded): time vs split-K for the layer
 shapes of one O_local-object shard; NW distinct weight sets are cycled so that weights stream from HBM as in a
-real step.  Env A/B: ES_CONV_DEEP=0|1, ES_CONV_DEBUG=64 (no XCD remap)."""
+real step.  """
 import sys, os, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
