@@ -8,13 +8,17 @@ box loop (BASELINE configs[1]); with ``--workload full`` one layout step + one D
 over the same O objects (the metric's "layout+SDF" step; needs the volume path).
 Inputs (weights, graph, noise tables) are resident in HBM before the timed region starts.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).  The objects of the collated
-(block-diagonal) batch graph are block-partitioned over the ranks (the per-object shape UNet is 99.98 % of the step
-FLOPs); each DDIM step exchanges the 64-d conv-pool codes with one all-gather ("echo" message passing) and every
-rank runs the small shape GCN on the full graph.
-  --scaling weak (default): a batch of N scenes of --nodes objects each, collated as the reference's collate_fn does
-      (BASELINE configs[4]); per-GPU work is fixed, value = N scenes x steps / max-over-ranks time (scene-steps/s).
-  --scaling strong: ONE scene sharded over the N GPUs (BASELINE configs[3]); value = steps / time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).
+  --scaling strong (default; BASELINE configs[3]): ONE 32-node scene, its objects block-partitioned over the N GPUs (the
+      per-object shape UNet is 99.98 % of the step FLOPs).  The path has a real exchange step here: every DDIM step
+      all-gathers the 64-d conv-pool codes ("echo" message passing, 8 KB) and every rank runs the small shape GCN on the
+      full graph; the layout branch (1 % of the work) is replicated.  value = steps / max-over-ranks time -- the same
+      quantity as at N = 1.
+  --scaling weak (BASELINE configs[4] shape): --scenes-per-gpu scenes per GPU, partitioned BY SCENE (the collated batch graph
+      is block diagonal, threedfront_dataset.py:698-701), so no rank needs another rank's codes: no data-path collective at
+      all; value = total scenes x steps / max-over-ranks time (scene-steps/s).
+At N = 1 the line also carries the BASELINE configs[1] (layout only) and configs[2] (16-node full step) results as
+``sub_records``.
 """
 import argparse
 import json
@@ -90,6 +94,48 @@ def time_dominant_kernel(ss, dev, reps=3):
     return flops / us / 1e6, us / len(ops), len(ops)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` as measured by the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in
+    its own pass, FETCH doubled as the MI355X guide prescribes for wide streaming reads on gfx950): bench.py cannot collect
+    counters itself, so it reports the number recorded under profiles/ for this same command -- or null."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
+def sub_records(dev, lay, use_graph, a):
+    """BASELINE configs[1] and configs[2] from the same command (N = 1): the layout loop alone (already timed on its stream) and
+    the full step of a 16-node scene."""
+    recs = [{'config': 'configs[1]: EchoLayout box diffusion, 32-node graph, 1000-step DDPM', 'metric': 'layout steps/s',
+             'value': lay['steps_per_s'], 'ms_per_step': lay['ms_per_step'], 'kernels_per_step': lay['kernels_per_step'],
+             'hbm_GBps_algorithmic': lay['hbm_GBps_algorithmic']}]
+    O = 16
+    net, den, obj_embed, triples = build_layout(dev, O, seed=116)
+    df, sden, uc = build_shape(dev, O, 116, triples)
+    n = max(10, min(a.steps, 30))
+    den.sample(obj_embed, triples, noise=None, n_steps=3, use_graph=use_graph)
+    noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    sden.sample(uc, triples, noise1=noise1, n_steps=2, use_graph=use_graph)
+    st, ss = next(iter(den._plans.values())), next(iter(sden._plans.values()))
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
+    e[1].record()
+    ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
+    e[2].record()
+    torch.cuda.synchronize()
+    tl, tsh = e[0].elapsed_time(e[1]) / n, e[1].elapsed_time(e[2]) / n
+    recs.append({'config': 'configs[2]: EchoScene full (layout+SDF) 16-node graph, 64^3 SDF', 'metric': 'full steps/s',
+                 'value': round(1e3 / (tl + tsh), 3), 'ms_per_step': round(tl + tsh, 4), 'layout_ms': round(tl, 4),
+                 'shape_ms': round(tsh, 4), 'steps_timed': n,
+                 'shape_TFLOPs': round(ss['plan'].flops / (tsh * 1e-3) / 1e12, 1)})
+    return recs
+
+
 def cpu_baseline_shape(df, uc, triples, O_sample):
     """One DDIM step of the CPU oracle on the first O_sample objects (cost is linear in objects)."""
     from oracle import echoscene_oracle as orc
@@ -127,7 +173,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--nodes', type=int, default=32)
     ap.add_argument('--workload', default='full', choices=['full', 'layout'])
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'])
+    ap.add_argument('--scenes-per-gpu', type=int, default=2,
+                    help='weak scaling: scenes per GPU (configs[4] is 8 per GPU; 2 keeps the default run inside ~20 GB)')
+    ap.add_argument('--no-sub-records', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     a = ap.parse_args()
@@ -150,20 +199,24 @@ def main():
 
     O = a.nodes
     full = a.workload == 'full'
-    weak = a.scaling == 'weak' and world > 1
-    scenes = world if weak else 1
+    weak = a.scaling == 'weak'
+    scenes_local = a.scenes_per_gpu if weak else 1
+    scenes = scenes_local * world if weak else 1
     # strong: ONE scene, objects block-partitioned over the ranks; the layout branch (1 % of
     #         the work, couples all nodes of a scene every step) is replicated on every rank.
-    # weak:   `world` scenes collated into one block-diagonal graph; the shape branch shards its objects (= one scene
-    #         per rank for equal scene sizes) and still exchanges codes / runs the GCN on the full graph (the code path
-    #         does not look at connectivity); each rank runs the layout loop of its own scene.
-    net, den, obj_embed, triples = build_layout(dev, O, seed=100, graph_seed=100 + (rank if weak else 0))
+    # weak:   every rank owns `scenes_local` whole scenes, collated into one block-diagonal graph of its own: both loops
+    #         run rank-locally, nothing is exchanged during the steps.
+    from echoscene_amd import synth
     if weak:
-        from echoscene_amd import synth
-        objs_all, triples_all = synth.collate_graphs([synth.synthetic_graph(O, seed=100 + s) for s in range(scenes)])
+        graphs = [synth.synthetic_graph(O, seed=100 + rank * scenes_local + s) for s in range(scenes_local)]
+        _, triples = synth.collate_graphs(graphs)
+        net, den, _, _ = build_layout(dev, O, seed=100)
+        obj_embed = torch.randn(O * scenes_local, 640, generator=torch.Generator().manual_seed(100 + rank))
     else:
-        triples_all = triples
-    O_all = O * scenes
+        net, den, obj_embed, triples = build_layout(dev, O, seed=100)
+    triples_all = triples
+    O_all = O * scenes_local
+    sh_rank, sh_world = (0, 1) if weak else (rank, world)
     use_graph = not a.no_graph
     # untimed warm-up (also builds the plans and captures the graphs)
     den.sample(obj_embed, triples, noise=None, n_steps=max(a.warmup, 1), use_graph=use_graph)
@@ -171,7 +224,7 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O_all, 100, triples_all, rank, world)
+        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world)
         noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
         sden.sample(uc, triples_all, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
@@ -198,12 +251,12 @@ def main():
         done = 0
         while full and done < a.steps:          # the DDIM loop is 100 iterations long
             n = min(a.steps - done, sden.S)
-            if world == 1:
+            if sh_world == 1:
                 ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
             else:                               # per-step echo all-gather over RCCL (parallel.sharded_ddim_loop)
                 from echoscene_amd.parallel import sharded_ddim_loop
                 sden._cur, sden._use_graph = ss, use_graph
-                sharded_ddim_loop(sden, O_all, n, world)
+                sharded_ddim_loop(sden, O_all, n, sh_world)
             done += n
         ev[3].record()
     torch.cuda.synchronize()
@@ -240,21 +293,24 @@ def main():
                 'data': 'synthetic',
                 'config': {'workload': 'EchoScene full (layout+SDF) %d-node synthetic graph (T=%d), 3x16^3 latent -> '
                                        '64^3 SDF, layout 1000-step DDPM + shape 100-step DDIM schedules; %s'
-                                       % (O, T, ('%d scenes collated into one graph, one per GPU, echo all-gather of codes every step'
-                                                 % scenes) if weak else ('1 scene, objects sharded over %d GPU(s)' % world)),
+                                       % (O, T, ('configs[4] shape: %d scenes per GPU x %d GPU(s), partitioned by scene (block-diagonal '
+                                                 'batch graph): no per-step collective' % (scenes_local, world)) if weak
+                                          else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
+                                                '[O,64] codes every DDIM step over RCCL)' % world)),
                            'scenes': scenes, 'hip_graph': use_graph, 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
                                      'kernels_per_step': ss['plan'].n_ops,
                                      'algorithmic_TFLOP_per_step': round(flops / 1e12, 3)}},
                 'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'k_conv_ws',
+                             'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic('k_conv_ws'), 'kernel': 'k_conv_ws',
                              'launches_per_step': dom_n, 'avg_launch_us': None if dom_us is None else round(dom_us, 1),
                              'whole_shape_step_TFLOPs': round(ach_step, 1),
                              'note': 'achieved = algorithmic FLOPs of the k_conv_ws launches of one shape step / their '
                                      'duration (HIP events on the launch stream, launches replayed back to back); '
-                                     'whole_shape_step = all FLOPs of the step / shape-step time (all kernels); traffic: '
-                                     'PMC bytes per launch are in profiles/ (separate rocprofv3 --pmc passes)'},
+                                     'whole_shape_step = all FLOPs of the step / shape-step time (all kernels); traffic = HBM '
+                                     'bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/'
+                                     'r02_pmc_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); null when that file is absent'},
             }
         else:
             ach = lay['hbm_GBps_algorithmic']
@@ -267,9 +323,11 @@ def main():
                                        '1000-step DDPM, HIP denoiser + graph conv' % (O, T),
                            'scenes_per_gpu': 1, 'hip_graph': use_graph, 'layout': lay},
                 'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': 'k_linear_rows'},
+                             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic('k_linear_rows'), 'kernel': 'k_linear_rows'},
             }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not weak and not a.no_sub_records and full:
+            out['sub_records'] = sub_records(dev, lay, use_graph, a)
+        if world == 1 and not weak and not a.no_cpu_baseline:
             v, n = cpu_baseline_layout(net, obj_embed, triples, O, budget_s=8.0 if full else 15.0)
             if full:
                 Os = 4

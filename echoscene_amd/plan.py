@@ -102,33 +102,64 @@ def centre_tap(w):
 class GraphIndex:
     """Device index arrays of one scene graph: gather indices for s/o and the CSR that turns
     scatter_add + average (model/graph.py:172-199) into a deterministic segmented mean whose
-    summation order equals the reference's (s-messages in triple order, then o-messages)."""
+    summation order equals the reference's (s-messages in triple order, then o-messages).
 
-    def __init__(self, triples, num_objs, device):
-        tri = triples.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
-        self.O, self.T = int(num_objs), int(tri.shape[0])
-        if self.T and (tri[:, [0, 2]].min() < 0 or tri[:, [0, 2]].max() >= self.O):
-            raise IndexError('triple endpoint out of range')
-        self.s = torch.from_numpy(tri[:, 0].astype(np.int32)).to(device)
-        self.o = torch.from_numpy(tri[:, 2].astype(np.int32)).to(device)
-        self.p_host = tri[:, 1].copy()
-        self.tri_host = tri
+    ``capacity``: number of triple ROWS the plans built on this index process (>= the number of triples; the extra rows
+    gather node 0 and are listed in no node's CSR segment, so they never reach a result).  Plans bake pointers and row
+    counts, not indices: ``update()`` rewrites the arrays in place for another graph with the same node count and a triple
+    count within the capacity, and every plan / captured hipGraph built on this object stays valid (eval_3dfront.py visits a
+    different scene graph on every call)."""
+
+    def __init__(self, triples, num_objs, device, capacity=None):
+        self.O = int(num_objs)
         self.device = device
+        n = int(triples.reshape(-1, 3).shape[0])
+        self.T = max(int(capacity or 0), n)                      # rows the plans run over
+        self.s = torch.zeros(max(self.T, 1), dtype=torch.int32, device=device)
+        self.o = torch.zeros(max(self.T, 1), dtype=torch.int32, device=device)
         self._csr = {}
+        self.update(triples)
+
+    def update(self, triples):
+        tri = triples.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
+        n = int(tri.shape[0])
+        if n > self.T:
+            raise ValueError('graph has %d triples, capacity %d' % (n, self.T))
+        if n and (tri[:, [0, 2]].min() < 0 or tri[:, [0, 2]].max() >= self.O):
+            raise IndexError('triple endpoint out of range')
+        self.n_triples = n
+        pad = np.zeros((self.T - n, 3), dtype=np.int64)
+        full = np.concatenate([tri, pad], 0) if self.T > n else tri
+        self.s[:self.T].copy_(torch.from_numpy(full[:, 0].astype(np.int32)))
+        self.o[:self.T].copy_(torch.from_numpy(full[:, 2].astype(np.int32)))
+        self.p_host = full[:, 1].copy()                          # [capacity] predicate ids (padding rows: predicate 0)
+        self.tri_host = tri                                      # the real triples
+        for key in list(self._csr):
+            self._fill_csr(key)
+
+    def _fill_csr(self, key):
+        off_s, off_o = key
+        tri = self.tri_host
+        rows, offs, ptr = [], [], [0]
+        for n in range(self.O):
+            ts = np.nonzero(tri[:, 0] == n)[0]
+            to = np.nonzero(tri[:, 2] == n)[0]
+            rows += ts.tolist() + to.tolist()
+            offs += [off_s] * len(ts) + [off_o] * len(to)
+            ptr.append(len(rows))
+        cap = max(2 * self.T, 1)                                 # every triple is listed twice (subject + object side)
+        if key not in self._csr:
+            z = lambda k: torch.zeros(k, dtype=torch.int32, device=self.device)
+            self._csr[key] = (z(self.O + 1), z(cap), z(cap))
+        dp, dr, do = self._csr[key]
+        dp.copy_(torch.tensor(ptr, dtype=torch.int32))
+        dr[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
+        do[:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32))
 
     def csr(self, off_s, off_o):
         key = (off_s, off_o)
         if key not in self._csr:
-            tri = self.tri_host
-            rows, offs, ptr = [], [], [0]
-            for n in range(self.O):
-                ts = np.nonzero(tri[:, 0] == n)[0]
-                to = np.nonzero(tri[:, 2] == n)[0]
-                rows += ts.tolist() + to.tolist()
-                offs += [off_s] * len(ts) + [off_o] * len(to)
-                ptr.append(len(rows))
-            mk = lambda a: torch.tensor(a, dtype=torch.int32).to(self.device)
-            self._csr[key] = (mk(ptr), mk(rows if rows else [0]), mk(offs if offs else [0]))
+            self._fill_csr(key)
         return self._csr[key]
 
 
@@ -509,7 +540,7 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
             b.rowsel(tables['t_lin'], step, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim), rows=O)
         else:
             b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
-    pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
+    pred = b.pred_rows = b.dev(w.pred_table[torch.from_numpy(g.p_host)])     # refreshed in place for a new graph
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
     b.tags.update(ctx=ctx, gcn_in=View(objbuf))
     if emb is not None:

@@ -298,7 +298,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 b.rowsel(tables['t_lin'], step, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim), rows=O)
             else:
                 b.linear([seg(emb)], w.shape_t, O, View(objbuf, col=ucw + gdim, ld=Dobj, width=gdim))
-        pred = b.dev(w.pred_table[torch.from_numpy(g.p_host)])
+        pred = b.pred_rows = b.dev(w.pred_table[torch.from_numpy(g.p_host)])     # refreshed in place for a new graph
         ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
         b.tags.update(ctx=ctx, code=View(objbuf, col=ucw, ld=Dobj, width=gdim))
         emb_ld = w.emb_all.N

@@ -338,8 +338,8 @@ def test_conv_down_dhw(dev):
 def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     """The dominant kernel on launches shaped like the shipped ones (>= 256 tiles of 256 rows, W = 16 / 8 / 4, ragged last
     tile, bias + per-object vector + fp32 residual + both outputs, fused 1x1 skip phase) against F.conv3d on the same
-    fp16-rounded operands (k_conv_ws: producer / consumer waves, two K units per barrier, odd unit counts, the
-    lane-owned-column epilogue with residual prefetch)."""
+    fp16-rounded operands (k_conv_ws: producer / consumer waves, the lane-owned-column epilogue with residual
+    prefetch)."""
     from echoscene_amd.plan import Builder, View
     from echoscene_amd.plan_vol import PackedConv
     D, H, W = dims
@@ -372,15 +372,14 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_FORCE256': '1'},
-                                 {'ES_CONV_FORCE256': '1', 'ES_CONV_UPS': '1'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_FORCE256': '1'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
     non-specialised k_conv_lean for 256-row tiles) must give the same
     results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
     (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
     1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
-    tiles: k_conv_ws with two K units per barrier by default, one per barrier with ES_CONV_UPS=1."""
+    tiles."""
     import os
     import subprocess
     import sys

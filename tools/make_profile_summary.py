@@ -3,12 +3,15 @@
    gpurun_out/bench_final.json                     (python bench.py --steps 100 --warmup 5)
    gpurun_out/prof_final/*/*kernel_stats.csv       (rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline)
    gpurun_out/pmc_final/<set>/*/*counter_collection.csv   (one rocprofv3 --kernel-trace --pmc <set> pass per counter set)
-usage: python tools/make_profile_summary.py r01"""
+usage: python tools/make_profile_summary.py r02 [gpurun_out sub-directory]
+Also writes profiles/<tag>_pmc_traffic.json: HBM bytes per launch by kernel family (FETCH_SIZE x 2 -- gfx950 reports half of a
+wide streaming read, MI355X_MICROARCH.md section HBM -- + WRITE_SIZE, both KB in rocprofv3), which bench.py reports as
+roofline.traffic."""
 import csv, glob, json, os, re, shutil, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, 'profiles')
-go = os.path.join(root, 'gpurun_out')
+go = os.path.join(root, 'gpurun_out', *(sys.argv[2:3]))
 line = [l for l in open(os.path.join(go, 'bench_final.json')) if l.startswith('{')][-1]
 open(os.path.join(out, tag + '_bench_line.json'), 'w').write(line)
 bench = json.loads(line)
@@ -54,6 +57,17 @@ for r in rows[:18]:
         '-' if not (gui and mf is not None) else '%.3f' % (mf / (gui / 8 * 1024)),
         '-' if not (gui and lds is not None) else '%.3f' % (lds / (gui / 8 * 256)),
         '-' if not (wc and wa is not None) else '%.2f' % (wa / wc)))
+traffic = {}
+fam = collections.defaultdict(lambda: collections.defaultdict(list))
+for n, d in pmc.items():
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        fam[n.split('<')[0]][c] += d.get(c, [])
+for n, d in fam.items():
+    if d['FETCH_SIZE'] and d['WRITE_SIZE']:
+        fe, wr = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']), sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
+        traffic[n] = {'hbm_bytes_per_launch': int((2 * fe + wr) * 1024), 'fetch_kb_raw': round(fe, 1), 'write_kb_raw': round(wr, 1),
+                      'launches_sampled': len(d['FETCH_SIZE'])}
+json.dump(traffic, open(os.path.join(out, tag + '_pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 extra = os.path.join(out, tag + '_notes.md')
 if os.path.exists(extra):
     md += ['', open(extra).read()]
