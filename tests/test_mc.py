@@ -62,14 +62,14 @@ def _compare(sdf_np, level):
         assert got['V'] == ref['V'] and got['F'] == ref['F'] and got['euler'] == ref['euler'], (got, ref)
         assert got['open_or_inconsistent_edges'] == ref['open_or_inconsistent_edges']
         # vertex multiset: lexicographically sorted coordinates (positions interpolated in fp32 on the device, fp64 in the oracle)
-        # every vertex sits on one grid edge (two integer coordinates, one interpolated): order both sets by that edge
-        def by_edge(p):
-            fl = np.floor(p + 1e-9).astype(np.int64)
-            axis = np.argmax(np.abs(p - np.round(p)), axis=1)
-            return p[np.lexsort((axis, fl[:, 2], fl[:, 1], fl[:, 0]))]
+        # vertex multiset: a one-to-one nearest-neighbour matching (positions are interpolated in fp32 on the device, fp64 in
+        # the oracle; sorting would be fragile where the interpolated coordinate lands next to a grid point)
         if ref['V']:
-            a, b = by_edge(v.cpu().numpy().astype(np.float64)), by_edge(rv)
-            assert np.abs(a - b).max() < 2e-5, np.abs(a - b).max()
+            from scipy.spatial import cKDTree
+            a = v.cpu().numpy().astype(np.float64)
+            dist, idx = cKDTree(rv).query(a)
+            assert dist.max() < 2e-5, dist.max()
+            assert len(np.unique(idx)) == len(rv)
         assert abs(got['volume'] - ref['volume']) <= 1e-5 * max(1.0, abs(ref['volume']))
         assert abs(got['area'] - ref['area']) <= 1e-5 * max(1.0, ref['area'])
     return meshes
