@@ -31,6 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FUSE_DEFAULT = False           # --fuse-loops default (set after measuring)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 
@@ -177,6 +178,9 @@ def main():
     ap.add_argument('--scenes-per-gpu', type=int, default=2,
                     help='weak scaling: scenes per GPU (configs[4] is 8 per GPU; 2 keeps the default run inside ~20 GB)')
     ap.add_argument('--no-sub-records', action='store_true')
+    ap.add_argument('--fuse-loops', type=int, default=-1,
+                    help='1: one hipGraph per full step with the layout step as a parallel branch of the shape step; 0: two streams; '
+                         '-1: the default of this build')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     a = ap.parse_args()
@@ -233,22 +237,42 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    fuse = full and sh_world == 1 and (FUSE_DEFAULT if a.fuse_loops < 0 else a.fuse_loops == 1)
+    fused = None
+    if fuse:
+        # ONE hipGraph per full step: the layout step is a parallel branch of the shape step (plan.combine_plans), so its 131
+        # small launches run in the gaps of the shape step's kernels instead of after them
+        from echoscene_amd.plan import combine_plans
+        fused = combine_plans(dev, ss['plan'], st['plan'])
+        st['step'].zero_()
+        fused.sample(ss['step'], 0, 2, use_graph=use_graph)          # capture outside the timed region
+        st['step'].zero_()
+        torch.cuda.synchronize()
     # The two loops are independent given the setup (the reference runs them back to back); they are enqueued on
     # two HIP streams so the latency-bound layout chain (few CUs busy) overlaps the MFMA-bound shape loop.
     s_lay, s_shp = torch.cuda.Stream(), torch.cuda.Stream()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t0 = time.perf_counter()
+    if fused is not None:
+        with torch.cuda.stream(s_shp):
+            ev[0].record(); ev[2].record()
+            done = 0
+            while done < a.steps:
+                n = min(a.steps - done, sden.S)
+                fused.sample(ss['step'], 0, n, use_graph=use_graph)
+                done += n
+            ev[1].record(); ev[3].record()
     with torch.cuda.stream(s_lay):
-        ev[0].record()
-        done = 0
+        ev[0].record() if fused is None else None
+        done = a.steps if fused is not None else 0
         while done < a.steps:                   # the layout loop is 1000 iterations long; K may exceed it
             n = min(a.steps - done, den.T)
             st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
             done += n
-        ev[1].record()
+        ev[1].record() if fused is None else None
     with torch.cuda.stream(s_shp):
-        ev[2].record()
-        done = 0
+        ev[2].record() if fused is None else None
+        done = a.steps if fused is not None else 0
         while full and done < a.steps:          # the DDIM loop is 100 iterations long
             n = min(a.steps - done, sden.S)
             if sh_world == 1:
@@ -258,12 +282,23 @@ def main():
                 sden._cur, sden._use_graph = ss, use_graph
                 sharded_ddim_loop(sden, O_all, n, sh_world)
             done += n
-        ev[3].record()
+        ev[3].record() if fused is None else None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
+    if fused is not None:
+        # per-loop figures for the record (outside the timed region): each loop alone on the idle GPU
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        nn = min(a.steps, 50)
+        e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph)
+        e[1].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
+        e[2].record(); torch.cuda.synchronize()
+        solo = (e[0].elapsed_time(e[1]) * a.steps / nn, e[1].elapsed_time(e[2]) * a.steps / nn)
     lay_ms, shp_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+    fused_ms = None
+    if fused is not None:
+        fused_ms, (lay_ms, shp_ms) = lay_ms, solo
     tmax = torch.tensor([wall], device=dev if backend == 'nccl' else 'cpu')
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -297,7 +332,9 @@ def main():
                                                  'batch graph): no per-step collective' % (scenes_local, world)) if weak
                                           else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
                                                 '[O,64] codes every DDIM step over RCCL)' % world)),
-                           'scenes': scenes, 'hip_graph': use_graph, 'layout': lay,
+                           'scenes': scenes, 'hip_graph': use_graph, 'loops': ('one hipGraph per full step, layout step as a parallel branch '
+                                                                              '(%.3f ms per step); layout / shape below: each loop alone' % (fused_ms / a.steps))
+                           if fused_ms is not None else 'two HIP streams', 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
                                      'kernels_per_step': ss['plan'].n_ops,

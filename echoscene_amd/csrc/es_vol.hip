@@ -1000,7 +1000,10 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
 // after last use (341 -> 351 us on the 16^3 224->224 launch; the 3-tiles-in-flight variant of round 1 was equal too), and the A
 // tile shared by the three kw taps of a (chunk, kd, kh) group, i.e. A LDS-DMA / 3 (340 -> 360 us, commit 53fb667).  The
 // launch runs ~690k cycles at 1.97 GHz with the matrix pipe busy 49 % (exactly 16 cycles per MFMA): neither barrier count nor
-// DMA piece count is what the other half waits for.
+// DMA piece count is what the other half waits for.  Nor is it the phase relation of the two consumer waves of a SIMD (LDS-flag
+// hand-offs with a per-SIMD turn token instead of the barrier, 4-slot ring, commit f3c4f56: 341 -> 379 us) or the issue priority of
+// the producer waves (s_setprio 3: 340 -> 336 us, noise).  SQ buckets over all 12 waves: 45 % parked (waitcnt / barrier), 36 %
+// issue-stalled, 19 % issuing.
 // ---------------------------------------------------------------------------------------------
 template <int MI>
 __device__ __forceinline__ void ws_read_frags(const char* As, int fragA, int fragB, h8 (&af)[MI], h8 (&bfr)[7]) {
@@ -1018,16 +1021,9 @@ __device__ __forceinline__ void ws_mma(f4 (&acc)[MI][7], const h8 (&af)[MI], con
         for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
 }
 
-// AP_ ("anti-phase"): no workgroup barrier in the K loop.  Hand-offs go through LDS words -- per producer wave "units landed",
-// per consumer wave "units read", and per SIMD a TURN token that makes its two consumer waves take the matrix pipe strictly one
-// after the other: while one issues its 28 MFMAs the other polls for the next unit, reads its 11 fragments and waits for the
-// token, so the fragment reads (88 KiB per unit for the workgroup) run under MFMAs instead of in front of them.  With the single
-// barrier both consumers of a SIMD were in the same phase and the pipe idled during every read phase (49 % busy).  Needs no extra
-// registers: a wave still holds one fragment set.  4-slot ring (128 KiB): the producers run up to four units ahead.
-template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool AP_ = false>
+template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
-    constexpr int NS = AP_ ? 4 : 3, UPS_ = 1;                     // ring depth; K units per barrier
-    constexpr int SPIN_CAP = 1 << 18;                             // polls before a hand-off wait gives up (legit waits: a few)
+    constexpr int NS = 3, UPS_ = 1;                               // ring depth; K units per barrier
     constexpr int WROWS = BM_ / (NC_ / 2);
     constexpr int MI = WROWS / 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, UNIT_BYTES = A_BYTES + B_BYTES;
@@ -1061,16 +1057,6 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
     const int nloc = ks_end - ks_begin;                           // K units of this workgroup
     const int nstage = (nloc + UPS_ - 1) / UPS_;
-    // AP_: sync words behind the ring: [0..3] units landed (per producer wave), [4..11] units read (per consumer wave),
-    // [12..15] turn token of the SIMD's consumer pair (counts finished MFMA phases)
-    typedef __attribute__((address_space(3))) volatile int lds_vint;         // explicit LDS pointer: ds_read / ds_write, not flat
-    lds_vint* const sync = (lds_vint*)(smem + NS * STAGE_BYTES);
-    if constexpr (AP_) {
-        static_assert(NC_ == 8 && NP_ == 4, "anti-phase hand-off is written for 8 consumer + 4 producer waves");
-        if (tid < 16) sync[tid] = 0;
-        __syncthreads();
-    }
-
     if (wave >= NC_) {
         // =============================== producer ===============================
         const int pw = wave - NC_;
@@ -1187,27 +1173,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
             for (int u = 0; u < UPS_; ++u)
                 if (issued < nloc) { issue_unit(base + u * UNIT_BYTES); ++issued; }
         };
-        if constexpr (AP_) {
-            for (int u = 0; u < nloc; ++u) {
-                if (u >= NS) {                   // the slot of unit u held unit u - NS: every consumer must have read it
-                    const int need = u - NS + 1;
-                    for (int spin = 0; spin < SPIN_CAP; ++spin) {         // (bounded: a lost hand-off must not hang the GPU)
-                        int m = sync[4];
-#pragma unroll
-                        for (int c = 1; c < NC_; ++c) m = min(m, sync[4 + c]);
-                        if (m >= need) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                issue_stage(u);
-                if (u >= 1) {                    // at most unit u's pieces still in flight -> unit u-1 has landed: publish
-                    wait_vmcnt<NLOAD>();
-                    if (lane == 0) sync[pw] = u;
-                }
-            }
-            wait_vmcnt<0>();
-            if (lane == 0) sync[pw] = nloc;
-        } else {
+        {
             issue_stage(0);
             if (nstage > 1) issue_stage(1);
             for (int st = 0; st < nstage; ++st) {
@@ -1232,35 +1198,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     const int fragA = (wm * WROWS + i16) * 64 + ((q ^ f_swz(i16)) << 4);
     const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
     h8 af[MI], bfr[7];
-    if constexpr (AP_) {
-        const int simd = wave & 3, par = wave >> 2;          // waves w and w + 4 share a SIMD (tools/probes/probe_barrier_waves)
-        for (int u = 0; u < nloc; ++u) {
-            for (int spin = 0; spin < SPIN_CAP; ++spin) {    // unit u landed (all four producers)?
-                const int l = min(min(sync[0], sync[1]), min(sync[2], sync[3]));
-                if (l > u) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            ws_read_frags<MI>(smem + (u & (NS - 1)) * STAGE_BYTES, fragA, fragB, af, bfr);
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the fragments are in registers
-            if (lane == 0) sync[4 + wave] = u + 1;           // the slot may be refilled as far as this wave is concerned
-            const int want = 2 * u + par;
-            for (int spin = 0; spin < SPIN_CAP && sync[12 + simd] != want; ++spin) {}     // my turn on this SIMD's matrix pipe
-            asm volatile("" : "+v"(af[0]) :: "memory");      // (ties the MFMAs below to the poll above)
-            __builtin_amdgcn_sched_barrier(0);
-            // the token is handed on one MFMA row (7 MFMAs ~ 120 cycles) before the end: about the latency of the LDS write +
-            // the partner's poll, so its first MFMA arrives as the last ones of this wave drain
-#pragma unroll
-            for (int i = 0; i < MI - 1; ++i)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (lane == 0) sync[12 + simd] = want + 1;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc[MI - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[MI - 1], bfr[j], acc[MI - 1][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
+    {
         // (A half-step stagger of the two consumer waves of a SIMD -- one in its MFMA phase while the other waits for LDS --
         //  needs the previous unit's fragments live across the barrier; under the 168-register cap the allocator spilled the
         //  accumulators, so both consumers of a SIMD run in phase.)
@@ -1628,10 +1566,6 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        constexpr int LDSAP = 4 * (256 * BK * 2 + BNP * BK * 2) + 64;      // 4-slot ring + the hand-off words
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSAP));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSAP));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSAP));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
         ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
         attr_set = true;
@@ -1685,14 +1619,7 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
                                     M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
         const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
         const bool geglu = a->epilogue == ES_EPI_GEGLU;
-        static const char* ap_env = getenv("ES_CONV_AP");          // A/B switch: 0 = barrier per K unit, 1 = anti-phase hand-off
-        const bool ap = ap_env && atoi(ap_env) == 1;
-        constexpr int LDSAP = 4 * (256 * BK * 2 + BNP * BK * 2) + 64;
-        if (lean && ws && ap && (!geglu || !upm)) {
-            if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU, true>), grid, dim3(768), LDSAP, st, *a, g, ncdhw);
-            else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>), grid, dim3(768), LDSAP, st, *a, g, ncdhw);
-            else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>), grid, dim3(768), LDSAP, st, *a, g, ncdhw);
-        } else if (lean && ws && (!geglu || !upm)) {
+        if (lean && ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false>), grid, dim3(768), LDS256, st, *a, g, ncdhw);

@@ -305,6 +305,34 @@ class Plan:
             pass
 
 
+def combine_plans(device, main, side, side_repeat=1):
+    """One plan = ``main``'s ops on lane 0 and ``side_repeat`` copies of ``side``'s ops on lane 1 (forked before, joined after):
+    captured as ONE hipGraph with two parallel branches, so the latency-bound layout chain (32 workgroups per launch) can run
+    in the gaps of the MFMA-bound shape step instead of after it.  Both plans keep their own buffers / step counters."""
+    import copy
+    b = Builder(device)
+    b.use_lanes = True
+    fork, join = Op(), Op()
+    fork.kind, fork.lane = hip.OP_FORK, 1
+    join.kind, join.lane = hip.OP_JOIN, 1
+    ops = [fork]
+    for _ in range(side_repeat):
+        for op in side._arr:
+            o = Op()
+            C.memmove(C.byref(o), C.byref(op), C.sizeof(Op))
+            o.lane = 1
+            ops.append(o)
+    for op in main._arr:
+        o = Op()
+        C.memmove(C.byref(o), C.byref(op), C.sizeof(Op))
+        ops.append(o)
+    ops.append(join)
+    b.ops = ops
+    b.keep = [main, side]
+    b.weight_bytes, b.flops = main.weight_bytes + side.weight_bytes * side_repeat, main.flops + side.flops * side_repeat
+    return b.finish()
+
+
 # ------------------------------------------------------------------------------------------------
 # GraphTripleConvNet  (reference model/graph.py:89-250)
 # ------------------------------------------------------------------------------------------------
