@@ -31,7 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FUSE_DEFAULT = False           # --fuse-loops default (set after measuring)
+FUSE_DEFAULT = True            # --fuse-loops default: measured 24.34 -> 23.02 ms per full step (profiles/r02_notes.md)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 

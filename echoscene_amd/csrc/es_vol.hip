@@ -13,7 +13,9 @@
 //     operand of the next contraction; bias / time-embedding / residual adds are fused into the
 //     contraction epilogue.
 #include "es_common.h"
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -507,257 +509,16 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     }
 }
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // Workgroup = NW_ waves as (NW_/2)(M) x 2(N); tile BM_ x 224:
 //   <256, 8> wave tile 64 x 112 (16^3 and 16x8x8 levels: A+B bytes per flop -32 % vs <128,4>)
 //   <128, 4> wave tile 64 x 112
 //   < 64, 4> wave tile 32 x 112 (16x4x4 level: enough workgroups to cover the 256 CUs)
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int BM_, int NW_, int NS_>
-__global__ __launch_bounds__(64 * NW_, NS_ > 3 ? 1 : 2) void k_conv_mfma(const es_conv_args a, const ConvGeom g, const _Float16* zero_page, int ncdhw_) {
-    int ncdhw = ncdhw_;
-    constexpr int NT = 64 * NW_;                 // threads
-    constexpr int WROWS = BM_ / (NW_ / 2);       // rows per wave
-    constexpr int MI = WROWS / 16;               // 16-row MFMA tiles per wave in M
-    constexpr int NA = BM_ * 4 / NT;             // A glds per thread per stage
-    constexpr int NB = BNP * 4 / NT;             // B glds per thread per stage
-    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NLOAD = NA + NB;               // glds per thread per stage (uniform across waves)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = ncdhw >> 8;                  // ablation switches (ES_CONV_DEBUG, tools/microbench_conv.py)
-    ncdhw &= 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const long M = (long)g.O * g.D * g.H * g.W;
-    // XCD-aware tile mapping.  The dispatcher places hardware workgroup id b on XCD b % 8 (observed, speed only):
-    // taken literally, the 8 row tiles that share one weight slab (same column tile / K split) would sit on 8
-    // different XCDs and every XCD's L2 would pull the whole weight matrix from HBM (measured: the 16x4x4 level ran
-    // at 300 GB/s of weight traffic per XCD-copy, 6x off the MFMA time).  Remap (bijective for any grid size) so that
-    // each XCD owns a contiguous range of logical ids = x fastest: neighbours in x share the B slab and the
-    // A halo (adjacent depth slices) inside one L2.
-    int bx, by, bz;
-    {
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = L % (int)gridDim.x;
-        const int t = L / (int)gridDim.x;
-        by = t % (int)gridDim.y;
-        bz = t / (int)gridDim.y;
-        if (dbg & 64) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }      // A/B switch: literal mapping
-    }
-    const long m0 = (long)bx * BM_;
-    const int n0 = by * BN;
-
-    // ---- per-lane staging roles (fixed for the whole K loop) ----
-    int a_lc[NA], a_o[NA], a_d[NA], a_h[NA], a_w[NA];
-    bool a_ok[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int p = tid + NT * j;              // 16-B slot: row = p >> 2, physical chunk = p & 3
-        const int row = p >> 2;
-        a_lc[j] = (p & 3) ^ f_swz(row);
-        const long m = m0 + row;
-        a_ok[j] = m < M;
-        const long mm = a_ok[j] ? m : 0;
-        a_w[j] = (int)(mm & (g.W - 1));
-        a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
-        a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
-        a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
-    }
-    // B (weights) is pre-tiled on the host in exactly the LDS image order: one K step of one 224-column tile is a
-    // contiguous 16 KiB block, so every wave-level load is 1 KiB contiguous (8 full cache lines, no per-row addressing).
-
-    // ---- K-step generator (for the tile being STAGED, which runs 2-3 steps ahead of compute) ----
-    // Order: channel chunk OUTER, 3x3x3 tap INNER.  Consecutive K steps then read the same 64-B channel chunk of
-    // voxels shifted by one tap, so the A operand is re-used out of L2 up to 27x (with taps outer the re-use distance
-    // is the whole channel sweep of all co-resident workgroups, > the 4 MiB L2, and every tap re-fetches from MALL).
-    const int kch0 = a.Cin >> 5;
-    const int nks0 = a.taps * kch0;
-    const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
-    // split-K: this workgroup handles K steps [ks_begin, ks_end) of the nks steps
-    const int S = gridDim.z;
-    int ks_begin, ks_end;
-    split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
-    const int nloc = ks_end - ks_begin;
-    int st_phase = ks_begin >= nks0 ? 1 : 0;
-    int st_tap = st_phase ? 0 : ks_begin % a.taps;
-    int st_c = st_phase ? (ks_begin - nks0) * BK : (ks_begin / a.taps) * BK;
-    // per-row: pointer to the centre tap (+ this lane's 16-B chunk) and a 27-bit validity mask of the taps
-    const _Float16* a_ctr[NA];
-    unsigned a_msk[NA];
-    const _Float16* b_base;
-    const bool uniform_delta = (a.mode == ES_CONV_SAME || a.mode == ES_CONV_DOWN_HW);
-    auto set_phase = [&]() __attribute__((always_inline)) {
-        const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
-        const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
-        b_base = Wg + ((long)by * nks_ph) * (BNP * BK) + tid * 8;
-        const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
-        const int Cin = st_phase ? a.Cin2 : a.Cin;
-        const int mode = st_phase ? (int)ES_CONV_SAME : a.mode;
-        const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
-        const int ntap = st_phase ? 1 : a.taps;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int ch = mode == ES_CONV_DOWN_HW ? 2 * a_h[j] : a_h[j];
-            const int cw = mode == ES_CONV_DOWN_HW ? 2 * a_w[j] : a_w[j];
-            a_ctr[j] = Ag + ((((long)a_o[j] * g.D + a_d[j]) * Hi + ch) * Wi + cw) * Cin + a_lc[j] * 8;
-            unsigned m = 0;
-            if (ntap == 1) {
-                m = a_ok[j] ? 1u : 0u;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 27; ++t) {
-                    const int id = a_d[j] + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
-                    const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
-                    m |= (ok ? 1u : 0u) << t;
-                }
-            }
-            a_msk[j] = m;
-        }
-    };
-    set_phase();
-
-    // The LDS-DMA of one K step is NLOAD independent pieces (NA of the A tile, NB of the B tile).  They are issued
-    // one at a time BETWEEN the MFMA rows of the step being computed, so that their issue cost (60-180 cycles each)
-    // overlaps the matrix pipe instead of preceding it.
-    long st_delta = 0, st_boff = 0;
-    bool st_uni = true;
-    auto stage_prep = [&]() __attribute__((always_inline)) {
-        const int Cin = st_phase ? a.Cin2 : a.Cin;
-        const int ntap = st_phase ? 1 : a.taps;
-        st_boff = (long)((st_c >> 5) * ntap + st_tap) * (BNP * BK);
-        st_uni = st_phase || uniform_delta;
-        int kd = 0, kh = 0, kw = 0;
-        if (ntap == 27) { kd = st_tap / 9 - 1; kh = (st_tap / 3) % 3 - 1; kw = st_tap % 3 - 1; }
-        const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
-        st_delta = ((long)(kd * Hi + kh) * Wi + kw) * Cin + st_c;                      // wave-uniform
-    };
-    auto stage_piece = [&](int b, int pj) __attribute__((always_inline)) {
-        char* As = smem + b * STAGE_BYTES;
-        char* Bs = As + A_BYTES;
-        if (pj < NA) {
-            const int j = pj;
-            if (st_uni) {
-                glds16((((a_msk[j] >> st_tap) & 1u) && !(dbg & 16)) ? a_ctr[j] + st_delta : zero_page,
-                       As + (wave * 64 + NT * j) * 16);
-            } else {                             // nearest-upsample modes: source index is not a uniform shift
-                const _Float16* Ag = (const _Float16*)a.a;
-                const int kd = st_tap / 9 - 1, kh = (st_tap / 3) % 3 - 1, kw = st_tap % 3 - 1;
-                const int Di = (a.mode == ES_CONV_UP_DHW) ? g.D / 2 : g.D;
-                int id = a_d[j] + kd, ih = a_h[j] + kh, iw = a_w[j] + kw;
-                const bool ok = a_ok[j] && id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-                if (a.mode == ES_CONV_UP_DHW) id >>= 1;
-                ih >>= 1; iw >>= 1;
-                glds16(ok ? Ag + ((((long)a_o[j] * Di + id) * g.Hi + ih) * g.Wi + iw) * a.Cin + a_lc[j] * 8 + st_c : zero_page,
-                       As + (wave * 64 + NT * j) * 16);
-            }
-        } else {
-            const int j = pj - NA;
-            glds16(b_base + ((dbg & 32) ? 0 : st_boff) + NT * 8 * j, Bs + (wave * 64 + NT * j) * 16);
-        }
-    };
-    auto stage_advance = [&]() __attribute__((always_inline)) {
-        const int Cin = st_phase ? a.Cin2 : a.Cin;
-        const int ntap = st_phase ? 1 : a.taps;
-        if (++st_tap == ntap) {
-            st_tap = 0;
-            st_c += BK;
-            if (st_c == Cin && !st_phase && a.a2) { st_phase = 1; st_c = 0; set_phase(); }
-        }
-    };
-    auto stage = [&](int b) __attribute__((always_inline)) {   // whole K step at once (prologue of the pipeline)
-        stage_prep();
-#pragma unroll
-        for (int pj = 0; pj < NLOAD; ++pj) stage_piece(b, pj);
-        stage_advance();
-    };
-
-    f4 acc[MI][7];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const int i16 = lane & 15, q = lane >> 4;
-    // Software pipeline: while the MFMAs of K step ks run, the fragments of step ks+1 are read from LDS into
-    // a second register set and tiles ks+2, ks+3 are in flight from HBM/L2 (3-slot LDS ring).
-    auto load_frags = [&](int slot, h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline)) {
-        const char* As = smem + slot * STAGE_BYTES;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = wm * WROWS + i * 16 + i16;
-            af[i] = *(const h8*)(As + row * 64 + ((q ^ f_swz(row)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int row = wn * 112 + j * 16 + i16;
-            bfr[j] = *(const h8*)(Bs + row * 64 + ((q ^ f_swz(row)) << 4));
-        }
-    };
-    auto mma = [&](h8 (&af)[MI], h8 (&bfr)[7]) __attribute__((always_inline, unused)) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    };
-    // tiles ks+1 and ks+2 are in flight while tile ks is consumed (an additional register-level double buffer of the
-    // fragments was measured slower: LDS latency is not what this loop waits for)
-    {
-        h8 af[MI], bfr[7];
-#pragma unroll
-        for (int t = 0; t < NS_ - 1; ++t)
-            if (t < nloc) stage(t);
-        for (int ks = 0; ks < nloc; ++ks) {
-            // tile ks must have landed; tiles ks+1 .. ks+NS_-2 may stay in flight (vmcnt counts this wave's loads)
-            const int infl = min(NS_ - 2, nloc - 1 - ks);
-            if (infl >= 4) wait_vmcnt<4 * NLOAD>();
-            else if (infl == 3) wait_vmcnt<3 * NLOAD>();
-            else if (infl == 2) wait_vmcnt<2 * NLOAD>();
-            else if (infl == 1) wait_vmcnt<NLOAD>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();        // also: every wave finished reading ring slot (ks-1)%NS_, refilled below
-            const bool pf = (ks + NS_ - 1 < nloc) && !(dbg & 1);
-            const int slot = (ks + NS_ - 1) % NS_;
-            if (pf) stage_prep();
-            if (!(dbg & 8)) load_frags(ks % NS_, af, bfr);
-            // MFMA rows interleaved with the LDS-DMA pieces of tile ks+2 (order pinned with sched_barrier)
-            constexpr int PPR = (NLOAD + MI - 1) / MI;           // pieces per MFMA row
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if (!(dbg & 2)) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (pf) {
-#pragma unroll
-                    for (int pp = 0; pp < PPR; ++pp)
-                        if (i * PPR + pp < NLOAD) stage_piece(slot, i * PPR + pp);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (pf) stage_advance();
-        }
-    }
-
-    if (dbg & 4) { if (acc[0][0][0] == 123.456f) a.out_f32[0] = 1.f; return; }
-    conv_epilogue<BM_, NW_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_conv_lean: the same tiling / LDS image / epilogue as k_conv_mfma for the modes whose tap shift is one
-// wave-uniform offset (SAME, DOWN_HW, 1x1 / linear, fused 1x1 skip phase), with the K loop stripped to what the
-// hardware needs.  Why: ablation of k_conv_mfma (tools/microbench_small.py, ES_CONV_DEBUG) showed the loop was
+// k_conv_lean: implicit-GEMM conv / linear for every mode (SAME, strided, nearest-up fused, 1x1 / linear, fused 1x1 skip
+// phase), with the K loop stripped to what the hardware needs.  Why: ablation of the first conv kernel of round 1 (64-bit
+// pointer selects against a zero page; retired in round 2) showed the loop was
 // INSTRUCTION-ISSUE bound, not memory or MFMA bound -- ~400 instructions per K step (64-bit pointer selects against a
 // zero page, per-piece tap arithmetic, M0 through VALU + readfirstlane, the inlined up-sampling path) against 28 MFMAs:
 // 0.64 us per K step with all loads removed, 0.19 us of it MFMA.  Here:
@@ -791,7 +552,13 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.O * g.D * g.H * g.W;
-    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_mfma)
+    // XCD-aware tile mapping.  The dispatcher places hardware workgroup id b on XCD b % 8 (observed, speed only):
+    // taken literally, the 8 row tiles that share one weight slab (same column tile / K split) would sit on 8
+    // different XCDs and every XCD's L2 would pull the whole weight matrix from HBM (measured: the 16x4x4 level ran
+    // at 300 GB/s of weight traffic per XCD-copy, 6x off the MFMA time).  Remap (bijective for any grid size) so that
+    // each XCD owns a contiguous range of logical ids = x fastest: neighbours in x share the B slab and the
+    // A halo (adjacent depth slices) inside one L2.
+    int bx, by, bz;
     {
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -823,7 +590,6 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     }
     const int kch0 = a.Cin >> 5;
     const int nks0 = a.taps * kch0;
-    const int nks = nks0 + (a.a2 ? (a.Cin2 >> 5) : 0);
     const int S = gridDim.z;
     int ks_begin, ks_end;
     split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
@@ -1037,7 +803,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long M = (long)g.O * g.D * g.H * g.W;
-    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_mfma)
+    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_lean)
     {
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -1440,8 +1206,6 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a
     }
 }
 
-_Float16* g_zero_page = nullptr;
-
 int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -1450,16 +1214,10 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-// called outside of stream capture (es_plan_create / first direct call)
-int es_vol_init(void) {
-    if (!g_zero_page) {
-        ES_CHECK_HIP(hipMalloc((void**)&g_zero_page, 256));
-        ES_CHECK_HIP(hipMemset(g_zero_page, 0, 256));
-    }
-    return 0;
-}
+// library-wide one-off initialisation hook (nothing to allocate since the zero-page gather kernel was retired)
+int es_vol_init(void) { return 0; }
 
-// Tiled weight image consumed by k_conv_mfma: [n-tile of 224][K step][1024 slots of 16 B] where slot p holds
+// Tiled weight image consumed by the conv kernels: [n-tile of 224][K step][1024 slots of 16 B] where slot p holds
 // row = p >> 2 (output channel within the tile, rows 224..255 are zero padding), physical 16-B chunk p & 3 =
 // logical chunk ^ swizzle(row); K step index = (channel chunk of 32) * taps + tap  (tap inner).
 static inline int h_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
@@ -1525,13 +1283,41 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     g.lw = ilog2_exact(a->W); g.lh = ilog2_exact(a->H); g.ld = ilog2_exact(a->D);
     ES_REQUIRE(g.lw >= 0 && g.lh >= 0 && g.ld >= 0, "es_conv_mfma_f16: D,H,W must be powers of two (%d,%d,%d)", a->D, a->H, a->W);
     int ncdhw = a->out_ld < 0 ? 1 : 0;            // out_ld < 0 selects NCDHW fp32 output [O,N,V]
-    static const char* dbg_env = getenv("ES_CONV_DEBUG");
-    const int dbgf = dbg_env ? atoi(dbg_env) : 0;
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
-    if (!g_zero_page) if (int rc = es_vol_init()) return rc;
     const long M = (long)a->O * a->D * a->H * a->W;
     // split-K factors are derived from Mh: the row count of the WHOLE problem when this launch is one shard of it
     const long Mh = (long)(a->O_hint > a->O ? a->O_hint : a->O) * a->D * a->H * a->W;
+    // The kernels address their operands with 31-bit byte offsets from a buffer descriptor.  Larger tensors are processed in
+    // object chunks (every object is independent; O_hint keeps the split-K choice of the whole problem).
+    {
+        const long per_obj_in = (long)g.Di * g.Hi * g.Wi * a->Cin * 2, per_obj_in2 = a->a2 ? (long)a->D * a->H * a->W * a->Cin2 * 2 : 0;
+        const long halo = 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
+        const long lim = (1L << 31) - halo - 1;
+        long omax = a->O;
+        if (per_obj_in > 0) omax = std::min(omax, lim / per_obj_in);
+        if (per_obj_in2 > 0) omax = std::min(omax, lim / per_obj_in2);
+        ES_REQUIRE(omax >= 1, "es_conv_mfma_f16: one object exceeds 2 GiB of input (%ld bytes)", per_obj_in);
+        if (omax < a->O) {
+            const long V = (long)a->D * a->H * a->W;
+            for (long o0 = 0; o0 < a->O; o0 += omax) {
+                es_conv_args c = *a;
+                c.O = (int32_t)std::min(omax, (long)a->O - o0);
+                c.O_hint = a->O_hint > a->O ? a->O_hint : a->O;
+                c.a = (const char*)a->a + o0 * per_obj_in;
+                if (a->a2) c.a2 = (const char*)a->a2 + o0 * per_obj_in2;
+                if (a->rowvec) c.rowvec = a->rowvec + o0 * a->rowvec_ld;
+                if (ncdhw) {
+                    c.out_f32 = a->out_f32 + o0 * a->N * V;
+                } else {
+                    if (a->res) c.res = a->res + o0 * V * a->out_ld;
+                    if (a->out_f32) c.out_f32 = a->out_f32 + o0 * V * a->out_ld;
+                    if (a->out_f16) c.out_f16 = (char*)a->out_f16 + o0 * V * a->out_ld * 2;
+                }
+                if (int rc = es_conv_mfma_f16(&c, stream)) return rc;
+            }
+            return 0;
+        }
+    }
     // N <= 4 with a narrow input (VQ-VAE conv_out 64 -> 1 at 64^3): direct kernel, weights in the rows layout.  Wider
     // inputs (UNet eps conv 224 -> 3) go through the MFMA tile: 98 % column padding, but the direct kernel's 756
     // dependent 16-B loads per voxel cost 2.4x (O=32) to 10x (O=4) more than the padded tile.
@@ -1552,23 +1338,27 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const long wg256 = ((M + 255) / 256) * ntn, wg128 = ((M + 127) / 128) * ntn;
     const long hg256 = ((Mh + 255) / 256) * ntn, hg128 = ((Mh + 127) / 128) * ntn;      // the same counts for the whole problem
     const int nks = a->taps * (a->Cin / 32) + (a->a2 ? a->Cin2 / 32 : 0);
-    static bool attr_set = false;
     constexpr int LDS256 = 3 * (256 * BK * 2 + BNP * BK * 2), LDS128 = 3 * (128 * BK * 2 + BNP * BK * 2),
                   LDS64 = 3 * (64 * BK * 2 + BNP * BK * 2);
-    if (!attr_set) {
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<256, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<128, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<64, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<256, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_lean<64, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
-        attr_set = true;
+    {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            auto set = [](const void* f, int bytes) {
+                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+            };
+            set((const void*)k_conv_lean<256, 8>, LDS256);
+            set((const void*)k_conv_lean<128, 4>, LDS128);
+            set((const void*)k_conv_lean<64, 4>, LDS64);
+            set((const void*)k_conv_lean<256, 8, true>, LDS256);
+            set((const void*)k_conv_lean<128, 4, true>, LDS128);
+            set((const void*)k_conv_lean<64, 4, true>, LDS64);
+            set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
+        });
+        ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
     hipStream_t st = (hipStream_t)stream;
     int S = a->splitk;
@@ -1597,17 +1387,10 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             }
     }
     if (S <= 1 || !can_split) S = 1;
-    const int flags = ncdhw | (dbgf << 8);
     static const char* tile_env = getenv("ES_CONV_TILE");     // A/B switch: force 128-row tiles
     const bool no256 = tile_env && atoi(tile_env) == 128;
-    // k_conv_lean: every mode whose tap shift is wave-uniform, tensors addressable with 31-bit byte offsets
-    static const char* old_env = getenv("ES_CONV_OLD");       // A/B switch: 1 = always the general kernel
-    const long in_bytes = (long)a->O * g.Di * g.Hi * g.Wi * a->Cin * 2 + 4L * ((g.Hi + 1) * g.Wi + 1) * a->Cin;
-    const long in2_bytes = a->a2 ? M * a->Cin2 * 2 : 0;
     const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
-    const bool lean = (!upm || (!a->a2 && a->taps == 27)) && in_bytes < (1L << 31) && in2_bytes < (1L << 31) &&
-                      !(old_env && atoi(old_env) == 1) && dbgf == 0;
-    ES_REQUIRE(lean || a->mode != ES_CONV_DOWN_DHW, "es_conv_mfma_f16: DOWN_DHW needs the lean kernel (tensor < 2 GiB, ES_CONV_OLD unset)");
+    ES_REQUIRE(!upm || (!a->a2 && a->taps == 27), "es_conv_mfma_f16: nearest-up modes take 3x3x3 convs without a fused skip");
     static const char* f256_env = getenv("ES_CONV_FORCE256");  // test switch: 256-row tiles (the ws kernels) for any problem size
     const bool force256 = f256_env && atoi(f256_env) == 1;
     if (force256 && a->splitk < 0 && !split256) S = 1;
@@ -1619,24 +1402,21 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
                                     M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
         const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
         const bool geglu = a->epilogue == ES_EPI_GEGLU;
-        if (lean && ws && (!geglu || !upm)) {
+        if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         }
-        else if (lean && upm) hipLaunchKernelGGL((k_conv_lean<256, 8, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
-        else if (lean) hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
-        else hipLaunchKernelGGL((k_conv_mfma<256, 8, 3>), grid, dim3(512), LDS256, st, *a, g, g_zero_page, flags);
+        else if (upm) hipLaunchKernelGGL((k_conv_lean<256, 8, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
-        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<128, 4, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
-        else if (lean) hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
-        else hipLaunchKernelGGL((k_conv_mfma<128, 4, 3>), grid, dim3(256), LDS128, st, *a, g, g_zero_page, flags);
+        if (upm) hipLaunchKernelGGL((k_conv_lean<128, 4, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
     } else {
         dim3 grid((unsigned)((M + 63) / 64), ntn, 1);
-        if (lean && upm) hipLaunchKernelGGL((k_conv_lean<64, 4, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
-        else if (lean) hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
-        else hipLaunchKernelGGL((k_conv_mfma<64, 4, 3>), grid, dim3(256), LDS64, st, *a, g, g_zero_page, flags);
+        if (upm) hipLaunchKernelGGL((k_conv_lean<64, 4, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
+        else hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
     }
     if (S > 1) {
         const long n4 = M * (a->N / 4);
@@ -1717,10 +1497,13 @@ extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
 extern "C" int es_vq_lookup(const es_vq_args* a, es_stream stream) {
     ES_REQUIRE(a->n_embed > 0 && a->n_embed * 16 <= 160 * 1024 - 1024, "es_vq_lookup: n_embed=%d too large for LDS", a->n_embed);
     ES_REQUIRE(a->Cpad >= 3, "es_vq_lookup: Cpad=%d", a->Cpad);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ES_CHECK_HIP(hipFuncSetAttribute((const void*)k_vq_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr_set = true;
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)k_vq_lookup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        });
+        ES_REQUIRE(attr_err == hipSuccess, "es_vq_lookup: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
     const long M = (long)a->O * a->V;
     hipLaunchKernelGGL(k_vq_lookup, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->n_embed * 16, (hipStream_t)stream, *a);

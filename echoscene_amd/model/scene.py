@@ -375,25 +375,30 @@ class Sg2ScDiffModel(_SceneModel):
                                         noise=shape_noise)
 
     def _layout_and_shapes(self, gen_shape, dec_objs, dec_triples, obj_embed_, latent, layout_noise, shape_noise):
-        """The two loops only share the setup (the reference runs them back to back, EchoScene.py:402-419): the shape
-        branch (100 DDIM steps + VQ-VAE decode, MFMA-bound) is enqueued on a side HIP stream, the layout loop (1000
-        latency-bound steps that keep a few CUs busy) on the caller's stream; joined before returning."""
+        """The two loops only share the setup (the reference runs them back to back, EchoScene.py:402-419).  Here they are
+        ONE replayed hipGraph: each replay is a DDIM shape step with ten ancestral layout steps on a parallel branch
+        (samplers.sample_layout_and_shape), then the VQ-VAE decode."""
         if not gen_shape:
             return None, self._layout(dec_triples, obj_embed_, latent, layout_noise)
+        from ..samplers import sample_layout_and_shape
         uc = self._rel_s(obj_embed_)
         c = self._rel_s(latent)
-        cur = torch.cuda.current_stream(obj_embed_.device)
-        if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=obj_embed_.device)
-        side = self._side_stream
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            sdf = self.ShapeDiff.rel2shape({'obj_cat': dec_objs, 'triples': dec_triples, 'c_s': c, 'uc_s': uc},
-                                           noise=shape_noise, sync=False)
-        boxes = self._layout(dec_triples, obj_embed_, latent, layout_noise)
-        cur.wait_stream(side)
-        sdf.record_stream(cur)
-        return sdf, boxes
+        L, S = self.LayoutDiff, self.ShapeDiff
+        L.set_input({'preds': dec_triples, 'box': None, 'uc_b': obj_embed_, 'c_b': latent, 'obj_id_to_scene': None})
+        S.switch_eval()
+        S.set_input({'obj_cat': dec_objs, 'triples': dec_triples, 'c_s': c, 'uc_s': uc})
+        sden = S._denoiser()
+        need_c = S.df.conditioning_key == 'concat' or not S.df.diffusion_net.messsage_passing
+        if shape_noise is None:       # the reference seeds this draw from the wall clock (echo2shape.py:502)
+            g = torch.Generator(device=sden.device).manual_seed(int(time.time()))
+            shape_noise = torch.randn((1,) + tuple(S.z_shape), device=sden.device, generator=g)
+        x, z = sample_layout_and_shape(L._denoiser(), sden, obj_embed_, dec_triples, uc, c if need_c else None,
+                                       layout_noise=layout_noise, shape_noise=shape_noise)
+        s_, t_ = L.size_dim, L.translation_dim
+        boxes = {'sizes': x[:, 0:s_].contiguous(), 'translations': x[:, s_:s_ + t_].contiguous(),
+                 'angles': x[:, s_ + t_:L.bbox_dim].contiguous()}
+        S.gen_df = S._decoder().decode_no_quant(z, sync=True)
+        return S.gen_df, boxes
 
     @torch.no_grad()
     def sample(self, dec_objs, dec_triplets, dec_text_feat, dec_rel_feat, gen_shape=False, layout_noise=None,

@@ -281,6 +281,42 @@ class ShapeDenoiser:
         return sharded_ddim_loop(self, st['O'], n_steps, self.world, self.group).clone()
 
 
+def sample_layout_and_shape(lay, shp, obj_embed, triples, uc, c=None, layout_noise=None, shape_noise=None, use_graph=True):
+    """Both sampling loops of one scene (EchoScene.py:402-419 runs them back to back) as ONE replayed hipGraph: every replay = one
+    DDIM shape step on the main branch and ``T_layout // S_shape`` (= 10) ancestral layout steps on a parallel branch
+    (plan.combine_plans), so the latency-bound layout chain -- 131 launches of 32 workgroups per step -- runs inside the gaps
+    of the MFMA-bound shape step instead of after it (measured on the bench: 24.3 -> 23.0 ms per full step, i.e. the layout
+    step disappears).  Left-over layout steps (T not a multiple of S) run afterwards.  Returns (boxes x_0 [O, 8], latents z_0)."""
+    from .plan import combine_plans
+    if shp.world != 1:
+        return lay.sample(obj_embed, triples, noise=layout_noise, use_graph=use_graph), \
+            shp.sample(uc, triples, noise1=shape_noise, c=c, use_graph=use_graph)
+    st = lay._plan_for(obj_embed, triples)
+    if layout_noise is None:
+        st['noise'].normal_()
+    else:
+        st['noise'][:layout_noise.shape[0]].copy_(layout_noise.to(lay.device))
+    st['x'].copy_(st['noise'][0])
+    ss = shp._plan_for(uc, triples, c)
+    if shape_noise is None:
+        shape_noise = torch.randn((1,) + shp.z_shape, device=shp.device)
+    ss['x'].copy_(shape_noise.to(shp.device).expand(ss['hi'] - ss['lo'], *shp.z_shape))
+    r = lay.T // shp.S
+    done = 0
+    if r >= 1 and use_graph:
+        key = (id(st['plan']), id(ss['plan']), r)
+        if getattr(shp, '_fused_key', None) != key:
+            shp._fused, shp._fused_key = combine_plans(shp.device, ss['plan'], st['plan'], side_repeat=r), key
+        st['step'].zero_()
+        shp._fused.sample(ss['step'], 0, shp.S, use_graph=True)
+        done = r * shp.S
+    else:
+        ss['plan'].sample(ss['step'], 0, shp.S, use_graph=use_graph)
+    if done < lay.T:
+        st['plan'].sample(st['step'], done, lay.T - done, use_graph=use_graph)
+    return st['x'].clone(), ss['x'].clone()
+
+
 class VQDecoder:
     """VQVAE.decode_no_quant on the HIP path: latents [O,3,16,16,16] -> SDF [O,1,64,64,64]
     (the once-per-sample epilogue of rel2shape, echo2shape.py:522).  Objects are decoded in chunks so

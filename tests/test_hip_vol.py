@@ -372,10 +372,9 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_OLD': '1'}, {'ES_CONV_WS': '0'}, {'ES_CONV_FORCE256': '1'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}])
 def test_conv_alternate_kernels(env):
-    """The conv dispatcher's other kernels (the general k_conv_mfma used for tensors beyond 31-bit byte offsets, the
-    non-specialised k_conv_lean for 256-row tiles) must give the same
+    """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced) must give the same
     results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
     (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
     1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
@@ -387,8 +386,7 @@ def test_conv_alternate_kernels(env):
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
     sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae or test_conv_ws_at'
-    if 'ES_CONV_OLD' not in env:                 # the general kernel has no stride-2-in-depth mode (raises, by design)
-        sel += ' or test_conv_down_dhw'
+    sel += ' or test_conv_down_dhw'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
                        env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

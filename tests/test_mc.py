@@ -67,9 +67,9 @@ def _compare(sdf_np, level):
         if ref['V']:
             from scipy.spatial import cKDTree
             a = v.cpu().numpy().astype(np.float64)
-            dist, idx = cKDTree(rv).query(a)
-            assert dist.max() < 2e-5, dist.max()
-            assert len(np.unique(idx)) == len(rv)
+            dist, _ = cKDTree(rv).query(a)
+            dist2, _ = cKDTree(a).query(rv)
+            assert dist.max() < 2e-5 and dist2.max() < 2e-5, (dist.max(), dist2.max())      # same set (counts are equal, above)
         assert abs(got['volume'] - ref['volume']) <= 1e-5 * max(1.0, abs(ref['volume']))
         assert abs(got['area'] - ref['area']) <= 1e-5 * max(1.0, ref['area'])
     return meshes

@@ -19,10 +19,11 @@ O = a.nodes
 net, lden, obj_embed, triples = bench.build_layout(dev, O, seed=100)
 
 
-def fake_gather(local, num_rows, world, group=None):
-    out = torch.zeros((num_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    out[:local.shape[0]] = local
-    return out
+def fake_gather(local, num_rows, world, group=None, out=None):
+    if out is None:
+        out = torch.zeros((max(num_rows, local.shape[0]),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out[:local.shape[0]].copy_(local)        # rank 0's block; the other ranks' rows stay as they are
+    return out[:num_rows]
 
 
 parallel.all_gather_rows = fake_gather
