@@ -49,14 +49,14 @@ def build_layout(dev, O, seed, graph_seed=None):
     return net, den, obj_embed, triples
 
 
-def build_shape(dev, O, seed, triples, rank=0, world=1):
+def build_shape(dev, O, seed, triples, rank=0, world=1, deterministic=True):
     from echoscene_amd import synth, config as escfg
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     conf = escfg.shape_df_conf(224)
     df = DiffusionUNet(conf.unet.params, conditioning_key='crossattn')
     synth.seeded_fill_(df, prefix='bench.shape.')
-    den = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev, rank=rank, world=world)
+    den = ShapeDenoiser(df, conf.model.params, ddim_steps=100, device=dev, rank=rank, world=world, deterministic=deterministic)
     uc = torch.randn(O, 1, 1280, generator=torch.Generator().manual_seed(seed + 1))
     return df, den, uc
 
@@ -178,6 +178,9 @@ def main():
     ap.add_argument('--scenes-per-gpu', type=int, default=2,
                     help='weak scaling: scenes per GPU (configs[4] is 8 per GPU; 2 keeps the default run inside ~20 GB)')
     ap.add_argument('--no-sub-records', action='store_true')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='N > 1, strong scaling: shards reproduce the single-GPU latents bit for bit (split-K / GroupNorm tiling chosen '
+                         'from the global object count); off = every rank tunes them to its own share (faster at few objects per GPU)')
     ap.add_argument('--fuse-loops', type=int, default=-1,
                     help='1: one hipGraph per full step with the layout step as a parallel branch of the shape step; 0: two streams; '
                          '-1: the default of this build')
@@ -228,7 +231,7 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world)
+        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=a.deterministic)
         noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
         sden.sample(uc, triples_all, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
@@ -332,7 +335,8 @@ def main():
                                                  'batch graph): no per-step collective' % (scenes_local, world)) if weak
                                           else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
                                                 '[O,64] codes every DDIM step over RCCL)' % world)),
-                           'scenes': scenes, 'hip_graph': use_graph, 'loops': ('one hipGraph per full step, layout step as a parallel branch '
+                           'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': bool(a.deterministic) if sh_world > 1 else None,
+                           'loops': ('one hipGraph per full step, layout step as a parallel branch '
                                                                               '(%.3f ms per step); layout / shape below: each loop alone' % (fused_ms / a.steps))
                            if fused_ms is not None else 'two HIP streams', 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
