@@ -307,6 +307,43 @@ __device__ __forceinline__ void split_range(int nks0, int kch2, int taps, int bz
     ks_end = ue <= U0 ? ue * unit : nks0 + (ue - U0);
 }
 
+
+// XCD-aware tile mapping, shared by the conv kernels.  The dispatcher places hardware workgroup id b on XCD b % 8 (observed,
+// speed only): taken literally, the 8 row tiles that share one weight slab (same column tile / K split) would sit on 8
+// different XCDs and every XCD's L2 would pull the whole weight matrix from HBM (measured: the 16x4x4 level ran at 300 GB/s of
+// weight traffic per XCD-copy, 6x off the MFMA time).  Remap (bijective for any grid size) so that each XCD owns a contiguous
+// range of logical ids L, then order the tiles along L by what the launch re-uses:
+//   3x3x3 convs (<= 3 column tiles): x (row tiles) fastest -- neighbours share the B slab and the A halo (adjacent depth
+//     slices) inside one L2;
+//   1x1x1 / linear launches with several column tiles (qkv: 6, FeedForward: 16-24): COLUMN tiles fastest inside panels of
+//     column tiles whose weight slabs fit an L2 together (~3 MiB), so the workgroups that run side by side on an XCD share ONE
+//     activation row tile and a resident weight panel.  With x fastest the 29 MB activation of the 16x8x8 FeedForward
+//     projection was re-fetched once per column tile: rocprofv3 FETCH_SIZE 364 MB per launch (x2-corrected), MFMA busy 0.20.
+__device__ __forceinline__ void conv_tile_of(const es_conv_args& a, int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nwg = gx * gy * (int)gridDim.z;
+    const int orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int per_z = gx * gy;
+    bz = L / per_z;
+    const int t = L - bz * per_z;
+    if (a.taps == 1 && gy >= 2) {
+        const long slab = ((long)a.Cin + (a.a2 ? a.Cin2 : 0)) * BN * 2;                 // bytes of one column tile's weights
+        int npanel = (int)(((long)gy * slab + (3L << 20) - 1) / (3L << 20));
+        npanel = npanel < 1 ? 1 : (npanel > gy ? gy : npanel);
+        const int Pw = (gy + npanel - 1) / npanel;                                      // column tiles per panel
+        const int full = gx * Pw;
+        const int p = t / full, rr = t - p * full;
+        const int w = (gy - p * Pw) < Pw ? (gy - p * Pw) : Pw;                          // the last panel may be narrower
+        bx = rr / w;
+        by = p * Pw + (rr - bx * w);
+    } else {
+        bx = t % gx;
+        by = t / gx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue shared by the conv kernels.
 // MFMA D layout: lane holds D[row = q*4 + r][col = i16].  A direct store is 112 four-byte stores (+112 residual
@@ -552,23 +589,8 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const long M = (long)g.O * g.D * g.H * g.W;
-    // XCD-aware tile mapping.  The dispatcher places hardware workgroup id b on XCD b % 8 (observed, speed only):
-    // taken literally, the 8 row tiles that share one weight slab (same column tile / K split) would sit on 8
-    // different XCDs and every XCD's L2 would pull the whole weight matrix from HBM (measured: the 16x4x4 level ran
-    // at 300 GB/s of weight traffic per XCD-copy, 6x off the MFMA time).  Remap (bijective for any grid size) so that
-    // each XCD owns a contiguous range of logical ids = x fastest: neighbours in x share the B slab and the
-    // A halo (adjacent depth slices) inside one L2.
     int bx, by, bz;
-    {
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = L % (int)gridDim.x;
-        const int t = L / (int)gridDim.x;
-        by = t % (int)gridDim.y;
-        bz = t / (int)gridDim.y;
-    }
+    conv_tile_of(a, bx, by, bz);                 // XCD-aware, re-use-aware tile order
     const long m0 = (long)bx * BM_;
     const int n0 = by * BN;
 
@@ -803,17 +825,8 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long M = (long)g.O * g.D * g.H * g.W;
-    int bx, by, bz;                              // XCD-aware tile mapping (see k_conv_lean)
-    {
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = L % (int)gridDim.x;
-        const int t = L / (int)gridDim.x;
-        by = t % (int)gridDim.y;
-        bz = t / (int)gridDim.y;
-    }
+    int bx, by, bz;
+    conv_tile_of(a, bx, by, bz);                 // XCD-aware, re-use-aware tile order
     const long m0 = (long)bx * BM_;
     const int n0 = by * BN;
     const int kch0 = a.Cin >> 5;

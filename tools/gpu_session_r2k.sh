@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r2k
+timeout 300 python tools/microbench_linear.py > gpurun_out/r2k/linear.log 2>&1
+timeout 1500 python -m pytest tests/test_hip_vol.py tests/test_hip_traj.py -m gpu -x -q > gpurun_out/r2k/tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/r2k/summary.txt
+timeout 600 python bench.py --no-cpu-baseline --no-sub-records > gpurun_out/r2k/bench.json 2> gpurun_out/r2k/bench.err
+cat gpurun_out/r2k/summary.txt; grep -v amdgpu gpurun_out/r2k/linear.log; tail -3 gpurun_out/r2k/tests.log; cut -c1-300 gpurun_out/r2k/bench.json

@@ -15,7 +15,7 @@ go = os.path.join(root, 'gpurun_out', *(sys.argv[2:3]))
 line = [l for l in open(os.path.join(go, 'bench_final.json')) if l.startswith('{')][-1]
 open(os.path.join(out, tag + '_bench_line.json'), 'w').write(line)
 bench = json.loads(line)
-ks = glob.glob(os.path.join(go, 'prof_final', '*', '*kernel_stats.csv'))[0]
+ks = (glob.glob(os.path.join(go, 'prof_final', '*', '*kernel_stats.csv')) + glob.glob(os.path.join(go, 'prof_final', '*kernel_stats.csv')))[0]
 shutil.copy(ks, os.path.join(out, tag + '_full_step_kernel_stats.csv'))
 
 
@@ -27,7 +27,7 @@ def short(n):
 rows = list(csv.DictReader(open(ks)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(go, 'pmc_final', '*', '*', '*counter_collection.csv')):
+for f in glob.glob(os.path.join(go, 'pmc_final', '*', '*', '*counter_collection.csv')) + glob.glob(os.path.join(go, 'pmc_final', '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         pmc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 md = ['# Round %s profile summary (MI355X, rocprofv3)\n' % tag[1:],
