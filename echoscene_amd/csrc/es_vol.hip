@@ -783,7 +783,8 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
 //
 // One s_barrier per K unit (32-channel chunk x tap, 16 KiB A + 16 KiB B), shared by both roles, 3-slot ring:
 //   producer:  wait(own pieces of unit ks) -> barrier -> issue unit ks+2 into the slot the consumers just released
-//   consumer:  barrier -> read fragments of unit ks -> 28 MFMAs
+//   consumer:  28 MFMAs of unit ks, with the barrier of unit ks+1 after the first MFMA row and the fragments of unit ks+1 read
+//              into the registers the MFMA stream has released (see the consumer loop)
 // Measured in round 2 and NOT kept (profiles/r02_notes.md): two K units per barrier with the second unit's fragments re-filled
 // after last use (341 -> 351 us on the 16^3 224->224 launch; the 3-tiles-in-flight variant of round 1 was equal too), and the A
 // tile shared by the three kw taps of a (chunk, kd, kh) group, i.e. A LDS-DMA / 3 (340 -> 360 us, commit 53fb667).  The
@@ -978,19 +979,47 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
     h8 af[MI], bfr[7];
     {
-        // (A half-step stagger of the two consumer waves of a SIMD -- one in its MFMA phase while the other waits for LDS --
-        //  needs the previous unit's fragments live across the barrier; under the 168-register cap the allocator spilled the
-        //  accumulators, so both consumers of a SIMD run in phase.)
-        const char* const As0 = smem, * const As1 = smem + STAGE_BYTES, * const As2 = smem + 2 * STAGE_BYTES;
-        int ks = 0;
-        while (true) {                           // (the host never launches an empty K range)
-            __builtin_amdgcn_s_barrier(); ws_read_frags<MI>(As0, fragA, fragB, af, bfr); ws_mma<MI>(acc, af, bfr);
-            if (++ks >= nloc) break;
-            __builtin_amdgcn_s_barrier(); ws_read_frags<MI>(As1, fragA, fragB, af, bfr); ws_mma<MI>(acc, af, bfr);
-            if (++ks >= nloc) break;
-            __builtin_amdgcn_s_barrier(); ws_read_frags<MI>(As2, fragA, fragB, af, bfr); ws_mma<MI>(acc, af, bfr);
-            if (++ks >= nloc) break;
+        // Software pipeline WITHOUT a second fragment buffer (112 accumulators + 44 fragment registers is all the 168-register
+        // cap of 12 waves per CU allows): the fragments of unit ks+1 are read INTO THE REGISTERS OF UNIT ks as the MFMA
+        // stream releases them -- A row i-1 while row i multiplies, B column j right after its last use in the last row.
+        // The barrier that publishes unit ks+1 therefore sits after the first MFMA row of unit ks (all reads of slot ks are
+        // waited for there), and the LDS reads of a unit (11 x ds_read_b128 per wave, ~350 LDS-array cycles per CU and unit)
+        // run under the matrix pipe instead of in front of it.  A/B on one box (ES_CONV_PIPE, since removed): 3x3x3 launches
+        // -2.5 ... -3.2 % (319 -> 311 us at 16^3 224->224, 283 -> 275 and 409 -> 396 us at 16x8x8), 14-unit 1x1 launches +1 %.
+        int slot = 0;
+        __builtin_amdgcn_s_barrier();                                           // unit 0 published
+        ws_read_frags<MI>(smem, fragA, fragB, af, bfr);
+        for (int ks = 0; ks + 1 < nloc; ++ks) {
+            slot = slot == NS - 1 ? 0 : slot + 1;
+            const char* const An = smem + slot * STAGE_BYTES;                     // slot of unit ks + 1
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfr[j], acc[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the last A fragment of unit ks (requested after the B's) is in
+            __builtin_amdgcn_s_barrier();                                       // unit ks + 1 published; slot of unit ks released
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 1; i < MI; ++i) {
+                af[i - 1] = *(const h8*)(An + fragA + (i - 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < MI - 1) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[j] = *(const h8*)(An + fragB + j * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            af[MI - 1] = *(const h8*)(An + fragA + (MI - 1) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        ws_mma<MI>(acc, af, bfr);                                               // last unit
     }
     conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
