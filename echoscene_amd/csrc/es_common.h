@@ -35,3 +35,18 @@ __device__ __forceinline__ float es_silu(float x) { return x * __frcp_rn(1.0f + 
 __device__ __forceinline__ float es_silu_fast(float x) { return x / (1.0f + __expf(-x)); } // volume path (fp16 operands follow)
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float es_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for the volume path (the result is rounded to fp16 right after): erfc(|x|/sqrt 2) by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7), evaluated on the side where it does not cancel: gelu(x) = x < 0 ? x E / 2 : x - x E / 2.  Max abs error
+// 2.2e-7 over [-12, 12] (tests/test_hip_vol.py); ~14 VALU ops instead of erff's ~40 with divergent branches -- the exact
+// version cost ~9 us of the ~27 us a 256 x 224 FeedForward tile took (56 evaluations per lane).
+__device__ __forceinline__ float es_gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(__fmaf_rn(0.3275911f, z, 1.0f));
+    float pl = __fmaf_rn(t, 1.061405429f, -1.453152027f);
+    pl = __fmaf_rn(t, pl, 1.421413741f);
+    pl = __fmaf_rn(t, pl, -0.284496736f);
+    pl = __fmaf_rn(t, pl, 0.254829592f);
+    const float E = pl * t * __expf(-z * z);
+    const float h = 0.5f * x * E;
+    return x < 0.f ? h : x - h;
+}

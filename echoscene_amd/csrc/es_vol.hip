@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
             for (int e = 0; e < 4; ++e) {
                 float t0 = y0[e], t1 = y1[e];
                 if (a.silu == 1) { t0 = es_silu_fast(t0); t1 = es_silu_fast(t1); }
-                else if (a.silu == 2) { t0 = es_gelu(t0); t1 = es_gelu(t1); }
+                else if (a.silu == 2) { t0 = es_gelu_fast(t0); t1 = es_gelu_fast(t1); }
                 y[e] = (_Float16)t0; y[4 + e] = (_Float16)t1;
                 r[e] = (_Float16)x0[e]; r[4 + e] = (_Float16)x1[e];
             }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_geglu(const es_geglu_args a) {
         const f4 x = *(const f4*)p, g = *(const f4*)(p + a.C4);
         h4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * es_gelu(g[e]));
+        for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * es_gelu_fast(g[e]));
         *(h4*)((_Float16*)a.out_f16 + m * a.C4 + c) = y;
     }
 }
@@ -397,7 +397,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                         const f4 gt = *(const f4*)&gslab[row * 116 + c4 * 4] + *(const f4*)&a.bias[n0 + 112 + c4 * 4];
                         h4 hv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] * es_gelu(gt[e]));
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] * es_gelu_fast(gt[e]));
                         *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + oc0 + c4 * 4) = hv;
                     }
                 }

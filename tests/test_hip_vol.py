@@ -141,6 +141,25 @@ def test_groupnorm_layernorm_geglu_tocl(dev):
     assert _rel(xcl[:, :3], _cl(xin)) < 1e-3 and xcl[:, 3:].abs().max() == 0
 
 
+def test_gelu_of_the_volume_path_over_its_whole_range(dev):
+    """es_gelu_fast (erfc by Abramowitz-Stegun 7.1.26 on the non-cancelling side; FeedForward GEGLU, reference attention.py:39-46
+    uses F.gelu = exact erf): gate values on a grid over [-12, 12] with value 1 -> the fp16 output IS gelu(gate).  Bound: one fp16
+    rounding of the exact value plus 1e-6 absolute (the approximation's own error is 2.2e-7)."""
+    from echoscene_amd.plan import Builder
+    M, C = 64, 256
+    gate = torch.linspace(-12, 12, M * C).reshape(M, C)
+    hg = torch.cat([torch.ones(M, C), gate], 1).contiguous()
+    b = Builder(dev)
+    y = b.buf(M, C, dtype=torch.float16, zero=True)
+    b.geglu(b.dev(hg), M, C, y)
+    b.finish().run()
+    torch.cuda.synchronize()
+    ref = F.gelu(gate.double())
+    err = (y.double().cpu() - ref).abs()
+    bound = ref.abs() * 2.0 ** -10 + 1e-6 + 6e-8
+    assert bool((err <= bound).all()), 'max excess %.3e' % (err - bound).max().item()
+
+
 @pytest.mark.parametrize('Ntok,heads,dh', [(256, 8, 12), (1024, 2, 56), (256, 2, 84), (100, 3, 8)])
 def test_attention(dev, Ntok, heads, dh):
     from echoscene_amd.plan import Builder
