@@ -378,6 +378,16 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
         const float* vslab = (const float*)smem + (wave & ~1) * (16 * 116);    // value slab (wn = 0 wave of the pair)
         const float* gslab = vslab + 16 * 116;                                  // gate slab (wn = 1)
         const int oc0 = n0 >> 1;                              // output column of this tile's first value column
+        // bias goes into the accumulators first (a lane's column of tile j is fixed: 7 loads per tile, one round trip) -- the
+        // combine loop below used to fetch two bias quads per item behind the LDS reads, 8 dependent global loads per slab
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float bj = a.bias[n0 + wn * 112 + j * 16 + i16];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bj;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -393,8 +403,8 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                     const int row = idx / 28 + 8 * wn, c4 = idx % 28;
                     const long m = m0 + wm * WROWS + i * 16 + row;
                     if (m < M) {
-                        const f4 v = *(const f4*)&vslab[row * 116 + c4 * 4] + *(const f4*)&a.bias[n0 + c4 * 4];
-                        const f4 gt = *(const f4*)&gslab[row * 116 + c4 * 4] + *(const f4*)&a.bias[n0 + 112 + c4 * 4];
+                        const f4 v = *(const f4*)&vslab[row * 116 + c4 * 4];
+                        const f4 gt = *(const f4*)&gslab[row * 116 + c4 * 4];
                         h4 hv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] * es_gelu_fast(gt[e]));
@@ -1030,127 +1040,173 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_K = 64;
 
-// DP: padded head dim 32, 64, 96 or 256 (VQ-VAE AttnBlock: one head of 256).  NWV waves x 16 query rows per workgroup:
-// 8 waves (128 rows) for long sequences halve the K/V staging traffic per query.
-template <int DP, int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_attention(const es_attn_args a) {
-    constexpr int AT_Q = 16 * NWV;
+// DP: padded head dim 32, 64, 96 or 256 (VQ-VAE AttnBlock: one head of 256).  A wave owns NRT x 16 query rows, a workgroup
+// NWV waves: 128 rows for long sequences (every K / V fragment read from LDS feeds NRT MFMAs; three workgroups per CU).
+//
+// Both products are computed TRANSPOSED so that the probabilities never leave the registers:
+//   S^T = K Q^T   (A = K fragment, B = Q fragment): a lane holds S^T[key = t*16 + q*4 + r][row = i16] -- ONE query row per lane,
+//                 16 of its 64 keys; the row max / sum are 16 in-lane operations + two cross-lane steps (xor 16, 32);
+//   O^T = V^T P^T (A = V^T fragment, B = P^T): MFMA k-slot (q, e) of chunk kc is fed with key kc*32 + (e < 4 ? 0 : 16) + q*4 + (e & 3)
+//                 on BOTH operands -- exactly the keys the lane already holds for its row (the contraction does not care about
+//                 the order of the keys), so P^T is a register pack, and V^T comes as two 8-byte LDS reads per fragment.
+//   The lane then holds O[row = i16][d = j*16 + q*4 + r]: the online-softmax rescale is a per-lane scalar and the output store
+//   is 8 bytes per lane.
+// Round 1 / early round 2 wrote P to LDS in A-fragment order (16 ds_write_b16 + 2 ds_read_b128 per wave and K tile -- as many
+// LDS cycles as all K / V fragment reads together; rocprofv3: LDS active 0.57 of CU-cycles, MFMA busy 0.11).
+template <int DP, int NWV, int NRT>
+__global__ __launch_bounds__(64 * NWV, DP <= 64 ? 3 : 2) void k_attention(const es_attn_args a) {   // DP <= 64: <= 168 registers, three 4-wave workgroups per CU
+    constexpr int AT_Q = 16 * NRT * NWV;
     constexpr int KLD = DP + 8;              // halfs; +8 keeps 16-B alignment and skews banks
     constexpr int VLD = AT_K + 8;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[AT_K * KLD];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[DP * VLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Ps[NWV][16 * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int C = a.heads * a.dhead, ldq = 3 * C;
     const _Float16* base = (const _Float16*)a.qkv + (long)b * a.Ntok * ldq + h * a.dhead;
-    const int q0 = blockIdx.x * AT_Q + wave * 16;
+    const int q0 = blockIdx.x * AT_Q + wave * (16 * NRT);
 
-    // Q fragments for this wave's 16 rows: A[i=row][k=d], lane holds d = q4*8.. +7 of each 32-chunk
-    h8 qf[DP / 32];
+    // Q fragments: lane (i16, q4) holds d = kc*32 + q4*8 .. +7 of query row q0 + rt*16 + i16 (the B operand of S^T)
+    h8 qf[NRT][DP / 32];
 #pragma unroll
-    for (int kc = 0; kc < DP / 32; ++kc) {
-        const int d0 = kc * 32 + q4 * 8;
-        const _Float16* p = base + (long)(q0 + i16) * ldq + d0;
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[kc][e] = (d0 + e < a.dhead && q0 + i16 < a.Ntok) ? p[e] : (_Float16)0.f;
+        for (int kc = 0; kc < DP / 32; ++kc) {
+            const int d0 = kc * 32 + q4 * 8, row = q0 + rt * 16 + i16;
+            const _Float16* p = base + (long)row * ldq + d0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[rt][kc][e] = (d0 + e < a.dhead && row < a.Ntok) ? p[e] : (_Float16)0.f;
+        }
+    f4 oacc[NRT][DP / 16];
+    float mrow[NRT], lrow[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        mrow[rt] = -INFINITY; lrow[rt] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DP / 16; ++j) oacc[rt][j] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    f4 oacc[DP / 16];
-#pragma unroll
-    for (int j = 0; j < DP / 16; ++j) oacc[j] = f4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
 
-    for (int k0 = 0; k0 < a.Ntok; k0 += AT_K) {
-        __syncthreads();
-        // stage K [64][DP] and V^T [DP][64]; 4-half (8 B) granularity (dhead % 4 == 0).  Consecutive lanes take
-        // consecutive KEYS of one 4-channel chunk: the transposed V writes are then consecutive halfs (the other
-        // assignment, consecutive channel chunks, put 64 lanes on 4 banks: 16-way conflicts on every ds_write_b16).
-        for (int idx = tid; idx < AT_K * (DP / 4); idx += 64 * NWV) {
+    // K / V tiles are fetched one tile AHEAD into registers (8-byte items; consecutive lanes take consecutive KEYS of one
+    // 4-channel chunk, so the transposed V writes below are consecutive halfs -- the other assignment put 64 lanes on 4 banks)
+    // and written to LDS after the current tile's readers are done: the global-load round trip used to sit in front of every
+    // tile (load -> wait -> LDS write -> barrier -> 16 MFMAs per wave -> barrier, ~4 us per tile, one resident workgroup per CU).
+    constexpr int NT = 64 * NWV, NITEM = AT_K * (DP / 4), NIT = (NITEM + NT - 1) / NT;
+    constexpr bool PREFETCH = DP <= 96;                      // (DP = 256, the VQ-VAE block: 16 items per thread would not fit; load in place)
+    h4 kreg[NIT], vreg[NIT];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT;
             const int key = idx & (AT_K - 1), d = (idx >> 6) * 4;
-            h4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-            if (d < a.dhead && k0 + key < a.Ntok) {
+            kreg[it] = h4{0, 0, 0, 0}; vreg[it] = h4{0, 0, 0, 0};
+            if (idx < NITEM && d < a.dhead && k0 + key < a.Ntok) {
                 const _Float16* p = base + (long)(k0 + key) * ldq + d;
-                kv = *(const h4*)(p + C);
-                vv = *(const h4*)(p + 2 * C);
+                kreg[it] = *(const h4*)(p + C);
+                vreg[it] = *(const h4*)(p + 2 * C);
             }
-            *(h4*)&Ks[key * KLD + d] = kv;
+        }
+    };
+    if (PREFETCH) gload(0);
+    for (int k0 = 0; k0 < a.Ntok; k0 += AT_K) {
+        __syncthreads();                                      // the previous tile's fragment reads are done
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Vt[(d + e) * VLD + key] = vv[e];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < NITEM) {
+                const int key = idx & (AT_K - 1), d = (idx >> 6) * 4;
+                h4 kv = kreg[PREFETCH ? it : 0], vv = vreg[PREFETCH ? it : 0];
+                if (!PREFETCH) {                             // load in place, one item at a time
+                    kv = h4{0, 0, 0, 0}; vv = h4{0, 0, 0, 0};
+                    if (d < a.dhead && k0 + key < a.Ntok) {
+                        const _Float16* p = base + (long)(k0 + key) * ldq + d;
+                        kv = *(const h4*)(p + C);
+                        vv = *(const h4*)(p + 2 * C);
+                    }
+                }
+                *(h4*)&Ks[key * KLD + d] = kv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Vt[(d + e) * VLD + key] = vv[e];
+            }
         }
         __syncthreads();
-        // S = Q K^T  (16 x 64 per wave): B[k=d][j=key] = K[key][d]
-        f4 s[4];
+        if (PREFETCH && k0 + AT_K < a.Ntok) gload(k0 + AT_K); // in flight under this tile's MFMAs
+        // S^T = K Q^T (64 keys x 16 rows per row tile)
+        f4 s[NRT][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s[t] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int kc = 0; kc < DP / 32; ++kc) {
-                const h8 kf = *(const h8*)&Ks[(t * 16 + i16) * KLD + kc * 32 + q4 * 8];
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[kc], kf, s[t], 0, 0, 0);
-            }
-        }
-        // online softmax; lane holds S[row = q4*4 + r][key = t*16 + i16]
-        float alpha[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s[t][r] = (k0 + t * 16 + i16 < a.Ntok) ? s[t][r] * a.scale : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-            const float mnew = fmaxf(mrow[r], mx);
-            alpha[r] = __expf(mrow[r] - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { const float p = __expf(s[t][r] - mnew); s[t][r] = p; ps += p; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 16);
-            lrow[r] = lrow[r] * alpha[r] + ps;
-            mrow[r] = mnew;
-        }
-        // P (fp16) through LDS into A-fragment order; rescale O
+            for (int t = 0; t < 4; ++t) s[rt][t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[wave][(q4 * 4 + r) * VLD + t * 16 + i16] = (_Float16)s[t][r];
+            for (int kc = 0; kc < DP / 32; ++kc) {
+                const h8 kf = *(const h8*)&Ks[(t * 16 + i16) * KLD + kc * 32 + q4 * 8];
 #pragma unroll
-        for (int j = 0; j < DP / 16; ++j)
+                for (int rt = 0; rt < NRT; ++rt) s[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[rt][kc], s[rt][t], 0, 0, 0);
+            }
+        // online softmax of the lane's row; lane holds keys k0 + t*16 + q4*4 + r
+        h8 pf[NRT][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oacc[j][r] *= alpha[r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own LDS writes visible to own wave
-        __builtin_amdgcn_wave_barrier();
-        // O += P V : A[i=row][k=key], B[k=key][j=d] = Vt[d][key]
+        for (int rt = 0; rt < NRT; ++rt) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kc = 0; kc < AT_K / 32; ++kc) {
-            const h8 pf = *(const h8*)&Ps[wave][i16 * VLD + kc * 32 + q4 * 8];
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[rt][t][r] = (k0 + t * 16 + q4 * 4 + r < a.Ntok) ? s[rt][t][r] * a.scale : -INFINITY;
+                    mx = fmaxf(mx, s[rt][t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrow[rt], mx);
+            const float alpha = __expf(mrow[rt] - mnew);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float p = __expf(s[rt][t][r] - mnew); s[rt][t][r] = p; ps += p; }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            lrow[rt] = lrow[rt] * alpha + ps;
+            mrow[rt] = mnew;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[rt][kc][e] = (_Float16)s[rt][2 * kc + (e >> 2)][e & 3];
+#pragma unroll
+            for (int j = 0; j < DP / 16; ++j) oacc[rt][j] *= alpha;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int kc = 0; kc < AT_K / 32; ++kc)
 #pragma unroll
             for (int j = 0; j < DP / 16; ++j) {
-                const h8 vf = *(const h8*)&Vt[(j * 16 + i16) * VLD + kc * 32 + q4 * 8];
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, oacc[j], 0, 0, 0);
+                const _Float16* vp = &Vt[(j * 16 + i16) * VLD + kc * 32 + q4 * 4];
+                const h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 16);
+                const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) oacc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rt][kc], oacc[rt][j], 0, 0, 0);
+            }
+    }
+    // write O / l : lane holds O[row = i16 of the row tile][d = j*16 + q4*4 + r]
+    _Float16* out = (_Float16*)a.out_f16 + (long)b * a.Ntok * C + h * a.dhead;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int row = q0 + rt * 16 + i16;
+        if (row >= a.Ntok) continue;
+        const float inv = 1.0f / lrow[rt];
+#pragma unroll
+        for (int j = 0; j < DP / 16; ++j) {
+            const int d = j * 16 + q4 * 4;
+            if (d < a.dhead) {
+                const f4 o = oacc[rt][j] * inv;
+                const h4 hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *(h4*)&out[(long)row * C + d] = hv;
             }
         }
     }
-    // write O / l : lane holds O[row = q4*4 + r][d = j*16 + i16]
-    _Float16* out = (_Float16*)a.out_f16 + (long)b * a.Ntok * C + h * a.dhead;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = q0 + q4 * 4 + r;
-        if (row >= a.Ntok) continue;
-        const float inv = 1.0f / lrow[r];
-#pragma unroll
-        for (int j = 0; j < DP / 16; ++j) {
-            const int d = j * 16 + i16;
-            if (d < a.dhead) out[(long)row * C + d] = (_Float16)(oacc[j][r] * inv);
-        }
-    }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Direct 3x3x3 conv for N <= 4 output channels (final eps conv 224->3, VQ-VAE conv_out 64->1):
@@ -1399,6 +1455,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
+            set((const void*)k_conv_ws<128, 4, 2, false>, LDS128);
+            set((const void*)k_conv_ws<128, 4, 2, true>, LDS128);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
@@ -1453,6 +1511,13 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         else hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
     } else if (wg128 >= 512 || S > 1) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
+        static const char* ws128_env = getenv("ES_CONV_WS128");   // A/B switch: producer/consumer kernel for the 128-row tiles too
+        const bool ws128_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
+                              M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) && a->epilogue == ES_EPI_NONE;
+        if (ws128_env && atoi(ws128_env) == 1 && ws128_ok) {
+            if (upm) hipLaunchKernelGGL((k_conv_ws<128, 4, 2, true>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
+            else hipLaunchKernelGGL((k_conv_ws<128, 4, 2, false>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
+        } else
         if (upm) hipLaunchKernelGGL((k_conv_lean<128, 4, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
     } else {
@@ -1497,13 +1562,14 @@ extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
 
 extern "C" int es_attention_f16(const es_attn_args* a, es_stream stream) {
     ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 256 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 256)", a->dhead);
-    const bool big = a->Ntok >= 512 && a->dhead <= 96;       // 128 query rows per workgroup
-    dim3 grid((a->Ntok + (big ? 128 : 64) - 1) / (big ? 128 : 64), a->B * a->heads);
+    const bool big = a->Ntok >= 512 && a->dhead <= 96;       // 128 query rows per workgroup (4 waves x 2 row tiles), else 64 (4 x 1)
+    const int rows = big ? 128 : 64;
+    dim3 grid((a->Ntok + rows - 1) / rows, a->B * a->heads);
     hipStream_t st = (hipStream_t)stream;
-    if (a->dhead <= 32) { if (big) hipLaunchKernelGGL((k_attention<32, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<32, 4>), grid, dim3(256), 0, st, *a); }
-    else if (a->dhead <= 64) { if (big) hipLaunchKernelGGL((k_attention<64, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<64, 4>), grid, dim3(256), 0, st, *a); }
-    else if (a->dhead <= 96) { if (big) hipLaunchKernelGGL((k_attention<96, 8>), grid, dim3(512), 0, st, *a); else hipLaunchKernelGGL((k_attention<96, 4>), grid, dim3(256), 0, st, *a); }
-    else hipLaunchKernelGGL((k_attention<256, 4>), grid, dim3(256), 0, st, *a);
+    if (a->dhead <= 32) { if (big) hipLaunchKernelGGL((k_attention<32, 4, 2>), grid, dim3(256), 0, st, *a); else hipLaunchKernelGGL((k_attention<32, 4, 1>), grid, dim3(256), 0, st, *a); }
+    else if (a->dhead <= 64) { if (big) hipLaunchKernelGGL((k_attention<64, 4, 2>), grid, dim3(256), 0, st, *a); else hipLaunchKernelGGL((k_attention<64, 4, 1>), grid, dim3(256), 0, st, *a); }
+    else if (a->dhead <= 96) { if (big) hipLaunchKernelGGL((k_attention<96, 4, 2>), grid, dim3(256), 0, st, *a); else hipLaunchKernelGGL((k_attention<96, 4, 1>), grid, dim3(256), 0, st, *a); }
+    else hipLaunchKernelGGL((k_attention<256, 4, 1>), grid, dim3(256), 0, st, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

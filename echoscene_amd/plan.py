@@ -708,3 +708,8 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     b.linear([seg(h_segs[0])], w.out_conv, O, View(eps_out), prologue=hip.PRO_GN_SILU, gamma=w.out_gn[0],
              beta=w.out_gn[1], eps=1e-5)
     return objbuf
+
+
+# the volume-path ops (conv, groupnorm, attention, ...) are attached to Builder by plan_vol; importing it here makes
+# `from echoscene_amd.plan import Builder` complete on its own (a test that ran alone found Builder without them)
+from . import plan_vol  # noqa: E402,F401

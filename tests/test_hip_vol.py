@@ -163,6 +163,7 @@ def test_gelu_of_the_volume_path_over_its_whole_range(dev):
 @pytest.mark.parametrize('Ntok,heads,dh', [(256, 8, 12), (1024, 2, 56), (256, 2, 84), (100, 3, 8)])
 def test_attention(dev, Ntok, heads, dh):
     from echoscene_amd.plan import Builder
+    import echoscene_amd.plan_vol  # noqa: F401  (attaches the volume ops to Builder)
     B, Cc = 2, heads * dh
     qkv = (_rnd((B, Ntok, 3 * Cc), 1) * 1.5).half()
     q, k, v = qkv.float().chunk(3, -1)

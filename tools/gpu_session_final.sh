@@ -1,0 +1,13 @@
+#!/bin/bash
+# full GPU test suite, smoke, then the profile collection of the round
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=gpurun_out/${1:-final}
+mkdir -p $OUT
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1
+echo "gpu tests rc=$?" > $OUT/summary.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
+echo "smoke rc=$?" >> $OUT/summary.txt
+timeout 300 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
+bash tools/gpu_session_profile.sh ${1:-final}
+cat $OUT/summary.txt; tail -3 $OUT/tests_gpu.log; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -4

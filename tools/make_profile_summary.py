@@ -31,14 +31,14 @@ for f in glob.glob(os.path.join(go, 'pmc_final', '*', '*', '*counter_collection.
     for r in csv.DictReader(open(f)):
         pmc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
 md = ['# Round %s profile summary (MI355X, rocprofv3)\n' % tag[1:],
-      '* `%s_bench_line.json` -- `python bench.py --steps 100 --warmup 5`: **%.2f full steps/s** (shape %.2f ms + layout %.3f ms per step, '
-      'two HIP streams), CPU oracle baseline %.5f steps/s on %d host threads; `roofline.achieved` %.1f TFLOP/s for `k_conv_ws` '
+      '* `%s_bench_line.json` -- `python bench.py --steps 100 --warmup 5`: **%.2f full steps/s** (one replayed hipGraph per full step, the layout step '
+      'as a parallel branch of the shape step; each loop alone: shape %.2f ms, layout %.3f ms per step), CPU oracle baseline %.5f steps/s on %d host threads; `roofline.achieved` %.1f TFLOP/s for `k_conv_ws` '
       '(avg launch %.1f us, %d launches per step).' % (
           tag, bench['value'], bench['config']['shape']['ms_per_step'], bench['config']['layout']['ms_per_step'],
           bench['cpu_baseline']['value'], bench['cpu_baseline']['cores'], bench['roofline']['achieved'],
           bench['roofline'].get('avg_launch_us') or 0, bench['roofline'].get('launches_per_step') or 0),
       '* `%s_full_step_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` '
-      '(both loops; 23 executions of the shape step, 23+ of the layout step).' % tag,
+      '(23 executions of the fused step, plus the stand-alone loops bench.py times for its per-loop record).' % tag,
       '* PMC: separate `rocprofv3 --kernel-trace --pmc <set>` passes of `python bench.py --steps 6 --warmup 2 --no-cpu-baseline` '
       '(FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY).\n',
       '| kernel | calls | avg us | % of GPU time | FETCH_SIZE KB/launch (raw; gfx950 reports 1/2 of wide streaming reads) | WRITE_SIZE KB/launch | MFMA busy / (GUI_ACTIVE/8 x 1024 SIMDs) | LDS active / CU-cycles | wave-cycles waiting |',

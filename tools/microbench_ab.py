@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CASES = [('3x3x3 224->224 @16^3', 32, (16, 16, 16), 224, 224, 27, 'res'), ('3x3x3 448->448 @16x8x8', 32, (16, 8, 8), 448, 448, 27, 'res'),
          ('3x3x3 672->448 @16x8x8', 32, (16, 8, 8), 672, 448, 27, 'res'), ('qkv 448->1344 @16x8x8', 32, (16, 8, 8), 448, 1344, 1, 'f16'),
          ('ff2 1792->448 @16x8x8', 32, (16, 8, 8), 1792, 448, 1, 'res'), ('ff1 GEGLU 448->3584 @16x8x8', 32, (16, 8, 8), 448, 3584, 1, 'geglu'),
-         ('ff1 GEGLU 672->5376 @16x4x4', 32, (16, 4, 4), 672, 5376, 1, 'geglu')]
+         ('ff1 GEGLU 672->5376 @16x4x4', 32, (16, 4, 4), 672, 5376, 1, 'geglu'),
+         ('3x3x3 672->672 @16x4x4', 32, (16, 4, 4), 672, 672, 27, 'res'), ('3x3x3 1344->672 @16x4x4', 32, (16, 4, 4), 1344, 672, 27, 'res')]
 
 
 def child():
