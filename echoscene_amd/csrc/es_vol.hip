@@ -1048,7 +1048,8 @@ constexpr int AT_K = 64;
 //                 16 of its 64 keys; the row max / sum are 16 in-lane operations + two cross-lane steps (xor 16, 32);
 //   O^T = V^T P^T (A = V^T fragment, B = P^T): MFMA k-slot (q, e) of chunk kc is fed with key kc*32 + (e < 4 ? 0 : 16) + q*4 + (e & 3)
 //                 on BOTH operands -- exactly the keys the lane already holds for its row (the contraction does not care about
-//                 the order of the keys), so P^T is a register pack, and V^T comes as two 8-byte LDS reads per fragment.
+//                 the order of the keys), so P^T is a register pack, and V^T comes as two transposing 8-byte LDS reads
+//                 (ds_read_b64_tr_b16) of the row-major V tile per fragment.
 //   The lane then holds O[row = i16][d = j*16 + q*4 + r]: the online-softmax rescale is a per-lane scalar and the output store
 //   is 8 bytes per lane.
 // Round 1 / early round 2 wrote P to LDS in A-fragment order (16 ds_write_b16 + 2 ds_read_b128 per wave and K tile -- as many
@@ -1057,9 +1058,8 @@ template <int DP, int NWV, int NRT, int MINW = (DP <= 64 ? 3 : 2)>
 __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args a) {   // DP <= 64: <= 168 registers, three 4-wave workgroups per CU
     constexpr int AT_Q = 16 * NRT * NWV;
     constexpr int KLD = DP + 8;              // halfs; +8 keeps 16-B alignment and skews banks
-    constexpr int VLD = AT_K + 8;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[AT_K * KLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Vt[DP * VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[AT_K * KLD];      // V row-major like K; transposed by the read (below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
     // XCD-aware order (hardware workgroup id b runs on XCD b % 8; same bijective remap as conv_tile_of): each XCD owns a contiguous
@@ -1096,18 +1096,19 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
         for (int j = 0; j < DP / 16; ++j) oacc[rt][j] = f4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // K / V tiles are fetched one tile AHEAD into registers (8-byte items; consecutive lanes take consecutive KEYS of one
-    // 4-channel chunk, so the transposed V writes below are consecutive halfs -- the other assignment put 64 lanes on 4 banks)
-    // and written to LDS after the current tile's readers are done: the global-load round trip used to sit in front of every
-    // tile (load -> wait -> LDS write -> barrier -> 16 MFMAs per wave -> barrier, ~4 us per tile, one resident workgroup per CU).
-    constexpr int NT = 64 * NWV, NITEM = AT_K * (DP / 4), NIT = (NITEM + NT - 1) / NT;
+    // K / V tiles are fetched one tile AHEAD into registers and written to LDS after the current tile's readers are done: the
+    // global-load round trip used to sit in front of every tile.  Items are 8 bytes with the CHANNEL chunk fastest across lanes:
+    // a wave's load covers whole key rows (coalesced) and both tiles are stored row-major -- V is not transposed on the way in
+    // (the first versions scattered it with four ds_write_b16 per item, which forced lanes along keys and 64 cache lines per load
+    // instruction); the PV step reads it through ds_read_b64_tr_b16 instead.
+    constexpr int NT = 64 * NWV, CPR = DP / 4, NITEM = AT_K * CPR, NIT = (NITEM + NT - 1) / NT;
     constexpr bool PREFETCH = DP <= 96;                      // (DP = 256, the VQ-VAE block: 16 items per thread would not fit; load in place)
     h4 kreg[NIT], vreg[NIT];
     auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT;
-            const int key = idx & (AT_K - 1), d = (idx >> 6) * 4;
+            const int key = idx / CPR, d = (idx - key * CPR) * 4;
             kreg[it] = h4{0, 0, 0, 0}; vreg[it] = h4{0, 0, 0, 0};
             if (idx < NITEM && d < a.dhead && k0 + key < a.Ntok) {
                 const _Float16* p = base + (long)(k0 + key) * ldq + d;
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT;
             if (idx < NITEM) {
-                const int key = idx & (AT_K - 1), d = (idx >> 6) * 4;
+                const int key = idx / CPR, d = (idx - key * CPR) * 4;
                 h4 kv = kreg[PREFETCH ? it : 0], vv = vreg[PREFETCH ? it : 0];
                 if (!PREFETCH) {                             // load in place, one item at a time
                     kv = h4{0, 0, 0, 0}; vv = h4{0, 0, 0, 0};
@@ -1134,8 +1135,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
                     }
                 }
                 *(h4*)&Ks[key * KLD + d] = kv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Vt[(d + e) * VLD + key] = vv[e];
+                *(h4*)&Vs[key * KLD + d] = vv;
             }
         }
         __syncthreads();
@@ -1156,7 +1156,11 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
             }
         // online softmax of the lane's row, in the exp2 domain (scale * log2 e folded into one multiply); lane holds keys
         // k0 + t*16 + q4*4 + r; only the last tile can hold keys >= Ntok
+        // The kernel is VALU-bound here (~130 scalar-width operations per row tile and K tile against 16 MFMAs): the row maximum
+        // is taken over the RAW scores (scale > 0), scale * log2 e and the subtraction of the maximum are one packed FMA per two
+        // keys, sums and the rescale of O are packed too, and O is only rescaled when some row's maximum moved.
         h8 pf[NRT][2];
+        typedef float f2 __attribute__((ext_vector_type(2)));
         const float c2 = a.scale * 1.44269504088896340736f;
         const bool ragged = k0 + AT_K > a.Ntok;              // wave-uniform
 #pragma unroll
@@ -1166,38 +1170,55 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = s[rt][t][r] * c2;
-                    if (ragged && k0 + t * 16 + q4 * 4 + r >= a.Ntok) v = -INFINITY;
-                    s[rt][t][r] = v;
-                    mx = fmaxf(mx, v);
+                    if (ragged && k0 + t * 16 + q4 * 4 + r >= a.Ntok) s[rt][t][r] = -INFINITY;
+                    mx = fmaxf(mx, s[rt][t][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrow[rt], mx);
+            const float mnew = fmaxf(mrow[rt], mx * c2);     // running maximum, exp2 domain
             const float alpha = __builtin_amdgcn_exp2f(mrow[rt] - mnew);
-            float ps = 0.f;
+            const f2 c22 = {c2, c2}, nm2 = {-mnew, -mnew};
+            f2 ps2 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[rt][t][r] - mnew); s[rt][t][r] = p; ps += p; }
+                for (int hf = 0; hf < 2; ++hf) {
+                    const f2 v = {s[rt][t][2 * hf], s[rt][t][2 * hf + 1]};
+                    const f2 e = __builtin_elementwise_fma(v, c22, nm2);
+                    const f2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    ps2 += pp;
+                    pf[rt][t >> 1][(t & 1) * 4 + 2 * hf] = (_Float16)pp[0];
+                    pf[rt][t >> 1][(t & 1) * 4 + 2 * hf + 1] = (_Float16)pp[1];
+                }
+            float ps = ps2[0] + ps2[1];
             ps += __shfl_xor(ps, 16);
             ps += __shfl_xor(ps, 32);
             lrow[rt] = lrow[rt] * alpha + ps;
             mrow[rt] = mnew;
+            if (__ballot(alpha != 1.0f) != 0) {              // some row's maximum moved: rescale O (wave-uniform branch)
+                const f2 al2 = {alpha, alpha};
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[rt][kc][e] = (_Float16)s[rt][2 * kc + (e >> 2)][e & 3];
-#pragma unroll
-            for (int j = 0; j < DP / 16; ++j) oacc[rt][j] *= alpha;
+                for (int j = 0; j < DP / 16; ++j) {
+                    f2 lo = {oacc[rt][j][0], oacc[rt][j][1]}, hi = {oacc[rt][j][2], oacc[rt][j][3]};
+                    lo *= al2; hi *= al2;
+                    oacc[rt][j] = f4{lo[0], lo[1], hi[0], hi[1]};
+                }
+            }
         }
         // O^T += V^T P^T
 #pragma unroll
         for (int kc = 0; kc < AT_K / 32; ++kc)
 #pragma unroll
             for (int j = 0; j < DP / 16; ++j) {
-                const _Float16* vp = &Vt[(j * 16 + i16) * VLD + kc * 32 + q4 * 4];
-                const h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 16);
+                // ds_read_b64_tr_b16 (tools/probes/probe_ds_read_tr.hip): within a 16-lane group lane i supplies the address of 4
+                // contiguous halfs, lane c receives element c % 4 of the chunks addressed by lanes c / 4, 4 + c / 4, 8 + c / 4, 12 + c / 4.
+                // Lane i = 4 jj + m points at V[key kb + jj][d = 16 j + 4 m ..]; lane c then holds V[kb + 0..3][16 j + c]: four keys
+                // of ITS channel -- the V^T fragment, with no transposed copy of V anywhere.
+                typedef short s4v __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) s4v* lds_s4;
+                const _Float16* vp = &Vs[(kc * 32 + q4 * 4 + (i16 >> 2)) * KLD + j * 16 + (i16 & 3) * 4];
+                const h4 v0 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)vp));
+                const h4 v1 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vp + 16 * KLD)));
                 const h8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) oacc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[rt][kc], oacc[rt][j], 0, 0, 0);
@@ -1576,6 +1597,7 @@ extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
 
 extern "C" int es_attention_f16(const es_attn_args* a, es_stream stream) {
     ES_REQUIRE(a->dhead % 4 == 0 && a->dhead <= 256 && a->dhead > 0, "es_attention_f16: dhead=%d (multiple of 4, <= 256)", a->dhead);
+    ES_REQUIRE(a->scale > 0.f, "es_attention_f16: scale=%g must be positive (the row maximum is taken over the raw scores)", (double)a->scale);
     const bool big = a->Ntok >= 512 && a->dhead <= 96;       // 128 query rows per workgroup (4 waves x 2 row tiles), else 64 (4 x 1)
     const int rows = big ? 128 : 64;
     dim3 grid((a->Ntok + rows - 1) / rows, a->B * a->heads);
