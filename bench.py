@@ -240,8 +240,21 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    fuse = full and sh_world == 1 and (FUSE_DEFAULT if a.fuse_loops < 0 else a.fuse_loops == 1)
+    want_fuse = full and (FUSE_DEFAULT if a.fuse_loops < 0 else a.fuse_loops == 1)
+    fuse = want_fuse and sh_world == 1
     fused = None
+    fused_sharded = False
+    if want_fuse and sh_world > 1 and not ss.get('empty'):
+        # sharded scene: a DDIM step is stem graph -> all-gather -> main graph; the (replicated) layout step rides on the main
+        # graph as a parallel branch, exactly as in the single-GPU case (two streams serialise: section 5 of DESIGN.md)
+        from echoscene_amd.plan import combine_plans
+        ss['main_plan_alone'] = ss['main_plan']
+        ss['main_plan'] = combine_plans(dev, ss['main_plan_alone'], st['plan'])
+        st['step'].zero_()
+        ss['main_plan'].sample(ss['step'], 0, 1, use_graph=use_graph)      # capture outside the timed region
+        st['step'].zero_()
+        torch.cuda.synchronize()
+        fused_sharded = True
     if fuse:
         # ONE hipGraph per full step: the layout step is a parallel branch of the shape step (plan.combine_plans), so its 131
         # small launches run in the gaps of the shape step's kernels instead of after them
@@ -267,7 +280,7 @@ def main():
             ev[1].record(); ev[3].record()
     with torch.cuda.stream(s_lay):
         ev[0].record() if fused is None else None
-        done = a.steps if fused is not None else 0
+        done = a.steps if (fused is not None or fused_sharded) else 0
         while done < a.steps:                   # the layout loop is 1000 iterations long; K may exceed it
             n = min(a.steps - done, den.T)
             st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
@@ -299,6 +312,12 @@ def main():
         e[2].record(); torch.cuda.synchronize()
         solo = (e[0].elapsed_time(e[1]) * a.steps / nn, e[1].elapsed_time(e[2]) * a.steps / nn)
     lay_ms, shp_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+    if fused_sharded:
+        # the layout steps ran inside the sharded main graphs; for the record (outside the timed region): the layout loop alone
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        nn = min(a.steps, 50)
+        e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph); e[1].record(); torch.cuda.synchronize()
+        lay_ms = e[0].elapsed_time(e[1]) * a.steps / nn
     fused_ms = None
     if fused is not None:
         fused_ms, (lay_ms, shp_ms) = lay_ms, solo
@@ -338,7 +357,7 @@ def main():
                            'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': bool(a.deterministic) if sh_world > 1 else None,
                            'loops': ('one hipGraph per full step, layout step as a parallel branch '
                                                                               '(%.3f ms per step); layout / shape below: each loop alone' % (fused_ms / a.steps))
-                           if fused_ms is not None else 'two HIP streams', 'layout': lay,
+                           if fused_ms is not None else ('layout step as a parallel branch of the sharded main graph' if fused_sharded else 'two HIP streams'), 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
                                      'kernels_per_step': ss['plan'].n_ops,

@@ -1529,14 +1529,28 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     static const char* f256_env = getenv("ES_CONV_FORCE256");  // test switch: 256-row tiles (the ws kernels) for any problem size
     const bool force256 = f256_env && atoi(f256_env) == 1;
     if (force256 && a->splitk < 0 && !split256) S = 1;
-    if ((wg256 >= 256 || force256) && (S == 1 || split256 || wg256 >= 256) && !no256) {
+    static const char* ws_env = getenv("ES_CONV_WS");             // A/B switch: 0 = no warp specialisation
+    // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
+    const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
+                                M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
+    const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
+    const bool geglu = a->epilogue == ES_EPI_GEGLU;
+    // Small problems (few objects per GPU: the strong-scaling regime, or the 16x4x4 level): fewer than 256 tiles of 256 rows.  The
+    // 128- / 64-row kernels below stream the weight tile twice / four times per 256 rows and cost 0.9 us per K unit and workgroup
+    // against 0.64 us for a 256-row producer/consumer tile, so keep the 256-row tiles and split K until about one workgroup per
+    // CU runs (A/B ES_CONV_WSSPLIT: shape step 21.44 -> 20.76 ms at 32 objects, 13.69 -> 12.61 / 9.22 -> 8.32 / 6.68 -> 6.27 ms at 16 / 8 / 4).
+    static const char* wss_env = getenv("ES_CONV_WSSPLIT");       // A/B switch: 0 = off
+    bool ws_split = false;
+    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && !(wss_env && atoi(wss_env) == 0)) {
+        // (hg256: the tile count of the WHOLE problem -- a shard with O_hint makes the choice the unsharded run makes, so its
+        //  partial sums are cut in the same places and the results stay bit-identical; it then simply runs fewer workgroups)
+        int s2 = (int)(256 / hg256);
+        if (s2 > 8) s2 = 8;
+        while (s2 > 1 && nks / s2 < 24) --s2;
+        if (s2 >= 2 && hg256 * s2 >= 160) { S = s2; ws_split = true; }
+    }
+    if ((wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
-        static const char* ws_env = getenv("ES_CONV_WS");         // A/B switch: 0 = no warp specialisation
-        // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
-        const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
-                                    M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
-        const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
-        const bool geglu = a->epilogue == ES_EPI_GEGLU;
         if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);

@@ -388,3 +388,32 @@ def test_configs4_rank_shapes_on_one_gpu():
         e = _rel(zb[sidx * O:(sidx + 1) * O], z1)
         print('configs[4] rank shapes: scene %d of the 8-scene batch vs alone: rel err %.2e' % (sidx, e))
         assert e < 2e-3
+
+
+def test_bench_two_ranks_on_one_gpu_strong_and_weak():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks
+    sharing the one GPU of the test box over gloo (ES_DIST_BACKEND=gloo: NCCL refuses two ranks on one device; the exchange is
+    staged through host memory in that mode, everything else is the N > 1 code path: object sharding, stem graph -> all-gather
+    -> main graph with the layout step as a parallel branch, max-over-ranks timing, one JSON line from rank 0)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, scaling in ((['--nodes', '8'], 'strong'), (['--scaling', 'weak', '--scenes-per-gpu', '1', '--nodes', '8'], 'weak')):
+        with socket.socket() as sck:
+            sck.bind(('127.0.0.1', 0))
+            port = sck.getsockname()[1]
+        env = dict(os.environ, ES_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+               '--no-cpu-baseline', '--no-sub-records'] + extra
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout[-1500:]
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['steps'] == 3 and d['value'] > 0
+        assert d['config']['scenes'] == (2 if scaling == 'weak' else 1)
+        assert 'roofline' in d and d['roofline']['achieved'] > 0
