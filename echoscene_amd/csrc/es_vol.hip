@@ -1545,7 +1545,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         // (hg256: the tile count of the WHOLE problem -- a shard with O_hint makes the choice the unsharded run makes, so its
         //  partial sums are cut in the same places and the results stay bit-identical; it then simply runs fewer workgroups)
         int s2 = (int)(256 / hg256);
-        if (s2 > 8) s2 = 8;
+        const int s2max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;      // workspace contract (echoscene_hip.h): 16 slabs for small outputs
+        if (s2 > s2max) s2 = s2max;
         while (s2 > 1 && nks / s2 < 24) --s2;
         if (s2 >= 2 && hg256 * s2 >= 160) { S = s2; ws_split = true; }
     }

@@ -166,7 +166,7 @@ class VolBuilderMixin:
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
         if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
-            need = max(8, splitk or 0) * M * pc.N
+            need = max(16 if M * pc.N <= (1 << 22) else 8, splitk or 0) * M * pc.N      # contract of es_conv_args.splitk = -1
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
                 self._ws = self.buf(need)
                 for op in self.ops:

@@ -170,7 +170,8 @@ typedef struct es_conv_args {
     int32_t splitk;           /* 0/1: none; S > 1: K is split over S workgroups per tile, partial sums go to
                                  `workspace` and a second kernel reduces them in a fixed order (deterministic)
                                  and applies the epilogue.  Used for the small-M 16x4x4 level (M = 8192 rows
-                                 cannot fill 256 CUs otherwise).  -1: let the library choose.            */
+                                 cannot fill 256 CUs otherwise).  -1: let the library choose; `workspace` must then hold
+                                 8 * M * N floats, or 16 * M * N floats when M * N <= 2^22 (small outputs are split up to 16 ways) */
     int32_t out_ld;           /* leading dimension of both outputs and of res (>= N);
                                  out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
     int32_t O_hint;           /* 0, or the object count of the WHOLE problem when this launch is one shard of it

@@ -10,4 +10,6 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 echo "smoke rc=$?" >> $OUT/summary.txt
 timeout 300 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
 bash tools/gpu_session_profile.sh ${1:-final}
-cat $OUT/summary.txt; tail -3 $OUT/tests_gpu.log; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -4
+timeout 600 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
+timeout 600 python tools/emulate_shards.py --steps 20 --deterministic 2>&1 | grep "^world" > $OUT/shards_det.txt
+cat $OUT/summary.txt; tail -3 $OUT/tests_gpu.log; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -4; cat $OUT/shards_default.txt $OUT/shards_det.txt
