@@ -63,8 +63,10 @@ def build_shape(dev, O, seed, triples, rank=0, world=1, deterministic=True):
 
 def time_dominant_kernel(ss, dev, reps=3):
     """roofline.achieved for the dominant kernel: the step's conv launches that the library dispatches to the
-    warp-specialised 256-row-tile kernel k_conv_ws (workgroup count >= 256: the 16^3 and 16x8x8 levels) are replayed as
-    their own plan, timed with HIP events on the stream they are launched on.  Returns (TFLOP/s, avg us, launches)."""
+    warp-specialised 256-row-tile kernel k_conv_ws -- >= 256 tiles of 256 rows (the 16^3 and 16x8x8 levels), or fewer tiles with K
+    split over them (the 16x4x4 level; the rule below mirrors es_conv_mfma_f16) -- are replayed as their own plan and timed with
+    HIP events on the stream they are launched on (split launches include their fixed-order reduction kernel).
+    Returns (TFLOP/s, avg us, launches)."""
     from echoscene_amd import hip
     from echoscene_amd.plan import Builder
     plan = ss['plan']
@@ -74,8 +76,16 @@ def time_dominant_kernel(ss, dev, reps=3):
             continue
         c = op.u.conv
         M = c.O * c.D * c.H * c.W
-        if ((M + 255) // 256) * ((c.N + 223) // 224) < 256 or (c.N <= 4 and c.Cin <= 64) or c.Cin == 32:
-            continue                             # (Cin == 32: the zero-padded 3-channel input conv, not counted)
+        if (c.N <= 4 and c.Cin <= 64) or c.Cin == 32 or c.N % 4 or c.out_ld < 0:
+            continue                             # direct small-N kernel / NCDHW output / (Cin == 32: the zero-padded 3-channel input conv)
+        tiles = ((M + 255) // 256) * ((c.N + 223) // 224)
+        if tiles < 256:
+            nks = c.taps * (c.Cin // 32) + (c.Cin2 // 32 if c.a2 else 0)
+            s2 = min(256 // tiles, 16 if M * c.N <= (1 << 22) else 8)
+            while s2 > 1 and nks // s2 < 24:
+                s2 -= 1
+            if not (s2 >= 2 and tiles * s2 >= 160 and c.epilogue == 0 and c.workspace):
+                continue                         # stays on the 128- / 64-row k_conv_lean tiles
         ops.append(op)
         flops += 2.0 * M * c.N * (c.Cin * c.taps + c.Cin2)
     if not ops:

@@ -362,8 +362,6 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     const bool geglu_epi = EPI_ < 0 ? a.epilogue == ES_EPI_GEGLU : EPI_ == ES_EPI_GEGLU;
     if constexpr (!ACTIVE) {
         __syncthreads();
-        if (geglu_epi)
-            for (int i = 0; i < MI; ++i) { __syncthreads(); __syncthreads(); }
         return;
     }
     const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, q = lane >> 4;
@@ -373,46 +371,49 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
     float* part = S > 1 ? (float*)a.workspace + (long)bz * M * a.N : nullptr;   // [S][M][N] partial sums
     if (geglu_epi) {
-        // wave wn = 0 holds 112 value columns, its partner wn = 1 the matching 112 gate columns (tile-interleaved
-        // weight packing): both transpose their slab into LDS, the value wave combines and stores f16 [M, 4C].
-        const float* vslab = (const float*)smem + (wave & ~1) * (16 * 116);    // value slab (wn = 0 wave of the pair)
-        const float* gslab = vslab + 16 * 116;                                  // gate slab (wn = 1)
-        const int oc0 = n0 >> 1;                              // output column of this tile's first value column
-        // bias goes into the accumulators first (a lane's column of tile j is fixed: 7 loads per tile, one round trip) -- the
-        // combine loop below used to fetch two bias quads per item behind the LDS reads, 8 dependent global loads per slab
+        // Weight packing (PackedConv(geglu=True)): inside every 16-column MFMA tile, columns 0..7 are VALUE columns and columns
+        // 8..15 the GATE columns of the same 8 outputs.  In the accumulator layout (lane = column i16, rows q*4 + r) the value
+        // and the gate of one output element therefore sit in lanes i16 and i16 ^ 8 of ONE wave: two DPP row rotations exchange
+        // them (the low lanes hand over their rows 2, 3 and receive the gates of rows 0, 1; the high lanes the reverse), every
+        // lane evaluates two outputs, and the wave transposes its 16 x 56 fp16 results through a private 2.3 KB LDS slab into
+        // 16-byte stores.  The first version kept value and gate columns in the two waves of a pair and exchanged whole fp32
+        // slabs through LDS: 9 workgroup barriers, 112 ds_write_b32 and two slab reads per tile and wave.
+        const bool lo = i16 < 8;
+        const int cw = i16 & 7;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
+        for (int j = 0; j < 7; ++j) {                         // bias first: a lane's column of tile j is fixed
             const float bj = a.bias[n0 + wn * 112 + j * 16 + i16];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += bj;
         }
+        constexpr int HLD = 72;                               // halfs per slab row (56 + pad; 144 B keeps the 16-byte reads aligned)
+        _Float16* hslab = (_Float16*)smem + wave * (16 * HLD);
+        _Float16* outp = (_Float16*)a.out_f16 + (n0 >> 1) + wn * 56;     // first output column of this wave
+        const int rr = q * 4 + (lo ? 0 : 2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
-            __syncthreads();
-            // each wave of the pair combines 8 of the 16 rows: 8 x 28 float4 = 224 items, 3.5 per lane
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int idx = lane + 64 * t;
-                if (idx < 224) {
-                    const int row = idx / 28 + 8 * wn, c4 = idx % 28;
-                    const long m = m0 + wm * WROWS + i * 16 + row;
-                    if (m < M) {
-                        const f4 v = *(const f4*)&vslab[row * 116 + c4 * 4];
-                        const f4 gt = *(const f4*)&gslab[row * 116 + c4 * 4];
-                        h4 hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(v[e] * es_gelu_fast(gt[e]));
-                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + oc0 + c4 * 4) = hv;
-                    }
-                }
+            for (int j = 0; j < 7; ++j) {
+                const float s0 = lo ? acc[i][j][2] : acc[i][j][0], s1 = lo ? acc[i][j][3] : acc[i][j][1];
+                const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x128, 0xf, 0xf, false));   // row_ror:8
+                const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x128, 0xf, 0xf, false));
+                const float v0 = lo ? acc[i][j][0] : r0, g0 = lo ? r0 : acc[i][j][2];
+                const float v1 = lo ? acc[i][j][1] : r1, g1 = lo ? r1 : acc[i][j][3];
+                hslab[rr * HLD + j * 8 + cw] = (_Float16)(v0 * es_gelu_fast(g0));
+                hslab[(rr + 1) * HLD + j * 8 + cw] = (_Float16)(v1 * es_gelu_fast(g1));
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own slab writes visible to own wave
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                     // 16 rows x 7 pieces of 16 bytes
+                const int idx = lane + 64 * t;
+                const int row = idx / 7, c8 = idx - row * 7;
+                const long m = m0 + wm * WROWS + i * 16 + row;
+                if (idx < 112 && m < M) *(h8*)(outp + m * a.out_ld + c8 * 8) = *(const h8*)&hslab[row * HLD + c8 * 8];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -1403,7 +1404,7 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     ES_REQUIRE(!a->a2 || (a->Cin2 % 32 == 0 && a->Cin2 > 0), "es_conv_mfma_f16: Cin2=%d", a->Cin2);
     ES_REQUIRE(a->out_f32 || a->out_f16, "es_conv_mfma_f16: no output");
     ES_REQUIRE(a->epilogue == ES_EPI_NONE || (a->epilogue == ES_EPI_GEGLU && a->N % 224 == 0 && a->out_f16 && !a->out_f32 && !a->res &&
-                                              !a->rowvec && !a->a2 && a->bias && a->out_ld >= a->N / 2 && a->out_ld % 4 == 0 && a->splitk <= 1),
+                                              !a->rowvec && !a->a2 && a->bias && a->out_ld >= a->N / 2 && a->out_ld % 8 == 0 && a->splitk <= 1),
                "es_conv_mfma_f16: GEGLU epilogue needs N %% 224 == 0 (N=%d), bias, f16 output only, no split-K", a->N);
     ConvGeom g;
     g.O = a->O; g.D = a->D; g.H = a->H; g.W = a->W;

@@ -22,10 +22,11 @@ class PackedConv:
         W = W.detach().float().contiguous().cpu()
         self.geglu = False
         if geglu and W.dim() == 2 and (W.shape[0] // 2) % 112 == 0 and b is not None:
-            # GEGLU fused into the contraction epilogue (ES_EPI_GEGLU): per 224-column tile 112 value rows, then their
-            # 112 gate rows (value = first half of the projection, attention.py:39-46)
+            # GEGLU fused into the contraction epilogue (ES_EPI_GEGLU): every 16-row group of the packed weight = the value rows
+            # of 8 outputs, then their 8 gate rows (value = first half of the projection, attention.py:39-46), so the value and
+            # the gate of an output land in lanes i16 and i16 ^ 8 of one MFMA tile (echoscene_hip.h: es_conv_args.epilogue)
             C4 = W.shape[0] // 2
-            idx = torch.cat([torch.cat([torch.arange(t, t + 112), C4 + torch.arange(t, t + 112)]) for t in range(0, C4, 112)])
+            idx = torch.cat([torch.cat([torch.arange(t, t + 8), C4 + torch.arange(t, t + 8)]) for t in range(0, C4, 8)])
             W = W[idx].contiguous()
             b = b.detach().float()[idx].contiguous()
             self.geglu = True

@@ -178,9 +178,11 @@ typedef struct es_conv_args {
                                  (multi-GPU object sharding): the split-K factor is then chosen as for the whole problem,
                                  so that the fp32 partial sums -- and the result -- are bit-identical to the unsharded run */
     int32_t epilogue;         /* ES_EPI_NONE, or ES_EPI_GEGLU: GEGLU (attention.py:39-46) fused into the FeedForward
-                                 proj: the weight rows are packed tile-interleaved (per 224-column tile: 112 value
-                                 rows c0..c0+111, then their 112 gate rows 4C+c0..), N = 8C, the only output is
-                                 out_f16 [M, 4C] = (value + b) * gelu(gate + b), out_ld = leading dim of that  */
+                                 proj: the weight rows are packed tile-interleaved -- packed row 16 k + c holds the value
+                                 row of output 8 k + c for c < 8 and its gate row (4C + 8 k + c - 8) for c >= 8, i.e. every
+                                 16-column MFMA tile carries 8 outputs' value and gate columns -- N = 8C (a multiple of
+                                 224), the only output is out_f16 [M, 4C] = (value + b) * gelu(gate + b), out_ld = leading
+                                 dim of that (a multiple of 8)                                              */
 } es_conv_args;
 enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
