@@ -392,10 +392,10 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}, {'ES_CONV_WSSPLIT': '0'}])
 def test_conv_alternate_kernels(env):
-    """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced) must give the same
-    results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
+    """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
+    128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
     (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
     1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
     tiles."""
