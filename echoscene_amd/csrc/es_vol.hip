@@ -278,15 +278,14 @@ __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
 
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear on MFMA (fp16 in, fp32 accumulate).
-//   workgroup tile 128 (voxels) x 224 (output channels), K step 32, 4 waves as 2(M) x 2(N),
-//   wave tile 64 x 112 = 4 x 7 MFMA 16x16x32 tiles (112 accumulator VGPRs).
-//   N = 224 / 448 / 672 (and 3*C, 8*C) are all multiples of 224 at full width; ragged N / M are
-//   handled by zero-page rows and masked stores (narrow test configs).
+//   workgroup tile 256 / 128 / 64 (voxels) x 224 (output channels), K unit = 32 channels x one tap; waves as (rows) x 2 (columns),
+//   wave tile 64 (32) x 112 = 4 (2) x 7 MFMA 16x16x32 tiles (112 accumulator VGPRs).
+//   N = 224 / 448 / 672 (and 3*C, 8*C) are all multiples of 224 at full width; ragged N / M, halo and out-of-volume rows are
+//   out-of-range lanes of the LDS-DMA gather (hardware zero fill) and masked stores.
 // ---------------------------------------------------------------------------------------------
-constexpr int BN = 224, BK = 32, BNP = 256;     // BNP: B tile rows padded so that every thread issues 4 B loads
-// LDS ring depth NS_ is a template parameter: 3 (tiles ks+1, ks+2 in flight; two workgroups per CU hide the rest of
-// the load latency) or 6 for launches with <= 1 workgroup per CU (few objects per GPU, 16x4x4 level): five tiles in
-// flight, because a lone workgroup waits ~2.3 us per tile on HBM otherwise (measured 1.15 us per K step vs 0.3).
+constexpr int BN = 224, BK = 32, BNP = 256;     // BNP: LDS rows of a weight tile (224 padded to a whole number of 1 KiB pieces per wave;
+                                                // the 32 pad rows are zero-filled by out-of-range pieces, never fetched)
+// LDS ring: 3 slots (units ks+1, ks+2 in flight).  A 6-deep ring for lone workgroups measured neutral (round 1).
 
 struct ConvGeom {
     int O, D, H, W;          // output grid
