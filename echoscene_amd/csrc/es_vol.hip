@@ -1496,8 +1496,6 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
-            set((const void*)k_conv_ws<128, 4, 2, false>, LDS128);
-            set((const void*)k_conv_ws<128, 4, 2, true>, LDS128);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
@@ -1556,7 +1554,23 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         while (s2 > 1 && nks / s2 < 24) --s2;
         if (s2 >= 2 && hg256 * s2 >= 160) { S = s2; ws_split = true; }
     }
-    if ((wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256) {
+    // Tiny K-short problems (the transformer linears at <= 8 objects per GPU: e.g. 1024 rows x 672 columns, 21 K units): even the
+    // 64-row tiles give only a few dozen workgroups, each a lone, latency-bound chain of K units (22-30 us for < 1 GFLOP).
+    // Split K over 64-row tiles until about one workgroup per CU runs (>= 5 units per split).
+    static const char* tiny_env = getenv("ES_CONV_TINYSPLIT");     // A/B switch: 0 = off
+    bool tiny_split = false;
+    {
+        const long hg64 = ((Mh + 63) / 64) * ntn;
+        if (!ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
+            !(tiny_env && atoi(tiny_env) == 0)) {
+            int s3 = (int)((256 + hg64 - 1) / hg64);
+            const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
+            if (s3 > s3max) s3 = s3max;
+            if (s3 > nks / 5) s3 = nks / 5;
+            if (s3 >= 2) { S = s3; tiny_split = true; }
+        }
+    }
+    if ((wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
         if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
@@ -1565,19 +1579,12 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         }
         else if (upm) hipLaunchKernelGGL((k_conv_lean<256, 8, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
-    } else if (wg128 >= 512 || S > 1) {
+    } else if ((wg128 >= 512 || S > 1) && !tiny_split) {
         dim3 grid((unsigned)((M + 127) / 128), ntn, S);
-        static const char* ws128_env = getenv("ES_CONV_WS128");   // A/B switch: producer/consumer kernel for the 128-row tiles too
-        const bool ws128_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
-                              M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) && a->epilogue == ES_EPI_NONE;
-        if (ws128_env && atoi(ws128_env) == 1 && ws128_ok) {
-            if (upm) hipLaunchKernelGGL((k_conv_ws<128, 4, 2, true>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
-            else hipLaunchKernelGGL((k_conv_ws<128, 4, 2, false>), grid, dim3(384), LDS128, st, *a, g, ncdhw);
-        } else
         if (upm) hipLaunchKernelGGL((k_conv_lean<128, 4, true>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<128, 4>), grid, dim3(256), LDS128, st, *a, g, ncdhw);
     } else {
-        dim3 grid((unsigned)((M + 63) / 64), ntn, 1);
+        dim3 grid((unsigned)((M + 63) / 64), ntn, tiny_split ? S : 1);
         if (upm) hipLaunchKernelGGL((k_conv_lean<64, 4, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
     }
