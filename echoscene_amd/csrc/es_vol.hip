@@ -353,7 +353,7 @@ __device__ __forceinline__ void conv_tile_of(const es_conv_args& a, int& bx, int
 // all in flight (fully unrolled the epilogue spilled 100 registers there and cost more than the K loop gained).
 // EPI_: -1 = a.epilogue decides at run time (general kernels); ES_EPI_NONE / ES_EPI_GEGLU = compiled for that epilogue only
 // (k_conv_ws: with both paths in one function the register allocator spilled 150-250 dwords at the 168-register cap).
-template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false, int EPI_ = -1>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
+template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false, int EPI_ = -1, bool NOSYNC = false>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
 __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvGeom& g, f4 (&acc)[BM_ / (NW_ / 2) / 16][7],
                                               char* smem, long M, long m0, int n0, int wave, int lane, int S, int bz,
                                               int ncdhw) {
@@ -365,7 +365,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     }
     const int wm = wave >> 1, wn = wave & 1, i16 = lane & 15, q = lane >> 4;
     const int V = g.D * g.H * g.W;
-    __syncthreads();                                          // all waves done with the ring
+    if constexpr (!NOSYNC) __syncthreads();                   // all waves done with the ring (NOSYNC: the slabs live behind the ring, k_linear_ws)
     float* slab = (float*)smem + wave * (16 * 116);           // per wave: 16 rows x 112 cols (+4 pad) fp32 = 7.25 KB
     const bool vec_ok = !ncdhw && (a.N % 4 == 0) && (a.out_ld % 4 == 0) && (!a.rowvec || a.rowvec_ld % 4 == 0);
     float* part = S > 1 ? (float*)a.workspace + (long)bz * M * a.N : nullptr;   // [S][M][N] partial sums
@@ -1040,6 +1040,149 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
 }
 
+// a wave-uniform pointer the compiler can keep in SGPRs (buffer descriptors must be scalar; a descriptor it cannot prove uniform
+// is applied through a waterfall loop around every buffer instruction)
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (void*)(((unsigned long)hi << 32) | lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_linear_ws: k_conv_ws for the 1x1 / linear launches with several column tiles (qkv: 6, FeedForward: 16-24), where a tile has only
+// 14-84 K units against ~23 us of per-tile cost outside the K loop (tools/microbench_epilogue.py).  A workgroup owns ONE row tile and
+// walks NCB consecutive column tiles: the K units of all of them form one stream through the ring -- the producers' per-row set-up is
+// done once, they run two units ahead across the column-tile boundary (only the weight descriptor changes), and the consumers'
+// epilogue of tile c overlaps the loads of tile c+1 (the epilogue slabs live BEHIND the ring: no workgroup barrier in it).
+// Same tile, LDS image, K order and arithmetic as k_conv_ws (results are bit-identical).
+// ---------------------------------------------------------------------------------------------
+template <int EPI_>
+__global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, const ConvGeom g, int ncb) {
+    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NS = 3;
+    constexpr int WROWS = BM_ / (NC_ / 2), MI = WROWS / 16;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES, RING_BYTES = NS * STAGE_BYTES;
+    constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_, NLOAD = NA + NB;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    // tile mapping as conv_tile_of (XCD-contiguous ranges, column GROUPS fastest inside ~3 MiB weight panels)
+    int bx, byg;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+        const int orig = blockIdx.x + gx * blockIdx.y;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const long slab = (long)a.Cin * BN * 2 * ncb;
+        int npanel = (int)(((long)gy * slab + (3L << 20) - 1) / (3L << 20));
+        npanel = npanel < 1 ? 1 : (npanel > gy ? gy : npanel);
+        const int Pw = (gy + npanel - 1) / npanel, full = gx * Pw;
+        const int p = L / full, rr = L - p * full;
+        const int w = (gy - p * Pw) < Pw ? (gy - p * Pw) : Pw;
+        bx = rr / w;
+        byg = p * Pw + (rr - bx * w);
+    }
+    const long m0 = (long)bx * BM_;
+    const int by0 = byg * ncb;
+    const int kch = a.Cin >> 5;                  // K units per column tile
+    const int total = kch * ncb;
+    if (wave >= NC_) {
+        // =============================== producer ===============================
+        const int pw = wave - NC_;
+        unsigned voff[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (pw + NP_ * j) * 64 + lane;    // 16-B slot of the A tile: row = p >> 2, physical chunk = p & 3
+            const int row = p >> 2;
+            const long m = m0 + row;
+            voff[j] = m < M ? (unsigned)(m * a.Cin * 2 + (((p & 3) ^ f_swz(row)) * 16)) : OOB;
+        }
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.a), (short)0, (int)OOB, 0x00020000);
+        const _Float16* Wg = (const _Float16*)a.w;
+        int cb = 0, c = 0, islot = 0;
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg + (long)by0 * kch * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+        const unsigned voffB = (unsigned)lane * 16u;
+        auto issue = [&]() __attribute__((always_inline)) {
+            char* dst = smem + __builtin_amdgcn_readfirstlane(islot) * STAGE_BYTES;
+            const unsigned sA = (unsigned)__builtin_amdgcn_readfirstlane(c) * 64u;
+            const unsigned sB = (unsigned)__builtin_amdgcn_readfirstlane(c) * (unsigned)B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (pw + NP_ * j) * 1024), 16, (int)voff[j], (int)sA, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = pw + NP_ * j;
+                const unsigned vB = q * 16 >= BN ? OOB : voffB;          // the zero rows padding the weight tile: zero fill, no traffic
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + A_BYTES + q * 1024), 16, (int)vB, (int)(sB + (unsigned)q * 1024u), 0, 0);
+            }
+            islot = islot == NS - 1 ? 0 : islot + 1;
+            if (++c == kch) {                    // next column tile: same rows, next weight slab
+                c = 0; ++cb;
+                rB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wg + (long)(by0 + cb) * kch * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+            }
+        };
+        issue();
+        if (total > 1) issue();
+        for (int u = 0; u < total; ++u) {
+            if (u + 1 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of unit u have landed
+            __builtin_amdgcn_s_barrier();        // unit u visible to the consumers; the slot two behind released by them
+            if (u + 2 < total) issue();
+        }
+        return;
+    }
+    // =============================== consumer ===============================
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fragA = (wm * WROWS + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    int slot = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        f4 acc[MI][7];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        h8 af[MI], bfr[7];
+        __builtin_amdgcn_s_barrier();                                           // first unit of this column tile published
+        ws_read_frags<MI>(smem + slot * STAGE_BYTES, fragA, fragB, af, bfr);
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        for (int ks = 0; ks + 1 < kch; ++ks) {                                  // pipelined as in k_conv_ws
+            const char* const An = smem + slot * STAGE_BYTES;
+            slot = slot == NS - 1 ? 0 : slot + 1;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfr[j], acc[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 1; i < MI; ++i) {
+                af[i - 1] = *(const h8*)(An + fragA + (i - 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < MI - 1) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[j] = *(const h8*)(An + fragB + j * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            af[MI - 1] = *(const h8*)(An + fragA + (MI - 1) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ws_mma<MI>(acc, af, bfr);
+        conv_epilogue<BM_, NC_, true, true, EPI_, true>(a, g, acc, smem + RING_BYTES, M, m0, (by0 + cb) * BN, wave, lane, 1, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Self-attention, flash style, fp16 MFMA.  One workgroup = 64 query rows of one (batch, head);
 // 4 waves x 16 rows.  K tile [64 keys][dp], V tile transposed [dp][64 keys] in LDS.
@@ -1496,6 +1639,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
+            set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
+            set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
@@ -1572,7 +1717,20 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     }
     if ((wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
-        if (ws && (!geglu || !upm)) {
+        // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
+        static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
+        int ncb = 1;
+        if (ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
+            static const int cand[5] = {8, 6, 4, 3, 2};
+            for (int k = 0; k < 5; ++k)
+                if (ntn % cand[k] == 0 && (long)grid.x * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
+        }
+        if (ncb > 1) {
+            const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
+            constexpr int LDSLIN = LDS256 + 8 * 16 * 116 * 4;
+            if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
+            else hipLaunchKernelGGL((k_linear_ws<ES_EPI_NONE>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
+        } else if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false>), grid, dim3(768), LDS256, st, *a, g, ncdhw);

@@ -392,7 +392,7 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}, {'ES_CONV_WSSPLIT': '0'}])
+@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}, {'ES_CONV_WSSPLIT': '0'}, {'ES_CONV_LINWS': '0'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
     128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
