@@ -57,11 +57,11 @@ for r in rows[:18]:
         '-' if not (gui and mf is not None) else '%.3f' % (mf / (gui / 8 * 1024)),
         '-' if not (gui and lds is not None) else '%.3f' % (lds / (gui / 8 * 256)),
         '-' if not (wc and wa is not None) else '%.2f' % (wa / wc)))
-ws = [r for r in rows if 'k_conv_ws' in r['Name']]
+ws = [r for r in rows if 'k_conv_ws' in r['Name'] or 'k_linear_ws' in r['Name']]
 if ws:
     wt, wc = sum(float(r['TotalDurationNs']) for r in ws), sum(int(r['Calls']) for r in ws)
     md.append('')
-    md.append('Cross-check of `roofline.avg_launch_us`: rocprofv3 average over all `k_conv_ws` variants = %.1f us (%d calls); `bench.py` '
+    md.append('Cross-check of `roofline.avg_launch_us`: rocprofv3 average over all `k_conv_ws` / `k_linear_ws` variants = %.1f us (%d calls); `bench.py` '
               '(HIP events, launches replayed back to back, split-K launches including their reduction kernel) = %.1f us.'
               % (wt / wc / 1e3, wc, bench['roofline'].get('avg_launch_us') or 0))
 traffic = {}
