@@ -1,33 +1,43 @@
 // "rows" path: fp32 fused linear over small-M node/triple matrices + the diffusion updates.
 //
-// Roofline note: one layout denoising step streams ~524 MB of fp32 weights
-// for ~8.9 GFLOP (17 flop/B) -- HBM-bound, and in practice launch/latency-bound because it is a
-// chain of ~140 dependent [32 x K] @ [K x N] products.  Design consequences:
-//   * weights are pre-packed in MFMA-fragment order so that every wave-level load is one
-//     contiguous 1 KiB global_load_dwordx4 that lands directly in B-operand registers
-//     (no LDS round trip for the streamed operand -- it is used once per workgroup);
-//   * the small activation tile (<= 32 rows x 1024 cols) is staged ONCE per workgroup in LDS,
-//     where the norm/activation prologue (GroupNorm+SiLU / LayerNorm / GEGLU / gather /
-//     CSR mean pooling) is applied, so no separate elementwise kernels (= no extra launches);
-//   * exact fp32 on the matrix pipe: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain);
-//   * K is split over the 8 waves of a workgroup and reduced through LDS in a fixed order
-//     (deterministic, no float atomics).
+// Roofline note: one layout denoising step streams ~335 MB of fp32 weights for ~6.5 GFLOP --
+// HBM-bound on paper (42 us at 8 TB/s), in practice a chain of ~130 DEPENDENT [32 x K] @ [K x N] products whose cost is
+// the kernel boundary (~1.5 us) plus each kernel's own latency chain.  Round 2 gave one workgroup per 16 output columns
+// (N = 512 -> 32 workgroups on a 256-CU chip), each staging and normalising the WHOLE [32 x K] activation tile:
+// 6-28 us per launch, 2.6 % of the HBM roofline.  Round 3 design:
+//   * K is split over workgroups as well: grid = (column tiles x K slices, row tiles).  A slice's partial products go
+//     to its own SLAB of the output, out[s][M][N] (slice 0 adds bias and residuals); there is no reduction kernel and
+//     no in-launch hand-off -- the CONSUMER sums the slabs in fixed order while it stages its A operand (the
+//     launch-boundary reduce of the MI355X guide: costs nothing extra because that staging exists anyway).  Every
+//     operand that can be a slab tensor (A segments, the residual, the eps input of the DDPM update) carries
+//     (nslab, slab_stride);
+//   * prologues are PER SEGMENT and applied to the slice only: a workgroup normalises 32 x (K / S) elements instead of
+//     32 x K (GroupNorm groups never straddle a slice; LayerNorm reads its whole rows for the statistics -- L2 hits --
+//     and normalises the slice);
+//   * the choice of S depends on (K, N) only, never on M: per-row arithmetic is independent of the batch
+//     (collated scenes == single scenes, bit for bit);
+//   * weights are pre-packed in MFMA-fragment order: a wave-level load is one contiguous 1 KiB global_load_dwordx4
+//     that lands in B-operand registers (streamed once per workgroup, no LDS round trip), issued before the staging;
+//   * exact fp32 on the matrix pipe: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain); the k-blocks of a slice are
+//     dealt to the 4 waves and reduced through LDS in a fixed order (deterministic, no float atomics).
 #include "es_common.h"
 #include <cstdlib>
+#include <mutex>
+#include <initializer_list>
 
 namespace {
 
-constexpr int MT = 32;          // rows per workgroup (two 16-row MFMA tiles)
-constexpr int KC = 1024;        // K chunk staged in LDS
-constexpr int LDX = KC + 8;     // +8 floats: conflict-free ds_read_b128 of A fragments
-constexpr int NWAVE = 8;
+// Row tile = ONE 16-row MFMA tile.  The slab traffic of a launch is (column tiles) x S x M x K x 4 bytes whatever the row tile
+// (every workgroup re-reads its [MT x K/S] operand from all S slabs of the producer): 16 MB per [32 x 512] x [512 x 512] launch
+// at S = 8, and that L2 traffic -- not latency -- was the staging cost (1.3-2 us per 64 columns).  Halving the row tile gives the
+// same 256 workgroups at S = 4, i.e. half the bytes.
+constexpr int MT = 16;          // rows per workgroup
+constexpr int KCH = 1024;       // K columns of a slice staged in LDS at a time
+constexpr int NWAVE = 8;        // wave w owns the k-blocks w, w + 8, ... of the chunk
+constexpr int NKG = 8;
 constexpr int NTHREAD = NWAVE * 64;
-constexpr int MAXJ = KC / 16 / NWAVE;   // 16-wide k-blocks per wave per chunk
-
-struct Smem {
-    float x[MT][LDX];
-    float gb[2][KC];          // gamma / beta of the norm prologue (staged once, read by every row)
-};
+constexpr int MAXJ = KCH / 16 / NKG;     // 16-wide k-blocks per wave per chunk
+constexpr int LPR = NTHREAD / MT;        // lanes per row while staging (32: four 128-byte lines per row and pass)
 
 __device__ __forceinline__ const float* seg_base(const es_seg& s) {
     const float* p = s.ptr;   // (batched launches add blockIdx.z * a_bstride to segment 0 at the call site)
@@ -35,81 +45,151 @@ __device__ __forceinline__ const float* seg_base(const es_seg& s) {
     return p;
 }
 
-// Staging of one K chunk of the (virtually concatenated) A operand into LDS.
-// Thread mapping: row r = tid >> 4 (32 rows), column lane cl = tid & 15; a thread walks its row in
-// steps of 16 float4 -> 16 consecutive lanes read 256 contiguous bytes, no integer division, and the
-// segment loop / mode switch are wave-uniform (scalar branches only).  Loads are unconditional
-// (row index clamped, result masked) so that 8 of them are in flight per thread before first use.
-template <int PRO>
-__device__ __forceinline__ f4 post_a4(f4 v, f4 g) {
-    if (PRO == ES_PRO_GEGLU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * es_gelu(g[e]);
-    } else if (PRO == ES_PRO_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = es_silu(v[e]);
-    }
+__device__ __forceinline__ float load_slabs1(const float* p, int nslab, long slab_stride) {
+    float v = *p;
+    for (int j = 1; j < nslab; ++j) v += p[(long)j * slab_stride];
     return v;
 }
 
-template <int PRO>
-__device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, int m0, int kc0, int kc, int tid) {
-    const int r = tid >> 4, cl = tid & 15;
+// NS float4 loads of one slab tensor element issued together (slabs >= nslab are wave-uniformly skipped), summed in the fixed
+// order 0 .. nslab-1 by sum_slabs: the deferred split-K reduction of the producer.  These launches are pure latency chains: a
+// runtime loop over the slabs made every slab a dependent L2 round trip (8.6 us per split launch instead of ~4).
+template <int NS>
+__device__ __forceinline__ void load_slabs(f4 (&t)[NS], const float* p, int nslab, long slab_stride) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        t[j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (j == 0 || j < nslab) t[j] = *(const f4*)(p + (long)j * slab_stride);
+    }
+}
+template <int NS>
+__device__ __forceinline__ f4 sum_slabs(const f4 (&t)[NS], int nslab) {
+    f4 v = t[0];
+#pragma unroll
+    for (int j = 1; j < NS; ++j) if (j < nslab) v += t[j];
+    return v;
+}
+
+// Staging of the columns [c0, c0 + kc) of the (virtually concatenated) A operand into LDS tile x[MT][ldx], with each
+// segment's slab sum, input activation and prologue applied.  Thread mapping: row r = tid >> 3, lane cl = tid & 7; a
+// thread walks its row in steps of 8 float4 (8 lanes read one 128-byte line); 16 float4 loads (columns x slabs) are in flight
+// per thread before the first is used.  Segment loop / mode switches are wave-uniform.  GroupNorm: a group (gs = 4 .. 32
+// channels) is gs/4 adjacent lanes of one pass -> statistics by lane shuffles, two-pass (mean, then squared deviations).
+// NS: compile-time bound of the slab counts of this launch's segments (1, 2, 4, 8).
+// PROC: prologue class compiled in -- 0: none (raw / ReLU'd operands), 1: + GroupNorm(+SiLU) segments, 2: + SiLU / GEGLU
+// (tables, tests).  CSR: the segmented-mean gather is compiled in.  A launch costs ~4 us of which ~1 us was instruction fetch
+// when every path lived in one 31 KB kernel (each launch starts with a cold instruction cache): one lean kernel per class.
+template <int NS, int PROC, bool CSR>
+__device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, int ldx, int m0, int c0, int kc, int tid) {
+    // passes (32 lanes x float4 = 128 columns of a row) per batch: up to 16 float4 loads in flight per thread.  A pass that lies
+    // wholly past the region is skipped (wave-uniform): with 4 waves and 32-load batches the clamped duplicates of a 64-column
+    // slice cost +1.9 us per launch -- at one wave per SIMD nothing hides the dependent VALU chain of the prologue.
+    constexpr int UB = NS >= 8 ? 2 : 4;
+    const int r = tid >> 5, cl = tid & (LPR - 1);
     const int m = m0 + r;
     const bool row_ok = m < a.M;
     const int mc = row_ok ? m : a.M - 1;
     int koff = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const es_seg& sg = a.seg[s];
-        const int lo = max(kc0, koff), hi = min(min(kc0 + kc, koff + sg.width), a.K);
+        const int lo = max(c0, koff), hi = min(min(c0 + kc, koff + sg.width), a.K);
         if (lo < hi) {
             const int w4 = (hi - lo) >> 2;
-            const float* base = seg_base(sg) + (lo - koff) + (s == 0 ? (long)blockIdx.z * a.a_bstride : 0);
-            float* dst = &sm.x[r][lo - kc0];
-            if (sg.mode == ES_SEG_CSRMEAN) {
+            const int scol = lo - koff;                                 // first column inside the segment
+            const float* base = seg_base(sg) + scol + (s == 0 ? (long)blockIdx.z * a.a_bstride : 0);
+            float* dst = x + r * ldx + (lo - c0);
+            const int nslab = sg.nslab > 1 ? sg.nslab : 1;
+            const long sstr = sg.slab_stride;
+            const int pro = sg.pro;
+            const bool relu_in = sg.pre_act == ES_ACT_RELU;
+            if (CSR && sg.mode == ES_SEG_CSRMEAN) {
                 const int e0 = sg.idx[mc], e1 = sg.idx[mc + 1];
-                const float inv = 1.0f / (float)max(e1 - e0, 1);
-                for (int c4 = cl; c4 < w4; c4 += 16) {
+                for (int c4 = cl; c4 < w4; c4 += LPR) {
                     f4 v = {0.f, 0.f, 0.f, 0.f};
                     // stored order == scatter_add order of the reference.  Entries are fetched 8 at a time (index pairs,
-                    // then rows) and added in order: the scene node has ~2*O incident edges, and one dependent
-                    // index -> row load pair per entry made this op 49 us (12 % of a layout step).
+                    // then rows) and added in order (the scene node has ~2*O incident edges).
                     for (int e = e0; e < e1; e += 8) {
                         long off[8];
-                        f4 x[8];
+                        f4 t[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int ee = min(e + u, e1 - 1);
                             off[u] = (long)sg.ent_row[ee] * sg.ld + sg.ent_off[ee];
                         }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) x[u] = *(const f4*)(base + off[u] + 4 * c4);
+                        for (int u = 0; u < 8; ++u) t[u] = *(const f4*)(base + off[u] + 4 * c4);
+                        for (int j = 1; j < nslab; ++j) {               // (slab sources under a CSR mean: not on the sampling path)
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) if (e + u < e1) v += x[u];
+                            for (int u = 0; u < 8; ++u) t[u] += *(const f4*)(base + off[u] + 4 * c4 + (long)j * sstr);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (relu_in) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) t[u][q] = fmaxf(t[u][q], 0.f);
+                            }
+                            if (e + u < e1) v += t[u];
+                        }
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = row_ok ? v[e] / (float)max(e1 - e0, 1) : 0.f;
-                    (void)inv;
+                    for (int q = 0; q < 4; ++q) v[q] = row_ok ? v[q] / (float)max(e1 - e0, 1) : 0.f;
                     *(f4*)(dst + 4 * c4) = v;
                 }
             } else {
                 const long rowoff = (long)(sg.mode == ES_SEG_GATHER ? sg.idx[mc] : mc) * sg.ld;
                 const float* src = base + rowoff;
-                for (int u0 = 0; u0 * 16 < w4; u0 += 8) {
-                    f4 v[8], gt[8];
+                const bool gn = PROC >= 1 && (pro == ES_PRO_GN || pro == ES_PRO_GN_SILU);
+                const int lpg = gn ? (sg.gs >> 2) : 1;                  // lanes per GroupNorm group (1, 2, 4, 8)
+                const float* ga = sg.gamma ? sg.gamma + scol : src;
+                const float* be = sg.beta ? sg.beta + scol : src;
+                for (int u0 = 0; u0 * LPR < w4; u0 += UB) {
+                    f4 t[UB][NS], gt[PROC >= 2 ? UB : 1][NS], gav[PROC >= 1 ? UB : 1], bev[PROC >= 1 ? UB : 1];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c4 = min(cl + 16 * (u0 + u), w4 - 1);
-                        v[u] = *(const f4*)(src + 4 * c4);
-                        if (PRO == ES_PRO_GEGLU) gt[u] = *(const f4*)(src + a.K + 4 * c4);
+                    for (int u = 0; u < UB; ++u) {
+                        if (LPR * (u0 + u) >= w4) continue;
+                        const int c4 = min(cl + LPR * (u0 + u), w4 - 1);
+                        load_slabs<NS>(t[u], src + 4 * c4, nslab, sstr);
+                        if (PROC >= 2 && pro == ES_PRO_GEGLU) load_slabs<NS>(gt[PROC >= 2 ? u : 0], src + a.K + 4 * c4, nslab, sstr);
+                        if (PROC >= 1 && gn) { gav[PROC >= 1 ? u : 0] = *(const f4*)(ga + 4 * c4); bev[PROC >= 1 ? u : 0] = *(const f4*)(be + 4 * c4); }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c4 = cl + 16 * (u0 + u);
-                        if (c4 < w4) {
-                            f4 y = post_a4<PRO>(v[u], gt[u]);
+                    for (int u = 0; u < UB; ++u) {
+                        if (LPR * (u0 + u) >= w4) continue;
+                        const int c4 = cl + LPR * (u0 + u);
+                        f4 y = sum_slabs<NS>(t[u], nslab);
+                        if (relu_in) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = row_ok ? y[e] : 0.f;
+                            for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.f);
+                        }
+                        if (PROC >= 2 && pro == ES_PRO_GEGLU) {
+                            const f4 g = sum_slabs<NS>(gt[PROC >= 2 ? u : 0], nslab);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = y[q] * es_gelu(g[q]);
+                        } else if (PROC >= 2 && pro == ES_PRO_SILU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = es_silu(y[q]);
+                        } else if (PROC >= 1 && gn) {
+                            // (lanes past the region hold clamped duplicates of the last float4: their groups are whole
+                            //  duplicates too, because w4 is a multiple of lpg -- no foreign value enters a real group)
+                            float sm = (y[0] + y[1]) + (y[2] + y[3]);
+                            for (int o = 1; o < lpg; o <<= 1) sm += __shfl_xor(sm, o, LPR);
+                            const float inv_gs = 1.0f / (float)sg.gs;          // gs is a power of two: the multiplies below are exact divisions
+                            const float mean = sm * inv_gs;
+                            float sq = 0.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { const float d = y[q] - mean; sq += d * d; }
+                            for (int o = 1; o < lpg; o <<= 1) sq += __shfl_xor(sq, o, LPR);
+                            const float rstd = 1.0f / sqrtf(sq * inv_gs + sg.eps);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float z = (y[q] - mean) * rstd * gav[PROC >= 1 ? u : 0][q] + bev[PROC >= 1 ? u : 0][q];
+                                if (pro == ES_PRO_GN_SILU) z = es_silu(z);
+                                y[q] = z;
+                            }
+                        }
+                        if (c4 < w4) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = row_ok ? y[q] : 0.f;
                             *(f4*)(dst + 4 * c4) = y;
                         }
                     }
@@ -119,214 +199,157 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, Smem& sm, i
         koff += sg.width;
     }
     // zero the K padding (K not a multiple of 16)
-    const int kend = min(kc0 + kc, a.K) - kc0;
-    for (int c = kend + cl; c < kc; c += 16) sm.x[r][c] = 0.f;
+    const int kend = min(c0 + kc, a.K) - c0;
+    for (int c = kend + cl; c < kc; c += LPR) x[r * ldx + c] = 0.f;
 }
 
-// Norm prologues (GroupNorm32 [+SiLU] / LayerNorm) done while staging: the thread that stages columns
-// 4*(cl + 16u) of row r keeps them in registers (u < K/64 <= 16), statistics are reduced with lane shuffles inside the
-// 16-lane row group (GroupNorm group = gs/4 adjacent lanes; LayerNorm = all 16), the normalised tile is written to LDS
-// once.  No dependent LDS walks, no per-element global loads of the affine (gamma/beta sit in LDS).
-template <int PRO>
-__device__ __forceinline__ void stage_norm_load(const es_linear_args& a, int m0, int tid, f4 (&v)[16]) {
-    const int r = tid >> 4, cl = tid & 15;
-    const int m = m0 + r;
-    const int mc = m < a.M ? m : a.M - 1;
-    const int nu = a.K >> 6;                             // K % 64 == 0 (host-checked)
-    const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        if (u < nu) {
-            const int c0 = u << 6;                       // first column of this 64-wide slice: uniform segment choice
-            const es_seg& sg = c0 < w0 ? a.seg[0] : (c0 < w0 + w1 ? a.seg[1] : a.seg[2]);
-            const int cb = c0 < w0 ? 0 : (c0 < w0 + w1 ? w0 : w0 + w1);
-            v[u] = *(const f4*)(seg_base(sg) + (long)mc * sg.ld + (c0 - cb) + 4 * cl);
-        }
-    }
-}
-
-template <int PRO>
-__device__ __forceinline__ void stage_norm(const es_linear_args& a, Smem& sm, int m0, int tid, f4 (&v)[16]) {
-    const int r = tid >> 4, cl = tid & 15;
+// LayerNorm prologue: the operand is ONE direct segment of width K <= 128 * LNU.  Thread (r, cl) fetches its LNU float4 of
+// the WHOLE row (all slabs, all in flight), keeps them in registers for the statistics (two passes, 32-lane shuffles) and writes
+// the normalised columns of the slice [c0, c0 + kc) to the LDS tile -- the statistics need the row, the product only the slice.
+template <int NS, int LNU>
+__device__ __forceinline__ void stage_ln(const es_linear_args& a, float* x, int ldx, int m0, int c0, int kc, int tid) {
+    const int r = tid >> 5, cl = tid & (LPR - 1);
     const int m = m0 + r;
     const bool row_ok = m < a.M;
-    const int K = a.K, nu = K >> 6;
-    if (PRO == ES_PRO_LN) {
-        float s = 0.f;
+    const int mc = row_ok ? m : a.M - 1;
+    const es_seg& sg = a.seg[0];
+    const int K = sg.width, w4 = K >> 2;
+    const float* src = seg_base(sg) + (long)blockIdx.z * a.a_bstride + (long)mc * sg.ld;
+    const int nslab = sg.nslab > 1 ? sg.nslab : 1;
+    f4 v[LNU];
+    {
+        f4 t[LNU][NS];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) if (u < nu) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        for (int u = 0; u < LNU; ++u) load_slabs<NS>(t[u], src + 4 * min(cl + LPR * u, w4 - 1), nslab, sg.slab_stride);
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-        const float mean = s / (float)K;
-        float q = 0.f;
+        for (int u = 0; u < LNU; ++u) v[u] = sum_slabs<NS>(t[u], nslab);
+    }
+    float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) if (u < nu) {
+    for (int u = 0; u < LNU; ++u) if (cl + LPR * u < w4) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    const float mean = s / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < LNU; ++u) {
+        if (cl + LPR * u < w4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; q += d * d; }
         }
+    }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 16);
-        const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, LPR);
+    const float rstd = 1.0f / sqrtf(q / (float)K + sg.eps);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) if (u < nu) {
-            const int c = (u << 6) + 4 * cl;
-            const f4 ga = *(const f4*)&sm.gb[0][c], be = *(const f4*)&sm.gb[1][c];
+    for (int u = 0; u < LNU; ++u) {
+        const int c = 4 * (cl + LPR * u);
+        if (c >= c0 && c < c0 + kc && c < K) {
+            const f4 ga = *(const f4*)(sg.gamma + c), be = *(const f4*)(sg.beta + c);
             f4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = row_ok ? (v[u][e] - mean) * rstd * ga[e] + be[e] : 0.f;
-            *(f4*)&sm.x[r][c] = y;
-        }
-    } else {
-        const int gs = K >> 5;                           // channels per group: 4, 8, 16 or 32  (K = 128 .. 1024)
-        const int lpg = gs >> 2;                         // lanes per group: 1, 2, 4, 8
-#pragma unroll
-        for (int u = 0; u < 16; ++u) if (u < nu) {
-            float s = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-            for (int o = 1; o < lpg; o <<= 1) s += __shfl_xor(s, o, 16);
-            const float mean = s / (float)gs;
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - mean; q += d * d; }
-            for (int o = 1; o < lpg; o <<= 1) q += __shfl_xor(q, o, 16);
-            const float rstd = 1.0f / sqrtf(q / (float)gs + a.eps);
-            const int c = (u << 6) + 4 * cl;
-            const f4 ga = *(const f4*)&sm.gb[0][c], be = *(const f4*)&sm.gb[1][c];
-            f4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (v[u][e] - mean) * rstd * ga[e] + be[e];
-                if (PRO == ES_PRO_GN_SILU) t = es_silu(t);
-                y[e] = row_ok ? t : 0.f;
-            }
-            *(f4*)&sm.x[r][c] = y;
+            *(f4*)&x[r * ldx + (c - c0)] = y;
         }
     }
+    const int kend = min(c0 + kc, a.K) - c0;
+    for (int c = kend + cl; c < kc; c += LPR) x[r * ldx + c] = 0.f;
 }
 
-template <int PRO>
-__global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a) {
-    __shared__ Smem sm;
+// grid.x = column tiles x K slices (slice fastest: with the observed block -> XCD b % 8 placement the column tiles of one
+// slice share an XCD, i.e. one L2 copy of that slice of A -- speed only), grid.y = row tiles, grid.z = batch.
+// NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
+// unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
+template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI>
+__global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a, int S, int kbps, int ldx, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* x = smem;                                     // [MT][ldx]
+    float* red = smem + MT * ldx;                        // [NKG][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x;
+    const int slice = blockIdx.x % S, nt = blockIdx.x / S;
     const int m0 = blockIdx.y * MT;
-    const int Kp = (a.K + 15) & ~15;
-    const int nkb_total = Kp >> 4;
+    const int nkb_total = (a.K + 15) >> 4;
+    const int kb0 = slice * kbps, kb1 = slice == S - 1 ? nkb_total : kb0 + kbps;
     const int bz = blockIdx.z;                           // batched launch: z-th problem of identical shape
-    const f4* wp = (const f4*)a.wpack + ((size_t)bz * gridDim.x + nt) * nkb_total * 64;
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int nct = gridDim.x / S;
+    const f4* wp = (const f4*)a.wpack + ((size_t)bz * nct + nt) * nkb_total * 64;
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, q = lane >> 4;
 
-    // (0) Epilogue operands (bias, residuals, the affine of the second GroupNorm output) depend only on the output
-    // coordinates: issued FIRST so that their latency overlaps the weight stream, the staging and the product instead
-    // of adding one more dependent L2/HBM round trip after the reduction (launches here are ~5 us of pure latency).
-    const int ml = tid >> 4, nl = tid & 15;              // 32 x 16 outputs, one per thread
-    const int m_e = m0 + ml, n_e = nt * 16 + nl;
-    const bool geglu = a.act == ES_ACT_GEGLU;
+    // (0) Epilogue operands depend only on the output coordinates: issued FIRST so that their latency overlaps the weight
+    // stream, the staging and the product.  Thread (ml, nl), tid < 256, owns output (ml, nl) of the 16 x 16 tile.
+    const int ml = (tid >> 4) & 15, nl = tid & 15;
+    const int n_e = nt * 16 + nl, m_e = m0 + ml;
+    const bool geglu = GEGLU_EPI && a.act == ES_ACT_GEGLU;
     const float* bias = a.bias ? a.bias + (long)bz * a.N : nullptr;
-    const bool ok_e = m_e < a.M && n_e < a.N;
     const int nres = geglu ? nt * 8 + nl : n_e;          // column of the residual / output
+    const bool first = slice == 0;                       // slice 0 carries bias and residuals
+    float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f;
+    const bool ok_e = tid < 256 && m_e < a.M && n_e < a.N;
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
-    float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f, e_g2 = 0.f, e_b2 = 0.f;
-    if (bias && n_e < a.N) e_bias = bias[n_e];
-    if (a.res && ok_res) e_res = a.res[(long)m_e * a.res_ld + nres];
-    if (a.res2 && ok_res) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
-    if (a.out2 && ok_e) { e_g2 = a.gn2_gamma[n_e]; e_b2 = a.gn2_beta[n_e]; }
+    if (first && a.res && ok_res)
+        e_res = load_slabs1(a.res + (long)m_e * a.res_ld + nres, a.res_nslab > 1 ? a.res_nslab : 1, a.res_slab_stride);
+    if (first && a.res2 && ok_res) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
+    if (first && bias && n_e < a.N) e_bias = bias[n_e];
+    const int kg = wave;
 
-    for (int kc0 = 0; kc0 < Kp; kc0 += KC) {
-        const int kc = min(KC, Kp - kc0);
+    for (int c0 = kb0 * 16; c0 < kb1 * 16; c0 += KCH) {
+        const int kc = min(KCH, kb1 * 16 - c0);
         const int nkb = kc >> 4;
         // (1) issue this wave's weight-fragment loads first: HBM latency overlaps the staging below
         f4 bf[MAXJ];
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int kb = min(wave + j * NWAVE, nkb - 1);
-            bf[j] = __builtin_nontemporal_load(&wp[(size_t)((kc0 >> 4) + kb) * 64 + lane]);
+            const int kb = kg + j * NKG;
+            bf[j] = f4{1.f, 1.f, 1.f, 1.f};
+            if (kb < nkb && !(dbg & 1)) bf[j] = __builtin_nontemporal_load(&wp[(size_t)((c0 >> 4) + kb) * 64 + lane]);
         }
-        // (2) stage the activation chunk with its prologue applied
-        if (kc0 > 0) __syncthreads();
-        if (PRO == ES_PRO_GN || PRO == ES_PRO_GN_SILU || PRO == ES_PRO_LN) {
-            // affine (one float4 per thread: K <= KC, single chunk) and the activation rows are fetched in ONE round
-            // trip; the affine goes through LDS because every row needs all of it
-            const int c = tid * 4;
-            f4 gv = {0.f, 0.f, 0.f, 0.f};
-            const bool isg = c < a.K, isb = !isg && c - NTHREAD * 2 >= 0 && c - NTHREAD * 2 < a.K;
-            if (isg) gv = *(const f4*)&a.gamma[c];
-            else if (isb) gv = *(const f4*)&a.beta[c - NTHREAD * 2];
-            f4 v[16];
-            stage_norm_load<PRO>(a, m0, tid, v);
-            if (isg) *(f4*)&sm.gb[0][c] = gv;
-            else if (isb) *(f4*)&sm.gb[1][c - NTHREAD * 2] = gv;
-            __syncthreads();
-            stage_norm<PRO>(a, sm, m0, tid, v);
-        } else {
-            stage_chunk<PRO>(a, sm, m0, kc0, kc, tid);
-        }
+        // (2) stage the activation slice with its prologue applied
+        if (c0 > kb0 * 16) __syncthreads();
+        if (dbg & 2) { }
+        else if (LNU > 0) stage_ln<NS, (LNU > 0 ? LNU : 1)>(a, x, ldx, m0, c0, kc, tid);
+        else stage_chunk<NS, PROC, CSR>(a, x, ldx, m0, c0, kc, tid);
         __syncthreads();
-        // (4) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block, 2 row tiles
+        // (3) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            const int kb = wave + j * NWAVE;
+            const int kb = kg + j * NKG;
             if (kb < nkb) {
-                const f4 a0 = *(const f4*)&sm.x[i16][kb * 16 + 4 * q];
-                const f4 a1 = *(const f4*)&sm.x[16 + i16][kb * 16 + 4 * q];
+                const f4 a0 = *(const f4*)&x[i16 * ldx + kb * 16 + 4 * q];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bf[j][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bf[j][s], acc1, 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bf[j][s], acc0, 0, 0, 0);
             }
         }
     }
-    // (5) fixed-order cross-wave reduction through LDS, then the epilogue: one output per thread
+    // (4) fixed-order reduction over the k-block groups through LDS, then the epilogue: one output per thread
+    *(f4*)&red[wave * 256 + lane * 4] = acc0;
     __syncthreads();
-    float* red = &sm.x[0][0];                            // [NWAVE][2][256]
-    *(f4*)&red[(wave * 2 + 0) * 256 + lane * 4] = acc0;
-    *(f4*)&red[(wave * 2 + 1) * 256 + lane * 4] = acc1;
-    __syncthreads();
-    const int mt = ml >> 4, row = ml & 15;
     // D layout of mfma 16x16: lane = (row>>2)*16 + col holds D[row][col] in register row&3
-    const int off = mt * 256 + ((row >> 2) * 16 + nl) * 4 + (row & 3);
-    float s = 0.f;
+    const int off = ((ml >> 2) * 16 + nl) * 4 + (ml & 3);
+    float sres = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) s += red[w * 512 + off];
-    const int m = m_e, n = n_e;
-    float* out = a.out + (long)bz * a.out_bstride;
-    if (geglu) {
+    for (int w = 0; w < NKG; ++w) sres += red[w * 256 + off];
+    float* out = a.out + (long)bz * a.out_bstride + (long)slice * a.out_slab_stride;
+    if (GEGLU_EPI && geglu) {
         // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt + nl, lane nl + 8 its gate
-        float sb = s + e_bias;
+        float sb = sres + e_bias;
         const float gate = __shfl_xor(sb, 8, 16);
         if (ok_res) {
             float v = sb * es_gelu(gate);
             if (a.res) v += e_res;
-            out[(long)m * a.out_ld + nres] = v;
+            out[(long)m_e * a.out_ld + nres] = v;
         }
         return;
     }
-    const bool ok = ok_e;
-    if (ok) {
-        if (bias) s += e_bias;
-        if (a.act == ES_ACT_RELU) s = fmaxf(s, 0.f);
-        else if (a.act == ES_ACT_SILU) s = es_silu(s);
-        if (a.res) s += e_res;
-        if (a.res2) s += e_res2;
-        out[(long)m * a.out_ld + n] = s;
-    }
-    if (a.out2) {
-        // the 16 lanes of a row hold one GroupNorm32 group of the output (N = 512): two-pass statistics by shuffles
-        float t = ok ? s : 0.f;
-        float sum = t;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float mean = sum * (1.0f / 16.0f);
-        const float d = t - mean;
-        float sq = d * d;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
-        if (ok) {
-            float y = d * rsqrtf(sq * (1.0f / 16.0f) + a.gn2_eps) * e_g2 + e_b2;
-            if (a.gn2_silu) y = es_silu(y);
-            a.out2[(long)m * a.out2_ld + n] = y;
+    if (ok_e) {
+        if (first) {
+            if (bias) sres += e_bias;
+            if (a.act == ES_ACT_RELU) sres = fmaxf(sres, 0.f);
+            else if (a.act == ES_ACT_SILU) sres = es_silu(sres);
+            if (a.res) sres += e_res;
+            if (a.res2) sres += e_res2;
         }
+        out[(long)m_e * a.out_ld + n_e] = sres;
     }
 }
 
@@ -336,7 +359,7 @@ __global__ void k_ddpm_update(const es_update_args a) {
     const int st = *a.step;
     if (i < a.n) {
         const float* c = a.coef + (long)st * a.coef_stride;
-        const float x = a.x[i], e = a.eps[i];
+        const float x = a.x[i], e = load_slabs1(a.eps + i, a.eps_nslab > 1 ? a.eps_nslab : 1, a.eps_slab_stride);
         const float nz = a.noise[(long)st * a.noise_stride + i];
         const float x0 = c[0] * x - c[1] * e;
         const float mean = c[2] * x0 + c[3] * x;
@@ -350,7 +373,7 @@ __global__ void k_ddim_update(const es_update_args a) {
     const int st = *a.step;
     if (i < a.n) {
         const float* c = a.coef + (long)st * a.coef_stride;
-        const float x = a.x[i], e = a.eps[i];
+        const float x = a.x[i], e = load_slabs1(a.eps + i, a.eps_nslab > 1 ? a.eps_nslab : 1, a.eps_slab_stride);
         const float px0 = (x - c[0] * e) / c[1];
         a.x[i] = c[2] * px0 + c[3] * e;
     }
@@ -423,46 +446,159 @@ extern "C" int es_pack_linear_geglu_f32(const float* w, const float* h_bias, int
     return rc;
 }
 
-extern "C" int es_linear_rows_f32(const es_linear_args* a, es_stream stream) {
-    ES_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "es_linear_rows_f32: nseg=%d", a->nseg);
-    int ksum = 0;
+// K-slice choice.  It depends on (K, N) only -- never on M -- so that a row's arithmetic is independent of the batch it is part of.
+// kb_per_slice = 0: automatic when the op allows a split (no activation / GEGLU epilogue), else one slice.
+extern "C" int es_linear_rows_slices(const es_linear_args* a, int* kb_per_slice) {
+    const int nkb = (a->K + 15) / 16;
+    int kalign = 1;                                       // slices are cut at multiples of the largest GroupNorm group
     for (int s = 0; s < a->nseg; ++s) {
-        ES_REQUIRE(a->seg[s].width % 4 == 0 && a->seg[s].ld % 4 == 0,
+        const int pro = a->seg[s].pro ? a->seg[s].pro : a->prologue;
+        if (pro == ES_PRO_GN || pro == ES_PRO_GN_SILU) {
+            const int gs = a->seg[s].gs ? a->seg[s].gs : a->K / 32;
+            if (gs > 16 * kalign) kalign = (gs + 15) / 16;
+        }
+    }
+    int kbps = a->kb_per_slice;
+    if (kbps <= 0 || kbps >= nkb) { *kb_per_slice = nkb; return 1; }
+    kbps = (kbps + kalign - 1) / kalign * kalign;
+    if (kbps >= nkb) { *kb_per_slice = nkb; return 1; }
+    *kb_per_slice = kbps;
+    return (nkb + kbps - 1) / kbps;
+}
+
+extern "C" int es_linear_rows_auto_slices(int K, int N, int kalign_cols) {
+    // ~256 workgroups for TWO 16-row tiles (M = 32, one scene), slices of at least 128 columns (one k-block per wave), <= 8 slabs
+    static const char* env = getenv("ES_ROWS_SPLIT");     // A/B switch: 0 = never split, n = target workgroup count
+    int target = 256;
+    if (env) { target = atoi(env); if (target <= 0) return 0; }
+    const int nkb = (K + 15) / 16, nct = (N + 15) / 16;
+    int S = target / (2 * nct);
+    if (S > 8) S = 8;
+    if (S <= 1) return 0;
+    int kbps = (nkb + S - 1) / S;
+    if (kbps < 8) kbps = 8;
+    const int kal = kalign_cols > 16 ? (kalign_cols + 15) / 16 : 1;
+    kbps = (kbps + kal - 1) / kal * kal;
+    return kbps >= nkb ? 0 : kbps;
+}
+
+extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) {
+    es_linear_args a = *a_in;
+    ES_REQUIRE(a.nseg >= 1 && a.nseg <= 3, "es_linear_rows_f32: nseg=%d", a.nseg);
+    int ksum = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        ES_REQUIRE(a.seg[s].width % 4 == 0 && a.seg[s].ld % 4 == 0,
                    "es_linear_rows_f32: segment %d width/ld must be multiples of 4 (width=%d ld=%d)", s,
-                   a->seg[s].width, a->seg[s].ld);
-        ksum += a->seg[s].width;
+                   a.seg[s].width, a.seg[s].ld);
+        ES_REQUIRE(a.seg[s].nslab <= 1 || a.seg[s].slab_stride % 4 == 0, "es_linear_rows_f32: segment %d slab stride %d", s, a.seg[s].slab_stride);
+        ksum += a.seg[s].width;
     }
-    ES_REQUIRE(ksum == a->K, "es_linear_rows_f32: segment widths sum to %d, K=%d", ksum, a->K);
-    ES_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "es_linear_rows_f32: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
-    const bool norm = a->prologue == ES_PRO_GN || a->prologue == ES_PRO_GN_SILU || a->prologue == ES_PRO_LN;
-    if (norm) {
-        ES_REQUIRE(a->K <= KC && a->K % 64 == 0, "es_linear_rows_f32: norm prologue needs K <= %d and K %% 64 == 0 (K=%d)", KC, a->K);
-        ES_REQUIRE(a->gamma && a->beta, "es_linear_rows_f32: norm prologue without affine");
-        for (int s = 0; s < a->nseg; ++s)
-            ES_REQUIRE(a->seg[s].mode == ES_SEG_DIRECT && a->seg[s].width % 64 == 0,
-                       "es_linear_rows_f32: norm prologue needs direct segments with width %% 64 == 0");
-        if (a->prologue != ES_PRO_LN)
-            ES_REQUIRE(a->K % 128 == 0, "es_linear_rows_f32: GroupNorm32 prologue needs K %% 128 == 0 (K=%d)", a->K);
+    ES_REQUIRE(ksum == a.K, "es_linear_rows_f32: segment widths sum to %d, K=%d", ksum, a.K);
+    ES_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "es_linear_rows_f32: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    // the op-level prologue is shorthand for "every segment": GroupNorm32 / LayerNorm over the concatenation
+    if (a.prologue != ES_PRO_NONE) {
+        const bool norm = a.prologue == ES_PRO_GN || a.prologue == ES_PRO_GN_SILU || a.prologue == ES_PRO_LN;
+        if (norm) ES_REQUIRE(a.gamma && a.beta, "es_linear_rows_f32: norm prologue without affine");
+        if (a.prologue == ES_PRO_GN || a.prologue == ES_PRO_GN_SILU)
+            ES_REQUIRE(a.K % 128 == 0, "es_linear_rows_f32: GroupNorm32 prologue needs K %% 128 == 0 (K=%d)", a.K);
+        int koff = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            ES_REQUIRE(a.seg[s].pro == ES_PRO_NONE, "es_linear_rows_f32: op-level and segment-level prologues are exclusive");
+            a.seg[s].pro = a.prologue;
+            if (norm) {
+                a.seg[s].gamma = a.gamma + koff; a.seg[s].beta = a.beta + koff; a.seg[s].eps = a.eps;
+                a.seg[s].gs = a.prologue == ES_PRO_LN ? a.K : a.K / 32;
+            }
+            koff += a.seg[s].width;
+        }
     }
-    if (a->prologue == ES_PRO_GEGLU)
-        ES_REQUIRE(a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
-    const int nb = a->nbatch > 1 ? a->nbatch : 1;
-    ES_REQUIRE(nb == 1 || (a->nseg == 1 && a->seg[0].mode == ES_SEG_DIRECT && !norm && !a->res && !a->res2),
-               "es_linear_rows_f32: batched launch supports one direct segment, no norm prologue, no residuals");
-    ES_REQUIRE(a->act != ES_ACT_GEGLU || (a->N % 16 == 0 && !a->res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
-    ES_REQUIRE(!a->out2 || (a->N == 512 && a->act != ES_ACT_GEGLU && nb == 1 && a->gn2_gamma && a->gn2_beta),
-               "es_linear_rows_f32: the GroupNorm32 second output needs N == 512 (N=%d), an affine, no GEGLU, no batching", a->N);
-    dim3 grid((a->N + 15) / 16, (a->M + MT - 1) / MT, nb);
+    bool has_ln = false;
+    {
+        int koff = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const es_seg& sg = a.seg[s];
+            if (sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) {
+                ES_REQUIRE(sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta, "es_linear_rows_f32: GroupNorm segments are direct, with an affine");
+                ES_REQUIRE(sg.gs >= 4 && sg.gs <= 32 && (sg.gs & (sg.gs - 1)) == 0 && sg.width % sg.gs == 0 && koff % sg.gs == 0,
+                           "es_linear_rows_f32: GroupNorm group size %d (4..32, power of two, dividing the segment width %d and its offset %d)",
+                           sg.gs, sg.width, koff);
+            } else if (sg.pro == ES_PRO_LN) {
+                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta && sg.width <= 1024,
+                           "es_linear_rows_f32: LayerNorm prologue needs ONE direct segment of width <= 1024 with an affine");
+                has_ln = true;
+            } else if (sg.pro == ES_PRO_GEGLU) {
+                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
+            } else {
+                ES_REQUIRE(sg.pro == ES_PRO_NONE || sg.pro == ES_PRO_SILU, "es_linear_rows_f32: unknown prologue %d", sg.pro);
+            }
+            ES_REQUIRE(sg.pre_act == ES_ACT_NONE || sg.pre_act == ES_ACT_RELU, "es_linear_rows_f32: segment input activation %d", sg.pre_act);
+            koff += sg.width;
+        }
+    }
+    const int nb = a.nbatch > 1 ? a.nbatch : 1;
+    ES_REQUIRE(nb == 1 || (a.nseg == 1 && a.seg[0].mode == ES_SEG_DIRECT && a.seg[0].pro == ES_PRO_NONE && !a.res && !a.res2),
+               "es_linear_rows_f32: batched launch supports one direct segment, no prologue, no residuals");
+    ES_REQUIRE(a.act != ES_ACT_GEGLU || (a.N % 16 == 0 && !a.res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
+    int kbps = 0;
+    const int S = es_linear_rows_slices(&a, &kbps);
+    ES_REQUIRE(S == 1 || (a.act == ES_ACT_NONE && nb == 1 && a.out_slab_stride >= a.M * a.out_ld),
+               "es_linear_rows_f32: a K split (%d slices) needs no activation epilogue, no batching and out_slab_stride >= M * out_ld", S);
+    const int kcmax = kbps * 16 < KCH ? kbps * 16 : KCH;
+    const int ldx = kcmax + 8;
+    const size_t lds = (size_t)(MT * ldx + NWAVE * 256) * sizeof(float);
+    int nsmax = 1;
+    for (int s = 0; s < a.nseg; ++s) if (a.seg[s].nslab > nsmax) nsmax = a.seg[s].nslab;
+    ES_REQUIRE(nsmax <= 8, "es_linear_rows_f32: a segment with %d slabs (max 8)", nsmax);
+    ES_REQUIRE(!has_ln || nsmax <= 2, "es_linear_rows_f32: the LayerNorm operand may have at most 2 slabs (%d)", nsmax);
+    dim3 grid((unsigned)(((a.N + 15) / 16) * S), (a.M + MT - 1) / MT, nb);
     hipStream_t st = (hipStream_t)stream;
-    switch (a->prologue) {
-        case ES_PRO_NONE: hipLaunchKernelGGL(k_linear_rows<ES_PRO_NONE>, grid, dim3(NTHREAD), 0, st, *a); break;
-        case ES_PRO_SILU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_SILU>, grid, dim3(NTHREAD), 0, st, *a); break;
-        case ES_PRO_GN: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GN>, grid, dim3(NTHREAD), 0, st, *a); break;
-        case ES_PRO_GN_SILU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GN_SILU>, grid, dim3(NTHREAD), 0, st, *a); break;
-        case ES_PRO_LN: hipLaunchKernelGGL(k_linear_rows<ES_PRO_LN>, grid, dim3(NTHREAD), 0, st, *a); break;
-        case ES_PRO_GEGLU: hipLaunchKernelGGL(k_linear_rows<ES_PRO_GEGLU>, grid, dim3(NTHREAD), 0, st, *a); break;
-        default: ES_REQUIRE(false, "es_linear_rows_f32: unknown prologue %d", a->prologue);
+    int proc = 0;
+    bool csr = false;
+    for (int s = 0; s < a.nseg; ++s) {
+        const int pro = a.seg[s].pro;
+        if (pro == ES_PRO_GN || pro == ES_PRO_GN_SILU) proc = proc < 1 ? 1 : proc;
+        if (pro == ES_PRO_SILU || pro == ES_PRO_GEGLU) proc = 2;
+        csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN;
     }
+    const bool gepi = a.act == ES_ACT_GEGLU;
+    // kernel table: lean instantiations for what the sampling path launches, one general kernel per slab bound for the rest
+    static const void* const k_plain[4][2] = {
+        {(const void*)k_linear_rows<1, 0, false, 0, false>, (const void*)k_linear_rows<1, 1, false, 0, false>},
+        {(const void*)k_linear_rows<2, 0, false, 0, false>, (const void*)k_linear_rows<2, 1, false, 0, false>},
+        {(const void*)k_linear_rows<4, 0, false, 0, false>, (const void*)k_linear_rows<4, 1, false, 0, false>},
+        {(const void*)k_linear_rows<8, 0, false, 0, false>, (const void*)k_linear_rows<8, 1, false, 0, false>}};
+    static const void* const k_general[4] = {
+        (const void*)k_linear_rows<1, 2, true, 0, true>, (const void*)k_linear_rows<2, 2, true, 0, true>,
+        (const void*)k_linear_rows<4, 2, true, 0, true>, (const void*)k_linear_rows<8, 2, true, 0, true>};
+    static const void* const k_ln[2][2] = {
+        {(const void*)k_linear_rows<1, 0, false, 4, true>, (const void*)k_linear_rows<2, 0, false, 4, true>},
+        {(const void*)k_linear_rows<1, 0, false, 8, true>, (const void*)k_linear_rows<2, 0, false, 8, true>}};
+    static const void* const k_csr = (const void*)k_linear_rows<1, 0, true, 0, false>;
+    const int nsi = nsmax <= 1 ? 0 : nsmax <= 2 ? 1 : nsmax <= 4 ? 2 : 3;
+    const void* fn = nullptr;
+    if (has_ln) fn = k_ln[a.K <= 512 ? 0 : 1][nsi];
+    else if (csr && proc == 0 && nsmax == 1 && !gepi) fn = k_csr;
+    else if (!csr && proc <= 1 && !gepi) fn = k_plain[nsi][proc];
+    else fn = k_general[nsi];
+    {   // one-off per process, thread-safe: dynamic LDS limit (a 512-column chunk needs 73 KiB)
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            constexpr int bytes = (MT * (KCH + 8) + NWAVE * 256) * 4;
+            auto set = [](const void* f) {
+                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+            };
+            for (int i = 0; i < 4; ++i) { set(k_plain[i][0]); set(k_plain[i][1]); set(k_general[i]); }
+            for (int i = 0; i < 2; ++i) { set(k_ln[i][0]); set(k_ln[i][1]); }
+            set(k_csr);
+        });
+        ES_REQUIRE(attr_err == hipSuccess, "es_linear_rows_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    }
+    static const char* dbg_env = getenv("ES_ROWS_DBG");          // ablation switches of tools/microbench_rows.py (1: no weight loads, 2: no staging)
+    int dbg = dbg_env ? atoi(dbg_env) : 0;
+    void* kargs[] = {(void*)&a, (void*)&S, (void*)&kbps, (void*)&ldx, (void*)&dbg};
+    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, lds, st));
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

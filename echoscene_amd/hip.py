@@ -26,21 +26,23 @@ OP_FORK, OP_JOIN, OP_ROWSEL = 13, 14, 15
 class Seg(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('idx', C.c_void_p), ('ent_row', C.c_void_p), ('ent_off', C.c_void_p),
                 ('step', C.c_void_p), ('step_stride', C.c_int32), ('ld', C.c_int32), ('width', C.c_int32),
-                ('mode', C.c_int32)]
+                ('mode', C.c_int32), ('nslab', C.c_int32), ('slab_stride', C.c_int32), ('pre_act', C.c_int32),
+                ('pro', C.c_int32), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('gs', C.c_int32)]
 
 
 class LinearArgs(C.Structure):
     _fields_ = [('seg', Seg * 3), ('nseg', C.c_int32), ('M', C.c_int32), ('K', C.c_int32), ('N', C.c_int32),
                 ('wpack', C.c_void_p), ('bias', C.c_void_p), ('prologue', C.c_int32), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('eps', C.c_float), ('act', C.c_int32), ('res', C.c_void_p),
-                ('res_ld', C.c_int32), ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
+                ('res_ld', C.c_int32), ('res_nslab', C.c_int32), ('res_slab_stride', C.c_int32),
+                ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
                 ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32),
-                ('out2', C.c_void_p), ('out2_ld', C.c_int32), ('gn2_gamma', C.c_void_p), ('gn2_beta', C.c_void_p),
-                ('gn2_eps', C.c_float), ('gn2_silu', C.c_int32)]
+                ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32)]
 
 
 class UpdateArgs(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('noise', C.c_void_p), ('noise_stride', C.c_int32),
+    _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('eps_nslab', C.c_int32), ('eps_slab_stride', C.c_int32),
+                ('noise', C.c_void_p), ('noise_stride', C.c_int32),
                 ('coef', C.c_void_p), ('coef_stride', C.c_int32), ('step', C.c_void_p), ('n', C.c_int32),
                 ('inc_step', C.c_int32)]
 
@@ -118,6 +120,8 @@ EXPORTS = {
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    'es_linear_rows_slices': (C.c_int, [C.POINTER(LinearArgs), C.POINTER(C.c_int)]),
+    'es_linear_rows_auto_slices': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),
     'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
@@ -168,7 +172,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 2:
+        if L.es_abi_version() != 3:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -15,21 +15,44 @@ from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, RowSelArgs, Op
 
 
 class View:
-    """Pointer + leading dimension into a device matrix (column slices without copies)."""
+    """Pointer + leading dimension into a device matrix (column slices without copies).
+    ``nslab`` > 1: a SLAB tensor -- the split-K output of a rows launch, whose value is the fixed-order sum of ``nslab``
+    matrices ``slab_stride`` floats apart; whoever reads it (A segment, residual, DDPM update) sums the slabs."""
 
-    def __init__(self, t, col=0, ld=None, width=None, row=0):
+    def __init__(self, t, col=0, ld=None, width=None, row=0, nslab=1, slab_stride=0):
         self.t = t
         self.col = col
         self.row = row
         self.ld = (t.shape[-1] if t.dim() > 1 else 0) if ld is None else ld
         self.width = (t.shape[-1] - col) if width is None else width
+        self.nslab = nslab
+        self.slab_stride = slab_stride
 
     @property
     def ptr(self):
         return self.t.data_ptr() + 4 * (self.col + self.row * self.ld)
 
+    def cols(self, col, width):
+        """column slice of this view (slab tensors stay slab tensors)"""
+        return View(self.t, col=self.col + col, ld=self.ld, width=width, row=self.row, nslab=self.nslab,
+                    slab_stride=self.slab_stride)
 
-def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=None, step_stride=0, width=None):
+    def value(self):
+        """the matrix this view denotes, as a fresh tensor (tests / debugging only: sums the slabs in torch)"""
+        rows = self.t.shape[-2] if self.t.dim() > 1 else 1
+        base = self.t.storage_offset() + self.col + self.row * self.ld
+        out = None
+        for j in range(max(self.nslab, 1)):
+            m = self.t.as_strided((rows, self.width), (max(self.ld, 0), 1), base + j * self.slab_stride)
+            out = m.clone() if out is None else out + m
+        return out
+
+
+def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=None, step_stride=0, width=None,
+        pro=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, gs=0, pre_act=hip.ACT_NONE, goff=0):
+    """One K segment of a rows launch.  pro/gamma/beta/eps/gs: the segment's own prologue (GroupNorm in groups of ``gs``
+    channels, LayerNorm, SiLU); ``goff``: offset of the segment's first channel inside gamma/beta; ``pre_act``: activation
+    applied to the (slab-summed) source first."""
     s = Seg()
     s.ptr = view.ptr
     s.idx = idx.data_ptr() if idx is not None else None
@@ -40,7 +63,28 @@ def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=No
     s.ld = view.ld
     s.width = view.width if width is None else width
     s.mode = mode
+    s.nslab, s.slab_stride = view.nslab, view.slab_stride
+    s.pre_act = pre_act
+    s.pro = pro
+    s.gamma = gamma.data_ptr() + 4 * goff if gamma is not None else None
+    s.beta = beta.data_ptr() + 4 * goff if beta is not None else None
+    s.eps = eps
+    s.gs = gs
+    s._keep = (view.t, idx, ent_row, ent_off, step, gamma, beta)
     return s
+
+
+def norm_segs(views, gamma, beta, eps, silu, C=None, groups=32):
+    """segments of GroupNorm32(+SiLU) over the channel concatenation of ``views`` (th.cat([h, hs.pop()]) followed by
+    normalization(ch), openai_model_3d.py / denoise_net.py ResBlock.in_layers): groups never straddle a source."""
+    C = sum(v.width for v in views) if C is None else C
+    gs = C // groups
+    out, off = [], 0
+    for v in views:
+        assert v.width % gs == 0 and off % gs == 0
+        out.append(seg(v, pro=hip.PRO_GN_SILU if silu else hip.PRO_GN, gamma=gamma, beta=beta, eps=eps, gs=gs, goff=off))
+        off += v.width
+    return out
 
 
 class PackedLinear:
@@ -176,6 +220,7 @@ class Builder:
         # side-stream graph branches: measured SLOWER on MI355X (2.27 vs 2.06 ms per layout step) -- off by default
         self.use_lanes = os.environ.get('ES_LANES', '0') != '0'
         self.flops = 0
+        self.allow_split = True    # K split over workgroups with slab outputs (Builder.linear(out=None))
 
     def buf(self, *shape, dtype=torch.float32, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
@@ -201,12 +246,15 @@ class Builder:
         op.kind, op.lane = hip.OP_JOIN, lane
         self.ops.append(op)
 
-    def linear(self, segs, pl, M, out, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
-               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0, gn_out=None):
-        """gn_out = (View out2, gamma, beta, eps, silu): GroupNorm32(+SiLU) of the output for the next layer (N == 512)."""
+    def linear(self, segs, pl, M, out=None, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
+               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0, split=None):
+        """out = act(prologue(A) @ W^T + b) + res (+ res2).  ``out`` None: the output buffer is allocated here and, when the op
+        allows it (no activation epilogue, no batching) and ``split`` is not False, K is split over workgroups -- the returned
+        View is then a slab tensor.  ``split`` = int: k-blocks (16 columns) per slice; True / None: the library's choice."""
         a = LinearArgs()
         for i, s in enumerate(segs):
             a.seg[i] = s
+            self.keep.append(getattr(s, '_keep', None))
         a.nseg = len(segs)
         a.M, a.K, a.N = M, pl.K, pl.N
         a.wpack = pl.w.data_ptr()
@@ -219,27 +267,49 @@ class Builder:
         a.nbatch, a.a_bstride, a.out_bstride = pl.nbatch, a_bstride, out_bstride
         a.res = res.ptr if res is not None else None
         a.res_ld = res.ld if res is not None else 0
+        a.res_nslab, a.res_slab_stride = (res.nslab, res.slab_stride) if res is not None else (0, 0)
+        assert res2 is None or res2.nslab <= 1
         a.res2 = res2.ptr if res2 is not None else None
         a.res2_ld = res2.ld if res2 is not None else 0
+        if out is None:
+            Nout = pl.N // 2 if pl.geglu else pl.N
+            S, kbps = 1, 0
+            if split is not False and a.act == hip.ACT_NONE and pl.nbatch == 1 and self.allow_split:
+                if isinstance(split, int) and not isinstance(split, bool):
+                    kbps = split
+                else:
+                    kal = max([sg.gs for sg in segs if sg.pro in (hip.PRO_GN, hip.PRO_GN_SILU)] +
+                              ([pl.K // 32] if prologue in (hip.PRO_GN, hip.PRO_GN_SILU) else []) + [16])
+                    kbps = hip.lib().es_linear_rows_auto_slices(pl.K, pl.N, kal)
+                a.kb_per_slice = kbps
+                got = C.c_int(0)
+                S = hip.lib().es_linear_rows_slices(C.byref(a), C.byref(got))
+                a.kb_per_slice = got.value if S > 1 else 0
+            buf = self.buf(S, M, Nout)
+            out = View(buf[0], nslab=S, slab_stride=M * Nout if S > 1 else 0)
+            a.out_slab_stride = M * Nout if S > 1 else 0
+        else:
+            assert out.nslab <= 1
         a.out = out.ptr
         a.out_ld = out.ld
-        if gn_out is not None:
-            o2, g2, b2, e2, s2 = gn_out
-            a.out2, a.out2_ld = o2.ptr, o2.ld
-            a.gn2_gamma, a.gn2_beta, a.gn2_eps, a.gn2_silu = g2.data_ptr(), b2.data_ptr(), e2, int(bool(s2))
-            self.keep += [g2, b2]
         op = Op()
         op.kind, op.lane = hip.OP_LINEAR, (lane if self.use_lanes else 0)
         op.u.linear = a
         self.ops.append(op)
-        self.keep += [pl, gamma, beta]
+        self.keep += [pl, gamma, beta, out.t, res.t if res is not None else None, res2.t if res2 is not None else None]
         self.weight_bytes += pl.weight_bytes
         self.flops += 2 * M * pl.K * pl.N * pl.nbatch
         return out
 
     def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True):
+        """eps: tensor or (slab) View"""
         a = UpdateArgs()
-        a.x, a.eps = x.data_ptr(), eps.data_ptr()
+        if isinstance(eps, View):
+            assert eps.ld == eps.width and eps.col == 0
+            a.x, a.eps, a.eps_nslab, a.eps_slab_stride = x.data_ptr(), eps.ptr, eps.nslab, eps.slab_stride
+            self.keep.append(eps.t)
+        else:
+            a.x, a.eps = x.data_ptr(), eps.data_ptr()
         a.noise = noise.ptr if noise is not None else None
         a.noise_stride = noise_stride
         a.coef, a.coef_stride = coef.data_ptr(), coef.shape[1]
@@ -372,24 +442,24 @@ class GCNWeights:
 
 def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
     """obj: View [O, Dobj]; pred: View [T, Dp]; returns View of the last layer's object output
-    (and the predicate output when ``want_pred`` -- the samplers never consume it)."""
+    (and the predicate output when ``want_pred`` -- the samplers never consume it).
+    The two hidden products of a layer (net1's first Linear over the gathered triples, net2's first Linear over the pooled
+    messages) split K over workgroups: their ReLU is applied by the consumer to the slab sum (``pre_act``)."""
     O, T = g.O, g.T
     n = len(gw.layers)
     b.keep.append(g)            # the plan references the graph's device index arrays
     for li, L in enumerate(gw.layers):
         H, Dout = L['H'], L['Dout']
         W2 = 2 * H + Dp
-        t1 = View(b.buf(T, H))
-        b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
-                  seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, t1, act=hip.ACT_RELU)
+        t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
+                       seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T)          # relu deferred
         t2 = View(b.buf(T, W2))
-        b.linear([seg(t1)], L['n1b'], T, t2, act=hip.ACT_RELU)
+        b.linear([seg(t1, pre_act=hip.ACT_RELU)], L['n1b'], T, t2, act=hip.ACT_RELU)
         last = li == n - 1
         if 'proj' in L:
             # residual projections depend only on the layer input: side lane 2, joined before the last linear
             b.fork(2)
-            proj = View(b.buf(O, Dout))
-            b.linear([seg(obj, width=Dobj)], L['proj'], O, proj, lane=2)
+            proj = b.linear([seg(obj, width=Dobj)], L['proj'], O, lane=2)                     # slab tensor: read as a residual
             if not last or want_pred:
                 newp = View(b.buf(T, Dp))
                 b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp), lane=2)
@@ -397,13 +467,12 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
             proj = None
             newp = View(t2.t, col=H, ld=W2, width=Dp)
         ptr, rows, offs = g.csr(0, H + Dp)
-        n1 = View(b.buf(O, H))
-        b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRMEAN, idx=ptr, ent_row=rows, ent_off=offs)],
-                 L['n2a'], O, n1, act=hip.ACT_RELU)
+        n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRMEAN, idx=ptr, ent_row=rows, ent_off=offs)],
+                      L['n2a'], O)                                                           # relu deferred
         dst = out if (last and out is not None) else View(b.buf(O, Dout))
         if proj is not None:
             b.join(2)
-        b.linear([seg(n1)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
+        b.linear([seg(n1, pre_act=hip.ACT_RELU)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
         obj, Dobj = dst, Dout
         if not last or want_pred:
             pred = newp
@@ -586,109 +655,65 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
         cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
-    # GroupNorm32 of a 512-wide activation is computed by its PRODUCER (16 output columns per workgroup = one group):
-    # ``next_gn[name]`` = (consumer name, gamma, beta, eps, silu) of the norm that reads the output of item ``name``.
-    inp_, mid_, out_ = w.topo
-    order = [(f'input_blocks.{i}.{j}', it, False) for i, blk in enumerate(inp_) for j, it in enumerate(blk)]
-    order += [(f'middle_block.{j}', it, False) for j, it in enumerate(mid_)]
-    order += [(f'output_blocks.{i}.{j}', it, j == 0) for i, blk in enumerate(out_) for j, it in enumerate(blk)]
-    next_gn = {}
-    for (n0, it0, _), (n1, it1, cat1) in zip(order[:-1], order[1:]):
-        d1 = w.items[n1]
-        if it1[0] == 'res' and not cat1 and it1[1] == 512:
-            next_gn[n0] = (n1 + ':gn1', d1['gn1'][0], d1['gn1'][1], 1e-5, True)
-        elif it1[0] == 'attn' and it1[1] == 512:
-            next_gn[n0] = (n1 + ':gn', d1['gn'][0], d1['gn'][1], 1e-5 if w.concat else 1e-6, False)
-    pre = {}                                   # consumer key -> pre-normalised View
+    # Every trunk product writes a slab tensor (K split over workgroups) unless its consumer needs whole rows cheaply:
+    # the two LayerNorm operands of a transformer block (t0, t2) are produced with ``ln_split`` slices.
+    import os
+    ln_split = int(os.environ.get('ES_ROWS_LN_SPLIT', '2'))      # slices of a product whose consumer is a LayerNorm (A/B)
 
-    def gn_side(name, C):
-        """(gn_out tuple or None) for the op that produces the block-level output of item ``name``"""
-        g = next_gn.get(name)
-        if g is None or C != 512:
-            return None
-        v = View(b.buf(O, C))
-        pre[g[0]] = v
-        return (v, g[1], g[2], g[3], g[4])
+    def ln_kbps(K):
+        nkb = (K + 15) // 16
+        return False if ln_split <= 1 else max(8, (nkb + ln_split - 1) // ln_split)
 
     def run_block(name_prefix, blk, h_segs, hC):
-        """h_segs: list of Views forming the (possibly concatenated) input; returns (View, C)."""
+        """h_segs: list of Views forming the (possibly concatenated) input; returns (Views, C)."""
         for j, it in enumerate(blk):
             name = f'{name_prefix}.{j}'
             d = w.items[name]
             kind = it[0]
             if kind == 'conv_in':
-                o = View(b.buf(O, mc))
-                b.linear([seg(v) for v in h_segs], d['conv'], O, o, gn_out=gn_side(name, mc))
+                o = b.linear([seg(v) for v in h_segs], d['conv'], O)
                 h_segs, hC = [o], mc
             elif kind == 'res':
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
-                h1 = View(b.buf(O, cout))
-                h1n = View(b.buf(O, cout)) if cout == 512 else None      # silu(GN2(h1)) from conv1's epilogue
-                gn2 = (h1n, d['gn2'][0], d['gn2'][1], 1e-5, True) if h1n is not None else None
-                if (name + ':gn1') in pre:
-                    b.linear([seg(pre[name + ':gn1'])], d['conv1'], O, h1,
-                             res=View(emb_all, col=eo, ld=emb_ld, width=cout), gn_out=gn2)
+                h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
+                              res=View(emb_all, col=eo, ld=emb_ld, width=cout))
+                gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
+                if 'skip' in d and len(h_segs) <= 2:
+                    # out = conv2(silu(GN2(h1))) + skip(x): ONE op over the K-concatenation [h1 | x] with weights [W2 | Wskip],
+                    # the norm being the prologue of the first segment only
+                    o = b.linear(gn2 + [seg(v) for v in h_segs], d['conv2skip'], O)
                 else:
-                    b.linear([seg(v) for v in h_segs], d['conv1'], O, h1, prologue=hip.PRO_GN_SILU,
-                             gamma=d['gn1'][0], beta=d['gn1'][1], eps=1e-5,
-                             res=View(emb_all, col=eo, ld=emb_ld, width=cout), gn_out=gn2)
-                if 'skip' in d and h1n is not None and len(h_segs) <= 2:
-                    o = View(b.buf(O, cout))
-                    b.linear([seg(h1n)] + [seg(v) for v in h_segs], d['conv2skip'], O, o, gn_out=gn_side(name, cout))
-                    h_segs, hC = [o], cout
-                    b.tags[name] = h_segs[0]
-                    continue
-                if 'skip' in d:
-                    sk = View(b.buf(O, cout))
-                    b.linear([seg(v) for v in h_segs], d['skip'], O, sk)
-                    resv = sk
-                else:
-                    assert len(h_segs) == 1
-                    resv = h_segs[0]
-                o = View(b.buf(O, cout))
-                if h1n is not None:
-                    b.linear([seg(h1n)], d['conv2'], O, o, res=resv, gn_out=gn_side(name, cout))
-                else:
-                    b.linear([seg(h1)], d['conv2'], O, o, prologue=hip.PRO_GN_SILU, gamma=d['gn2'][0],
-                             beta=d['gn2'][1], eps=1e-5, res=resv)
+                    if 'skip' in d:
+                        resv = b.linear([seg(v) for v in h_segs], d['skip'], O)
+                    else:
+                        assert len(h_segs) == 1
+                        resv = h_segs[0]
+                    o = b.linear(gn2, d['conv2'], O, res=resv)
                 h_segs, hC = [o], cout
             elif kind == 'attn' and w.concat:
                 C = it[1]
                 xin = h_segs[0]
-                o = View(b.buf(O, C))
-                if (name + ':gn') in pre:
-                    b.linear([seg(pre[name + ':gn'])], d['av'], O, o, res=xin, gn_out=gn_side(name, C))
-                else:
-                    b.linear([seg(xin)], d['av'], O, o, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1], eps=1e-5,
-                             res=xin)
+                o = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-5, False, C=C), d['av'], O, res=xin)
                 h_segs, hC = [o], C
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
-                t0 = View(b.buf(O, C))
-                if (name + ':gn') in pre:
-                    b.linear([seg(pre[name + ':gn'])], d['proj_in'], O, t0)
-                else:
-                    b.linear([seg(xin)], d['proj_in'], O, t0, prologue=hip.PRO_GN, gamma=d['gn'][0], beta=d['gn'][1],
-                             eps=1e-6)
+                t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C), d['proj_in'], O, split=ln_kbps(C))
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
                 # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
-                t2 = View(b.buf(O, C))
-                b.linear([seg(t0)], d['vo1'], O, t2, prologue=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5,
-                         res=t0, res2=cavo[name])
+                t2 = b.linear([seg(t0, pro=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5, gs=C)], d['vo1'], O,
+                              res=t0, res2=cavo[name], split=ln_kbps(C))
                 b.tags[name + '.transformer_blocks.0:in'] = t0
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
-                gl = View(b.buf(O, 4 * C))                    # GEGLU applied in the ff1 epilogue
-                b.linear([seg(t2)], d['ff1'], O, gl, prologue=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5)
-                o = View(b.buf(O, C))
-                b.linear([seg(gl), seg(t2)], d['ff2po'], O, o, res=xin, gn_out=gn_side(name, C))
+                # GEGLU applied in the ff1 epilogue (needs finished sums: one slice, 16 * 4C / 16 column tiles)
+                gl = b.linear([seg(t2, pro=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5, gs=C)], d['ff1'], O)
+                o = b.linear([seg(gl), seg(t2)], d['ff2po'], O, res=xin)
                 h_segs, hC = [o], C
             elif kind in ('down', 'up'):
-                o = View(b.buf(O, hC))
-                b.linear([seg(v) for v in h_segs], d['conv'], O, o, gn_out=gn_side(name, hC))
+                o = b.linear([seg(v) for v in h_segs], d['conv'], O)
                 h_segs = [o]
             b.tags[name] = h_segs[0]
         return h_segs, hC
@@ -705,8 +730,8 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     for i, blk in enumerate(out):
         sk, sC = hs.pop()
         h_segs, hC = run_block(f'output_blocks.{i}', blk, [h_segs[0], sk], hC + sC)
-    b.linear([seg(h_segs[0])], w.out_conv, O, View(eps_out), prologue=hip.PRO_GN_SILU, gamma=w.out_gn[0],
-             beta=w.out_gn[1], eps=1e-5)
+    # (eps stays an ordinary tensor: it is also the result of the step-level API; one slice)
+    b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O, View(eps_out))
     return objbuf
 
 

@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 2
+#define ES_ABI_VERSION 3
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -45,6 +45,8 @@ int es_device_info(char* name_out, int name_cap, int* cu_count);
  * One generic fused kernel:  out = act( prologue(A) @ W^T + bias ) + res
  *   A is the horizontal concatenation of up to 3 segments, each either direct rows, rows
  *   gathered through an index (obj_vecs[s_idx]), or a CSR segment-mean (the scatter_add/avg pool).
+ *   Chip-wide parallelism for M = 32: grid = (16-column tiles x K slices, 16-row tiles); split-K partial sums are
+ *   never reduced by a kernel of their own -- they are "slab tensors" summed by whoever reads them next.
  * ---------------------------------------------------------------------------------------- */
 enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2 };
 enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
@@ -62,6 +64,19 @@ typedef struct es_seg {
     int32_t ld;            /* leading dimension of the source (0 = broadcast one row to all M)  */
     int32_t width;         /* columns this segment contributes to K (multiple of 4)             */
     int32_t mode;          /* ES_SEG_*                                                          */
+    /* slab form (round 3): the source is the split-K output of another es_linear_rows_f32 launch -- its value is
+     * sum_{j < nslab} ptr[j * slab_stride + ...] in fixed order j = 0 .. nslab-1, summed while this op stages its operand
+     * (the launch-boundary reduce; 0 / 1 = an ordinary tensor).  slab_stride in floats, a multiple of 4.            */
+    int32_t nslab, slab_stride;
+    int32_t pre_act;       /* ES_ACT_NONE / ES_ACT_RELU applied to the slab sum (a producer that splits K cannot apply its
+                              own ReLU; build_mlp's final_nonlinearity, model/layers.py:33-37)          */
+    /* per-segment prologue (the op-level `prologue` below is shorthand for the same prologue on every segment):
+     * ES_PRO_GN / GN_SILU: GroupNorm over THIS segment in groups of `gs` channels (4..32, power of two), affine gamma/beta
+     * [width]; ES_PRO_LN: LayerNorm over the segment (must be the only one); ES_PRO_SILU; ES_PRO_GEGLU.             */
+    int32_t pro;
+    const float* gamma; const float* beta;
+    float eps;
+    int32_t gs;
 } es_seg;
 
 typedef struct es_linear_args {
@@ -77,6 +92,7 @@ typedef struct es_linear_args {
     int32_t act;              /* ES_ACT_*                                                      */
     const float* res;         /* residual [M, N] added AFTER the activation, or NULL           */
     int32_t res_ld;
+    int32_t res_nslab, res_slab_stride;   /* the residual may itself be a slab tensor (see es_seg)  */
     const float* res2;        /* optional second residual (cross-attention-with-one-key vector) */
     int32_t res2_ld;
     float* out;               /* [M, N]  (ES_ACT_GEGLU: [M, N/2])                              */
@@ -84,15 +100,13 @@ typedef struct es_linear_args {
     /* batched launch (grid.z = nbatch): batch z uses seg[0].ptr + z*a_bstride, the z-th packed weight image
      * (images of equal shape stored back to back), bias + z*N, out + z*out_bstride.  0/1 = single problem. */
     int32_t nbatch, a_bstride, out_bstride;
-    /* optional second output: GroupNorm32 (+SiLU) of the OUTPUT row for the NEXT layer, written as out2[M, N].  A
-     * workgroup owns 16 output columns of every row, which for N = 512 is exactly one of the 32 groups, so the
-     * consumer's norm prologue (every workgroup re-normalising the whole tile) moves into the producer's epilogue.
-     * Requires N == 512 (group size 16); gn2_gamma/gn2_beta [N] are the CONSUMER's affine.  NULL = off. */
-    float* out2;
-    int32_t out2_ld;
-    const float* gn2_gamma; const float* gn2_beta;
-    float gn2_eps;
-    int32_t gn2_silu;
+    /* K split over workgroups (round 3).  kb_per_slice = number of 16-column k-blocks per slice (0 = one slice); the
+     * launch runs S = ceil(ceil(K/16) / kb_per_slice) slices per column tile and slice s writes its partial products to
+     * out + s * out_slab_stride (slice 0 adds bias and residuals): the output is a slab tensor for its consumers.  Needs
+     * act == ES_ACT_NONE and no batching.  Slices are cut at multiples of the largest GroupNorm group; the count depends on
+     * (K, N) only -- never on M -- so a row's arithmetic does not depend on the batch it is in. */
+    int32_t kb_per_slice;
+    int32_t out_slab_stride;  /* floats between output slabs (>= M * out_ld)                    */
 } es_linear_args;
 
 /* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
@@ -104,6 +118,11 @@ int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
 int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int K, float* h_out, float* h_bias_out);
 
 int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
+/* number of slices the launch will run for `args` (and the rounded kb_per_slice) -- the planner sizes the slab buffer with it */
+int es_linear_rows_slices(const es_linear_args* args, int* kb_per_slice);
+/* the library's default kb_per_slice for a [*, K] x [K, N] product whose slices must be multiples of kalign_cols columns
+ * (~256 workgroups per 32 rows, >= 128 columns per slice, <= 8 slabs); 0 = do not split */
+int es_linear_rows_auto_slices(int K, int N, int kalign_cols);
 
 /* ------------------------------------------------------------------------------------------
  * Diffusion updates.
@@ -120,6 +139,7 @@ int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
 typedef struct es_update_args {
     float* x;               /* [n] state, updated in place                                      */
     const float* eps;       /* [n] network output                                               */
+    int32_t eps_nslab, eps_slab_stride;   /* eps as a slab tensor (the denoiser's last product may split K) */
     const float* noise;     /* DDPM: noise + (*step)*noise_stride is this step's draw; DDIM: NULL */
     int32_t noise_stride;
     const float* coef;      /* [n_steps][coef_stride]                                           */

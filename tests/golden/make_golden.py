@@ -394,6 +394,59 @@ def case_shape_traj_full():
          sdf_sum=sdf.double().sum(), sdf_abs=sdf.double().abs().sum())
 
 
+def case_unet3d_full_O32():
+    """ONE reference UNet3D + echo-GCN eps evaluation at the BENCHMARKED shape (model_channels 224,
+    O = 32: every 3x3x3 / 1x1 launch has >= 256 row tiles, i.e. the plain k_conv_ws / k_linear_ws routes the bench times).
+    Same weights ('unet3d_full.') as the O = 2 / O = 4 goldens; openai_model_3d.py:816-863."""
+    import time
+    net = _unet3d(224, 1280)
+    fill(net, 'unet3d_full.')
+    O = 32
+    objs, triples = synth.synthetic_graph(O, seed=5)
+    x = rnd((O, 3, 16, 16, 16), 611)
+    uc = rnd((O, 1, 1280), 612)
+    t = torch.full((O,), 401, dtype=torch.long)
+    t0 = time.time()
+    with torch.no_grad():
+        eps = net(x, uc, triples, t, c_crossattn=[uc])
+    print('UNet3D forward at O=32: %.0f s' % (time.time() - t0))
+    save('unet3d_full_O32', x_seed=np.array(611), uc_s=uc, triples=triples, t=t, eps=eps)   # x = rnd((O,3,16,16,16), x_seed)
+
+
+def case_shape_traj_full_O16():
+    """VERDICT r2 #1 / BASELINE configs[2]: 2 DDIM steps of the reference's own DDIMSampler at model_channels 224, O = 16
+    (16x8x8 level = 128 row tiles -> split-K dispatch differs from both O = 4 and O = 32); ddim.py:127-262."""
+    import time
+    from model.networks.diffusion_shape.echo2shape import EchoToShape
+    from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+    net = _unet3d(224, 1280)
+    fill(net, 'unet3d_full.')
+    shim = _ShapeShim()
+    shim.df = shim.df_module = net
+    EchoToShape.register_schedule(shim, timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    shim.apply_model = lambda *a, **k: EchoToShape.apply_model(shim, *a, **k)
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    O = 16
+    objs, triples = synth.synthetic_graph(O, seed=16)
+    uc = rnd((O, 1, 1280), 162)
+    noise1 = synth.shape_noise(seed=7)
+    sampler = DDIMSampler(shim)
+    sampler.make_schedule(ddim_num_steps=100, ddim_eta=0.0, verbose=False)
+    x = noise1.repeat(O, 1, 1, 1, 1)
+    ts = np.flip(sampler.ddim_timesteps)
+    zs = []
+    t0 = time.time()
+    with torch.no_grad():
+        for i in range(2):
+            index = len(ts) - i - 1
+            tt = torch.full((O,), int(ts[i]), dtype=torch.long)
+            x, _ = sampler.p_sample_ddim(x, uc, tt, index=index, unconditional_guidance_scale=3.,
+                                         unconditional_conditioning=uc, triplet=triples)
+            zs.append(x.clone())
+    print('2 DDIM steps at O=16: %.0f s' % (time.time() - t0))
+    save('shape_traj_full_O16', uc_s=uc, triples=triples, z_steps=torch.stack(zs))
+
+
 def _vqvae(ch, n_embed):
     from model.networks.vqvae_networks.network import VQVAE
     p = escfg.vqvae_conf(ch).model.params
@@ -722,7 +775,8 @@ CASES = dict(box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=cas
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,
              layout_traj_full=case_layout_traj_full, shape_traj_full=case_shape_traj_full,
-             scene_edit=case_scene_edit, temb=case_temb, manifest=case_manifest)
+             scene_edit=case_scene_edit, temb=case_temb, manifest=case_manifest,
+             unet3d_full_O32=case_unet3d_full_O32, shape_traj_full_O16=case_shape_traj_full_O16)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -207,7 +207,7 @@ def test_unet1d_tiny_blockwise_vs_oracle(dev):
     for name, v in st['eps_plan'].tags.items():
         ref = trace[name]
         ref = ref.reshape(ref.shape[0], -1)
-        got = v.t[:, v.col:v.col + v.width].cpu()
+        got = v.value().cpu()                     # (slab tensors: the fixed-order sum of their slabs)
         err = (got - ref).abs().max().item()
         if not err < 1e-4 * max(1.0, ref.abs().max().item()):
             bad.append((name, '%.2e' % err, 'rows', (got - ref).abs().max(1).values.gt(1e-4).nonzero().flatten().tolist()))
@@ -299,10 +299,13 @@ def test_unet1d_concat_vs_reference_golden(dev, tag, mc, cd):
         _close(x, g['loop_x10'], 2e-4)
 
 
-def test_linear_groupnorm_second_output_and_rowsel(dev):
-    """The producer-side GroupNorm32(+SiLU) output (N = 512: one group per 16-column workgroup) against torch, fed
-    through three K segments; and the device-step-indexed row select used for the per-schedule time tables."""
-    from echoscene_amd.plan import Builder, PackedLinear, View, seg
+def test_linear_split_k_slab_chain_and_rowsel(dev):
+    """Round 3: K split over workgroups.  A product writes S partial-sum slabs (slice 0 carries bias + residual), and whoever
+    reads the tensor next sums them in fixed order: (a) as an A segment under a per-segment GroupNorm(+SiLU) prologue next
+    to a raw segment, (b) as a residual, (c) under a LayerNorm prologue, (d) with the deferred ReLU (``pre_act``).
+    Then the device-step-indexed row select used for the per-schedule time tables."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg, norm_segs
     rs = np.random.RandomState(5)
     M, K, N = 27, 3 * 512, 512
     X = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32))
@@ -311,20 +314,43 @@ def test_linear_groupnorm_second_output_and_rowsel(dev):
     R = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32))
     ga = torch.from_numpy((1 + 0.1 * rs.standard_normal(N)).astype(np.float32))
     be = torch.from_numpy((0.1 * rs.standard_normal(N)).astype(np.float32))
-    ref = F.linear(X, W, bias) + R
+    W2 = torch.from_numpy((rs.standard_normal((N, 2 * N)) / np.sqrt(2 * N)).astype(np.float32))
+    W3 = torch.from_numpy((rs.standard_normal((64, N)) / np.sqrt(N)).astype(np.float32))
+    ref1 = F.linear(X, W, bias) + R
     for silu in (False, True):
         b = Builder(dev)
         x = b.dev(X)
-        out, out2 = b.buf(M, N, zero=True), b.buf(M, N, zero=True)
-        b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
-                 PackedLinear(W, bias, dev), M, View(out), res=View(b.dev(R)),
-                 gn_out=(View(out2), b.dev(ga), b.dev(be), 1e-5, silu))
+        h = b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
+                     PackedLinear(W, bias, dev), M, res=View(b.dev(R)))
+        assert h.nslab == 4 and h.slab_stride == M * N, (h.nslab, h.slab_stride)       # 96 k-blocks, 32 column tiles
+        h2 = b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
+                      PackedLinear(W, bias, dev), M, res=View(b.dev(R)), split=48)
+        assert h2.nslab == 2
+        # (a) + (b): [GN(+SiLU)(h) | raw x] @ W2 + h
+        o = b.linear(norm_segs([h], b.dev(ga), b.dev(be), 1e-5, silu) + [seg(View(x, col=0, width=512))],
+                     PackedLinear(W2, None, dev), M, res=h)
+        # (c): LayerNorm over the slab tensor, (d): relu(h) as the operand of a plain product
+        o_ln = b.linear([seg(h2, pro=hip.PRO_LN, gamma=b.dev(ga), beta=b.dev(be), eps=1e-5, gs=N)], PackedLinear(W3, None, dev), M)
+        o_relu = b.linear([seg(h, pre_act=hip.ACT_RELU)], PackedLinear(W3, None, dev), M, act=hip.ACT_RELU)
         b.finish().run()
         torch.cuda.synchronize()
-        _close(out.cpu(), ref, 2e-5)
-        y = F.group_norm(ref, 32, ga, be, 1e-5)
-        _close(out2.cpu(), F.silu(y) if silu else y, 5e-5)
+        _close(h.value().cpu(), ref1, 2e-5)
+        y = F.group_norm(ref1, 32, ga, be, 1e-5)
+        y = F.silu(y) if silu else y
+        _close(o.value().cpu(), F.linear(torch.cat([y, X[:, :512]], 1), W2) + ref1, 5e-5)
+        _close(o_ln.value().cpu(), F.linear(F.layer_norm(ref1, (N,), ga, be, 1e-5), W3), 5e-5)
+        assert o_relu.nslab == 1                                                     # an activation epilogue needs finished sums
+        _close(o_relu.value().cpu(), F.relu(F.linear(F.relu(ref1), W3)), 5e-5)
+        # the split is a function of (K, N) only: a 300-row batch cuts K in the same places -> identical rows
+        b2 = Builder(dev)
+        xb = b2.dev(torch.cat([X] * 12)[:300])
+        hb = b2.linear([seg(View(xb, col=0, width=512)), seg(View(xb, col=512, width=512)), seg(View(xb, col=1024, width=512))],
+                       PackedLinear(W, bias, dev), 300, res=View(b2.dev(torch.cat([R] * 12)[:300])))
+        b2.finish().run()
+        torch.cuda.synchronize()
+        assert hb.nslab == h.nslab and torch.equal(hb.value()[:M].cpu(), h.value().cpu())
     # row select: out[r, :] = table[step, :]
+    from echoscene_amd.plan import Builder, View
     b = Builder(dev)
     table = b.dev(torch.from_numpy(rs.standard_normal((7, 300)).astype(np.float32)))
     step = b.buf(1, dtype=torch.int32, zero=True)
