@@ -196,6 +196,9 @@ def main():
                          '-1: the default of this build')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--check', action='store_true',
+                    help='seeded initial latents (the same for every world size) and a CRC32 of the final latents of the whole scene in the '
+                         'JSON line ("check"): with --deterministic the N-rank run must reproduce the 1-rank CRC bit for bit')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -276,6 +279,10 @@ def main():
         torch.cuda.synchronize()
     # The two loops are independent given the setup (the reference runs them back to back); they are enqueued on
     # two HIP streams so the latency-bound layout chain (few CUs busy) overlaps the MFMA-bound shape loop.
+    if full and a.check:                        # (after every capture run above: those advance the state)
+        xall = torch.randn(O_all, 3, 16, 16, 16, generator=torch.Generator().manual_seed(11))
+        ss['x'].copy_(xall[ss.get('lo', 0):ss.get('hi', O_all)])
+        torch.cuda.synchronize()
     s_lay, s_shp = torch.cuda.Stream(), torch.cuda.Stream()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t0 = time.perf_counter()
@@ -313,6 +320,16 @@ def main():
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
+    check = None
+    if full and a.check:                        # (before the per-loop replays below advance the state again)
+        import zlib
+        z = ss['x'].detach().cpu().contiguous()
+        if dist is not None and not weak:
+            parts = [None] * world
+            dist.all_gather_object(parts, z)
+            z = torch.cat(parts, 0)
+        check = {'latents_crc32': zlib.crc32(z.numpy().tobytes()), 'objects': int(z.shape[0]),
+                 'abs_sum': float(z.double().abs().sum())}
     if fused is not None:
         # per-loop figures for the record (outside the timed region): each loop alone on the idle GPU
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -411,6 +428,8 @@ def main():
                 out['cpu_baseline'] = {'value': round(v, 3), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
                                        'kind': 'port', 'sample': '%d layout denoising steps of the same %d-node graph '
                                        '(torch-CPU oracle, fp32)' % (n, O)}
+        if check is not None:
+            out['check'] = check
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

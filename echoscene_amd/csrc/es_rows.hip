@@ -265,6 +265,7 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* x = smem;                                     // [MT][ldx]
     float* red = smem + MT * ldx;                        // [NKG][256]
+    if (dbg & 4) return;                                 // (calibration of the launch floor, tools/microbench_rows.py)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = blockIdx.x % S, nt = blockIdx.x / S;
     const int m0 = blockIdx.y * MT;
@@ -287,10 +288,10 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a,
     float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f;
     const bool ok_e = tid < 256 && m_e < a.M && n_e < a.N;
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
-    if (first && a.res && ok_res)
+    if (first && a.res && ok_res && !(dbg & 8))
         e_res = load_slabs1(a.res + (long)m_e * a.res_ld + nres, a.res_nslab > 1 ? a.res_nslab : 1, a.res_slab_stride);
-    if (first && a.res2 && ok_res) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
-    if (first && bias && n_e < a.N) e_bias = bias[n_e];
+    if (first && a.res2 && ok_res && !(dbg & 8)) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
+    if (first && bias && n_e < a.N && !(dbg & 8)) e_bias = bias[n_e];
     const int kg = wave;
 
     for (int c0 = kb0 * 16; c0 < kb1 * 16; c0 += KCH) {

@@ -417,3 +417,19 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
         assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['steps'] == 3 and d['value'] > 0
         assert d['config']['scenes'] == (2 if scaling == 'weak' else 1)
         assert 'roofline' in d and d['roofline']['achieved'] > 0
+    # the sharded run must reproduce the single-rank run: same seeded latents, deterministic shards -> identical final latents
+    crcs = []
+    for nproc in (1, 2):
+        with socket.socket() as sck:
+            sck.bind(('127.0.0.1', 0))
+            port = sck.getsockname()[1]
+        env = dict(os.environ, ES_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '3', '--warmup', '1',
+               '--no-cpu-baseline', '--no-sub-records', '--nodes', '8', '--deterministic', '--check']
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+        assert d['check']['objects'] == 8
+        crcs.append((d['check']['latents_crc32'], d['check']['abs_sum']))
+    assert crcs[0] == crcs[1], 'the 2-rank sharded run does not reproduce the 1-rank latents: %s' % (crcs,)

@@ -60,6 +60,21 @@ def _shape_den(dev, S):
     return ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=S, device=dev)
 
 
+def test_shape_2_ddim_steps_O16_full_width_vs_reference(dev):
+    """BASELINE configs[2] (EchoScene full, 16-node graph, 64^3 SDF): at O = 16 the 16x8x8 level has 128 row tiles, so the conv
+    dispatcher takes split-K decisions that neither the O = 4 nor the O = 32 goldens reach.  Golden = 2 steps of the reference's
+    own DDIMSampler.p_sample_ddim at model_channels 224 (make_golden.py: shape_traj_full_O16)."""
+    g = load_golden('shape_traj_full_O16')
+    den = _shape_den(dev, 100)
+    noise1 = synth.shape_noise(seed=7)
+    print()
+    for k in (1, 2):
+        z = den.sample(g['uc_s'], g['triples'], noise1, n_steps=k)
+        mx, rms, _ = _errs(z, g['z_steps'][k - 1])
+        print('shape O=16 mc=224, %d DDIM steps: max abs err %.2e  rel rms %.2e' % (k, mx, rms))
+        assert torch.allclose(z.cpu(), g['z_steps'][k - 1], atol=2e-2, rtol=2e-2), (k, mx)
+
+
 def _decoder(dev):
     from echoscene_amd.model.vqvae import VQVAE
     from echoscene_amd.samplers import VQDecoder

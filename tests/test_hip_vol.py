@@ -272,8 +272,25 @@ def test_unet3d_full_eps_vs_reference_golden(dev):
     assert e < 2e-2
 
 
-@pytest.mark.parametrize('mc,ctx,prefix,world', [(32, 64, 'unet3d_tiny.', 2), (224, 1280, 'unet3d_full.', 4)])
-def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world):
+def test_unet3d_full_eps_O32_vs_reference_golden(dev):
+    """The BENCHMARKED routes against the reference: model_channels 224, O = 32 -- every 3x3x3 / 1x1 launch has
+    >= 256 row tiles, i.e. the plain k_conv_ws route, the column-panel order and k_linear_ws at 16-24 column tiles that
+    bench.py times.  Golden = ONE reference UNet3D + echo-GCN evaluation on CPU (make_golden.py: unet3d_full_O32)."""
+    g = load_golden('unet3d_full_O32')
+    O = 32
+    x = _rnd((O, 3, 16, 16, 16), int(g['x_seed']))
+    den = _shape(dev, 224, 1280, 'unet3d_full.', 100)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(x, g['uc_s'], g['triples'], iteration=it)
+    e = _rel(eps, g['eps'])
+    rms = ((eps.cpu() - g['eps']).pow(2).mean().sqrt() / g['eps'].pow(2).mean().sqrt()).item()
+    print('unet3d full O=32: fp16-MFMA eps vs fp32 reference golden: max rel err %.3e, rel rms %.3e' % (e, rms))
+    assert e < 2e-2
+
+
+@pytest.mark.parametrize('mc,ctx,prefix,world,O', [(32, 64, 'unet3d_tiny.', 2, 4), (224, 1280, 'unet3d_full.', 4, 4),
+                                                    (224, 1280, 'unet3d_full.', 8, 32)])
+def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world, O):
     """the sharded result must equal the single-GPU result BIT FOR BIT.  The multi-GPU decomposition
     on one GPU: ``world`` shards stepped with a simulated all-gather.  Every kernel treats objects independently; what used
     to differ was the fp32 summation order, because split-K factors and GroupNorm partial-sum tiles were picked from the
@@ -281,7 +298,6 @@ def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world):
     cut split-K ranges in the same places, so the tile size chosen per launch no longer matters."""
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
-    O = 4
     objs, triples = synth.synthetic_graph(O, seed=6)
     uc = _rnd((O, 1, ctx), 52)
     noise1 = synth.shape_noise(seed=7)
@@ -290,13 +306,14 @@ def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world):
     df = DiffusionUNet(p)
     synth.seeded_fill_(df, prefix=prefix)
     mpar = escfg.shape_df_conf().model.params
-    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev).sample(uc, triples, noise1)
+    nst = 4 if O <= 4 else 2                 # (the benchmarked decomposition: 32 objects over 8 ranks, full width)
+    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev).sample(uc, triples, noise1, n_steps=nst)
     shards = [ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, rank=r, world=world) for r in range(world)]
     for sh in shards:
         st = sh._plan_for(uc, triples)
         st['x'].copy_(noise1.to(dev).expand(st['hi'] - st['lo'], 3, 16, 16, 16))
         sh._cur, sh._use_graph = st, True
-    for i in range(4):
+    for i in range(nst):
         codes = torch.cat([sh.codes_local(i)[:sh._cur['hi'] - sh._cur['lo']].clone() for sh in shards], 0)
         for sh in shards:
             sh.step(i, codes)
