@@ -556,6 +556,18 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
     }
 }
 
+// 27-bit validity mask of the 3x3x3 taps around source voxel (cd, ch, cw) of a [nd, nh, nw] grid (bit t = kd*9 + kh*3 + kw set when
+// the tap lies inside): the outer product of three 3-bit axis masks, ~25 VALU operations.  The first version tested the 27 taps one
+// by one (27 x 6 compares per row, 4 rows per producer lane): 7.3 us of every tile's 8.7 us before its first K unit was published
+// (tools/conv_stamps.py), with the 8 consumer waves parked at their first barrier.
+__device__ __forceinline__ unsigned tap_mask27(int cd, int nd, int ch, int nh, int cw, int nw) {
+    const unsigned vw = ((cw >= 1 && cw <= nw) ? 1u : 0u) | ((cw >= 0 && cw < nw) ? 2u : 0u) | ((cw >= -1 && cw + 1 < nw) ? 4u : 0u);
+    const unsigned vh = ((ch >= 1 && ch <= nh) ? 1u : 0u) | ((ch >= 0 && ch < nh) ? 2u : 0u) | ((ch >= -1 && ch + 1 < nh) ? 4u : 0u);
+    const unsigned vd = ((cd >= 1 && cd <= nd) ? 1u : 0u) | ((cd >= 0 && cd < nd) ? 2u : 0u) | ((cd >= -1 && cd + 1 < nd) ? 4u : 0u);
+    const unsigned m9 = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+    return ((vd & 1u) ? m9 : 0u) | ((vd & 2u) ? m9 << 9 : 0u) | ((vd & 4u) ? m9 << 18 : 0u);
+}
+
 // Workgroup = NW_ waves as (NW_/2)(M) x 2(N); tile BM_ x 224:
 //   <256, 8> wave tile 64 x 112 (16^3 and 16x8x8 levels: A+B bytes per flop -32 % vs <128,4>)
 //   <128, 4> wave tile 64 x 112
@@ -675,12 +687,7 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
             if (ntap == 1) {
                 m = a_ok[j] ? 1u : 0u;
             } else {
-#pragma unroll
-                for (int t = 0; t < 27; ++t) {
-                    const int id = cd + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
-                    const bool ok = a_ok[j] && id >= 0 && id < Dsrc && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
-                    m |= (ok ? 1u : 0u) << t;
-                }
+                m = a_ok[j] ? tap_mask27(cd, Dsrc, ch, UP_ ? g.H : Hi, cw, UP_ ? g.W : Wi) : 0u;
             }
             msk[j] = m;
         }
@@ -822,6 +829,14 @@ __device__ __forceinline__ void ws_mma(f4 (&acc)[MI][7], const h8 (&af)[MI], con
         for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
 }
 
+#ifdef ES_STAMP
+// phase stamps of k_conv_ws (tools/conv_stamps.py; build with ES_BUILD_FLAGS=-DES_STAMP): 8 x 100 MHz wall-clock ticks per wave
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define ES_STAMP_AT(k) do { if (stamp && lane == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ES_STAMP_AT(k) do { } while (0)
+#endif
+
 template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
     constexpr int NS = 3, UPS_ = 1;                               // ring depth; K units per barrier
@@ -837,6 +852,10 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ES_STAMP
+    unsigned long long* stamp = g_stamp_buf ? g_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (NC_ + NP_) + wave) * 8 : nullptr;
+#endif
+    ES_STAMP_AT(0);
     const long M = (long)g.O * g.D * g.H * g.W;
     int bx, by, bz;
     conv_tile_of(a, bx, by, bz);                 // XCD-aware, re-use-aware tile order
@@ -915,17 +934,13 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
                 if (ntap == 1) {
                     m = a_ok[j] ? 1u : 0u;
                 } else {
-#pragma unroll
-                    for (int t = 0; t < 27; ++t) {
-                        const int id = cd + t / 9 - 1, ih = ch + (t / 3) % 3 - 1, iw = cw + t % 3 - 1;
-                        const bool ok = a_ok[j] && id >= 0 && id < Dsrc && ih >= 0 && ih < (UP_ ? g.H : Hi) && iw >= 0 && iw < (UP_ ? g.W : Wi);
-                        m |= (ok ? 1u : 0u) << t;
-                    }
+                    m = a_ok[j] ? tap_mask27(cd, Dsrc, ch, UP_ ? g.H : Hi, cw, UP_ ? g.W : Wi) : 0u;
                 }
                 msk[j] = m;
             }
         };
         set_phase();
+        ES_STAMP_AT(1);
         const unsigned voffB = (unsigned)lane * 16u;
         auto issue_unit = [&](char* dst) __attribute__((always_inline)) {        // dst: LDS base of the unit (A tile, then B tile)
             const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, st_tap) + (unsigned)st_c * 64u;
@@ -975,11 +990,14 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
             for (int st = 0; st < nstage; ++st) {
                 if (st + 1 < nstage) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of unit st have landed
                 __builtin_amdgcn_s_barrier();        // unit st visible to the consumers; slot (st+2)%3 released by them
+                if (st == 0) ES_STAMP_AT(2);
                 if (st + 2 < nstage) issue_stage(st + 2);
             }
         }
+        ES_STAMP_AT(3);
         f4 dummy[MI][7];
         conv_epilogue<BM_, NC_, false, true, EPI_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        ES_STAMP_AT(4);
         return;
     }
 
@@ -1003,7 +1021,9 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         // run under the matrix pipe instead of in front of it.  A/B on one box (ES_CONV_PIPE, since removed): 3x3x3 launches
         // -2.5 ... -3.2 % (319 -> 311 us at 16^3 224->224, 283 -> 275 and 409 -> 396 us at 16x8x8), 14-unit 1x1 launches +1 %.
         int slot = 0;
+        ES_STAMP_AT(1);
         __builtin_amdgcn_s_barrier();                                           // unit 0 published
+        ES_STAMP_AT(2);
         ws_read_frags<MI>(smem, fragA, fragB, af, bfr);
         for (int ks = 0; ks + 1 < nloc; ++ks) {
             slot = slot == NS - 1 ? 0 : slot + 1;
@@ -1037,7 +1057,9 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         }
         ws_mma<MI>(acc, af, bfr);                                               // last unit
     }
+    ES_STAMP_AT(3);
     conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+    ES_STAMP_AT(4);
 }
 
 // a wave-uniform pointer the compiler can keep in SGPRs (buffer descriptors must be scalar; a descriptor it cannot prove uniform
@@ -1495,6 +1517,13 @@ int ilog2_exact(int v) {
 }
 
 }  // namespace
+
+#ifdef ES_STAMP
+extern "C" int es_debug_set_stamp(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &q, sizeof(q)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // library-wide one-off initialisation hook (nothing to allocate since the zero-page gather kernel was retired)
 int es_vol_init(void) { return 0; }
