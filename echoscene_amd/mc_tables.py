@@ -14,8 +14,15 @@ the rows are derived at import time from the rule that defines them --
     orientation of the published table's first row, {0, 8, 3} -- and is fanned into triangles from the first vertex whose
     diagonals do not lie inside a cube face.
 
-Vertex positions (and therefore the vertex multiset of a mesh) do not depend on the table at all; the triangle count per case
-depends only on the loops; only the choice of diagonals inside a loop is a free convention.
+Vertex positions (and therefore the vertex multiset of a mesh) do not depend on the table at all.  What DOES differ from
+PyMCubes' classic (Lorensen / Bourke) table: (1) the choice of diagonals inside a loop, and (2) the LOOP STRUCTURE -- hence the
+triangle count -- on ambiguous-face cases.  The classic table is complement-symmetric (case c and case 255 - c get the same
+triangulation with flipped orientation); the rule above ("cut off every INSIDE corner") is not: 44 case / complement pairs get
+a different number of triangles here (e.g. cases 5 and 10 -> 2 triangles, their complements 250 and 245 -> 4, where the classic
+table has 2 in all four).  Face counts and topology of a mesh can therefore differ from ``mcubes.marching_cubes`` wherever
+an ambiguous face occurs; surfaces stay watertight because the rule is consistent across the shared face.  The per-case triangle
+counts are pinned by tests/test_mc.py::test_case_table_triangle_counts_are_pinned so the convention cannot change unnoticed
+(parity with PyMCubes is pinned for the vertex set only).
 """
 import numpy as np
 

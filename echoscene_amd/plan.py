@@ -388,6 +388,8 @@ def combine_plans(device, main, side, side_repeat=1):
     ops = [fork]
     for _ in range(side_repeat):
         for op in side._arr:
+            if op.kind in (hip.OP_FORK, hip.OP_JOIN):
+                continue                   # the side plan's own lanes collapse into lane 1 (an inner JOIN would stall the main stream)
             o = Op()
             C.memmove(C.byref(o), C.byref(op), C.sizeof(Op))
             o.lane = 1

@@ -166,8 +166,11 @@ class VolBuilderMixin:
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
-        if not ncdhw and M * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
-            need = max(16 if M * pc.N <= (1 << 22) else 8, splitk or 0) * M * pc.N      # contract of es_conv_args.splitk = -1
+        # eligibility from the WHOLE problem's row count (O_hint): a shard and the unsharded run must take the same can_split
+        # decision, or the library picks S from the global tile count for one and S = 1 for the other
+        Mh = max(a.O_hint, O) * D * H * W
+        if not ncdhw and Mh * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
+            need = max(16 if Mh * pc.N <= (1 << 22) else 8, splitk or 0) * M * pc.N     # contract of es_conv_args.splitk = -1
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
                 self._ws = self.buf(need)
                 for op in self.ops:
@@ -364,7 +367,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     # latent and the time-embedding table row.  In the single-GPU 'crossattn' plan it therefore runs as a parallel graph
     # branch (lane 2) and is joined right before the first SpatialTransformer3D -- ~0.4 ms off the critical path per step.
     side_join = {'pending': False}
-    if w.mp and not w.concat and Ol == Ofull and tables is not None and len(b.ops) > side0:
+    # (not with ES_LANES=1: emit_gcn's own FORK/JOIN pairs would then be nested inside this branch and every inner JOIN would
+    #  make the main stream wait for the whole echo chain)
+    if w.mp and not w.concat and Ol == Ofull and tables is not None and len(b.ops) > side0 and not b.use_lanes:
         for k in range(side0, len(b.ops)):
             if k not in keep_main:
                 b.ops[k].lane = 2

@@ -50,8 +50,11 @@ def marching_cubes_batch(sdf, level=0.02):
 
     ``sdf``: float32 CUDA tensor [O, n, n, n] (or [O, 1, n, n, n], the layout ``rel2shape`` returns).  Returns a list of
     (verts f32 [V,3] in grid-index units, faces int64 [T,3]) per object, CUDA tensors -- the values
-    ``mcubes.marching_cubes(sdf[i, 0].cpu().numpy(), level)`` produces in the reference (util_3d.py:214-217), up to the order of
-    the vertices / faces and the choice of diagonals inside a cell (mc_tables.py)."""
+    ``mcubes.marching_cubes(sdf[i, 0].cpu().numpy(), level)`` produces in the reference (util_3d.py:214-217) for the VERTEX SET
+    (one vertex per sign-changing grid edge, same interpolation), up to their order.  The FACES follow this package's own case
+    table (mc_tables.py): the diagonals inside a cell AND, on ambiguous-face cases, the loop structure / triangle count differ
+    from PyMCubes' classic table (44 case / complement pairs) -- face counts and topology can differ there; meshes are
+    watertight either way."""
     if sdf.dim() == 5:
         assert sdf.shape[1] == 1
         sdf = sdf[:, 0]

@@ -150,6 +150,16 @@ class ShapeDenoiser:
         self.tables = time_tables(self.w, self.temb, self.w.shape_t, self.device)
         self._plans, self.max_plans = {}, 2
 
+    def _insert_plan(self, key, st):
+        """bounded plan cache: evicting a plan also drops the fused (layout + shape) graph built on it -- each resident plan
+        owns its activation buffers, split-K workspace and captured graph (several GB at O = 32)"""
+        while len(self._plans) >= self.max_plans:
+            old = self._plans.pop(next(iter(self._plans)))
+            fk = getattr(self, '_fused_key', None)
+            if fk is not None and old.get('plan') is not None and fk[1] == id(old['plan']):
+                self._fused, self._fused_key = None, None
+        self._plans[key] = st
+
     def _plan_for(self, uc, triples, c=None):
         from .parallel import partition
         uc = uc.reshape(uc.shape[0], -1)
@@ -174,7 +184,7 @@ class ShapeDenoiser:
                 st = dict(empty=True, x=z(0, *self.z_shape), eps=z(0, *self.z_shape), lo=lo, hi=hi, O=O,
                           codes_local=z(block, 64), codes_all=z(block * self.world, 64), objbuf=None, cdev=None, xc=None)
                 st['sig'] = sig
-                self._plans[key] = st
+                self._insert_plan(key, st)
                 return st
             g = GraphIndex(triples, O, self.device, capacity=cap)
             b = Builder(self.device)
@@ -205,9 +215,7 @@ class ShapeDenoiser:
             if self.world > 1 and self.w.mp:
                 st['stem_plan'] = sub(b.ops[:b.split])
                 st['main_plan'] = sub(b.ops[b.split:])
-            if len(self._plans) >= self.max_plans:
-                self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = st
+            self._insert_plan(key, st)
         elif st.get('sig') != sig and not st.get('empty'):
             # same size class, another scene graph: rewrite indices / predicate rows in place, keep plans and graphs
             st['g'].update(triples)

@@ -49,6 +49,19 @@ def test_product_case_table_matches_oracle_polygoniser():
     assert (t[0] < 0).all() and (t[255] < 0).all()
 
 
+def test_case_table_triangle_counts_are_pinned():
+    """The product's case table is generated from a rule (mc_tables.py); its loop structure on ambiguous faces is a CONVENTION that
+    differs from PyMCubes' complement-symmetric table.  Pin the per-case triangle counts so it cannot drift unnoticed."""
+    import zlib
+    from echoscene_amd.mc_tables import tri_table
+    t = tri_table()
+    cnt = ((t >= 0).sum(1) // 3).astype(np.uint8)
+    assert int(cnt.sum()) == 820 and np.bincount(cnt).tolist() == [2, 16, 50, 80, 76, 32]
+    assert zlib.crc32(cnt.tobytes()) == 1786192196
+    assert (cnt[5], cnt[10], cnt[245], cnt[250]) == (2, 2, 4, 4)          # not complement-symmetric: the classic table has 2, 2, 2, 2
+    assert int((cnt != cnt[::-1]).sum()) == 88                             # 44 case / complement pairs differ
+
+
 def _compare(sdf_np, level):
     from echoscene_amd.postprocess import marching_cubes_batch
     sdf = torch.from_numpy(np.stack(sdf_np).astype(np.float32)).cuda()
@@ -76,6 +89,7 @@ def _compare(sdf_np, level):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 def test_marching_cubes_device_vs_oracle_analytic_and_noise():
     _compare([_sphere(32, (15.3, 16.1, 14.8), 9.7), _sphere(32, (10.2, 12.0, 20.5), 6.1)], 0.02)
     _compare([_noise(20, 1), _noise(20, 2), _noise(20, 3)], 0.02)
@@ -83,6 +97,7 @@ def test_marching_cubes_device_vs_oracle_analytic_and_noise():
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')
 def test_marching_cubes_on_decoded_sdf_64():
     """The shipped use: the VQ-VAE decoder's [O,1,64,64,64] output at level 0.02 (util_3d.py:194-217), through the
     sdf_to_mesh mirror (verts / n_cell - 0.5)."""
