@@ -53,13 +53,23 @@ def sharded_ddim_loop(backend, num_objects, n_steps, world, group=None):
         step(i, codes_all)    -> advance this rank's latents by DDIM iteration i given all objects' codes
         latents_local()       -> [O_local, C, D, H, W]
         gather_buffers()      -> optional: pre-allocated (send block, receive buffer) of the exchange
-    Per step on the HIP path: one captured graph (stem), one RCCL all-gather of [block, 64] floats per rank, one captured
-    graph (everything else) -- no allocation, no torch op in between.  Returns the full latents [O, C, D, H, W] on every
+    Per step on the HIP path: ONE captured graph = stem ops, the RCCL all-gather of [block, 64] floats per rank, everything else
+    (backend.step_graph); where the collective cannot be captured (gloo in the CPU / one-GPU tests) the step is graph launch (stem),
+    all-gather, graph launch (rest) -- no allocation, no torch op in between.  Returns the full latents [O, C, D, H, W] on every
     rank.  A rank without objects (more ranks than objects) still joins every collective."""
-    bufs = backend.gather_buffers() if (world > 1 and hasattr(backend, 'gather_buffers')) else None
+    exchange = world > 1 or getattr(backend, 'force_exchange', False)
+    bufs = backend.gather_buffers() if (exchange and hasattr(backend, 'gather_buffers')) else None
+    g = backend.step_graph(group) if (exchange and hasattr(backend, 'step_graph')) else None
+    if g is not None:
+        # one captured graph per step: stem -> RCCL all-gather -> main, no host work between the steps
+        backend.begin(0)
+        for i in range(n_steps):
+            g.replay()
+        zl = backend.latents_local()
+        return all_gather_rows(zl, num_objects, world, group) if world > 1 else zl
     for i in range(n_steps):
         cl = backend.codes_local(i)
-        if world > 1:
+        if exchange:
             ca = all_gather_rows(cl, num_objects, world, group, out=bufs[1] if bufs else None)
         else:
             ca = cl

@@ -281,7 +281,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             b.xc = xc
         else:
             b.stem(x, w.stem, b.buf(Ol, 32 * 512), code512, Ol)
-        if Ol == Ofull:
+        if Ol == Ofull and not getattr(b, 'force_exchange', False):
             b.linear([seg(View(code512))], w.stem_lin, Ol, View(objbuf, col=ucw, ld=Dobj, width=gdim))
             b.codes_local = None
             b.codes_all = None
@@ -369,7 +369,8 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     side_join = {'pending': False}
     # (not with ES_LANES=1: emit_gcn's own FORK/JOIN pairs would then be nested inside this branch and every inner JOIN would
     #  make the main stream wait for the whole echo chain)
-    if w.mp and not w.concat and Ol == Ofull and tables is not None and len(b.ops) > side0 and not b.use_lanes:
+    if (w.mp and not w.concat and Ol == Ofull and tables is not None and len(b.ops) > side0 and not b.use_lanes
+            and not getattr(b, 'force_exchange', False)):
         for k in range(side0, len(b.ops)):
             if k not in keep_main:
                 b.ops[k].lane = 2

@@ -129,7 +129,10 @@ class ShapeDenoiser:
     step as one hipGraph; world > 1 splits each step at the echo all-gather."""
 
     def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
-                 group=None, deterministic=True):
+                 group=None, deterministic=False, force_exchange=False):
+        """``force_exchange``: build the sharded step structure (stem plan -> code exchange -> main plan) even at world == 1 --
+        the one-GPU test of the captured RCCL exchange (tests/test_hip_scene.py)."""
+        self.force_exchange = bool(force_exchange)
         self.device = device or torch.device('cuda')
         self.df = df
         net = df.diffusion_net
@@ -144,8 +147,11 @@ class ShapeDenoiser:
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
         self.rank, self.world, self.group = rank, world, group
-        # deterministic: a shard reproduces the unsharded run bit for bit (split-K factors and GroupNorm partial-sum tiles are
-        # chosen from the GLOBAL object count); False lets every rank tune them to its local share (faster at few objects)
+        # deterministic=True: a shard reproduces the unsharded run BIT FOR BIT (split-K factors and GroupNorm partial-sum tiles are
+        # chosen from the GLOBAL object count).  Default False: every rank tunes them to its local share -- the results then differ
+        # from the single-GPU run in fp32 summation order only (5e-4 relative after 4 steps, inside the 2e-2 parity budget) and a
+        # shard of 4 objects runs 1.8x faster (one-GPU emulation: x3.6 vs x2.0 at 8 ranks): bit-exactness across world sizes costs
+        # the K split that small shards need, because a K loop cut in other places sums in another order.
         self.deterministic = deterministic
         self.tables = time_tables(self.w, self.temb, self.w.shape_t, self.device)
         self._plans, self.max_plans = {}, 2
@@ -189,6 +195,7 @@ class ShapeDenoiser:
             g = GraphIndex(triples, O, self.device, capacity=cap)
             b = Builder(self.device)
             b.shard_block = block
+            b.force_exchange = self.force_exchange
             if self.world > 1 and self.deterministic:
                 b.o_hint = O       # split-K / partial-sum tiling as in the unsharded run -> bit-identical latents
             x = b.buf(hi - lo, *self.z_shape)
@@ -212,7 +219,7 @@ class ShapeDenoiser:
                 return b2.finish()
             st['plan'] = b.finish()
             st['eps_plan'] = sub(b.ops[:n_eps_ops])
-            if self.world > 1 and self.w.mp:
+            if (self.world > 1 or self.force_exchange) and self.w.mp:
                 st['stem_plan'] = sub(b.ops[:b.split])
                 st['main_plan'] = sub(b.ops[b.split:])
             self._insert_plan(key, st)
@@ -256,6 +263,46 @@ class ShapeDenoiser:
     def latents_local(self):
         return self._cur['x']
 
+    def step_graph(self, group=None):
+        """ONE graph per DDIM step of the sharded loop ("RCCL on a dedicated stream, or direct peer
+        writes for the 8 KB"): this rank's stem ops -> the RCCL all-gather of the [block, 64] codes -> everything else, captured
+        together (torch.cuda.CUDAGraph: ProcessGroupNCCL collectives are capturable), so a step is a single graph launch with no
+        host round trip between its three parts.  The step counter lives on the device and is advanced by the captured DDIM
+        update.  Returns the graph, or None when the exchange cannot be captured (gloo test backend, an empty shard, eager mode,
+        or a capture error) -- the loop then falls back to graph launch / collective / graph launch per step."""
+        st = self._cur
+        if st.get('empty') or not self._use_graph or 'stem_plan' not in st:
+            return None
+        if 'step_graph' in st:
+            return st['step_graph']
+        st['step_graph'] = None
+        try:
+            import torch.distributed as dist
+            if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
+                return None
+            send, recv = st['codes_local'], st['codes_all']
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                dist.all_gather_into_tensor(recv, send, group=group)      # communicator set-up outside the capture (recv is scratch)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    st['stem_plan'].run()
+                    dist.all_gather_into_tensor(recv, send, group=group)
+                    st['main_plan'].run()
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            st['step_graph'] = g
+        except Exception as e:                 # noqa: BLE001 -- any capture problem: keep the three-call step
+            import warnings
+            warnings.warn('sharded DDIM step: the RCCL exchange could not be captured (%s); using graph / collective / graph per step' % e)
+            st['step_graph'] = None
+        return st['step_graph']
+
+    def begin(self, first_step):
+        """set the device step counter (the captured step graph does not re-set it every replay)"""
+        self._cur['step'].fill_(int(first_step))
+
     def eps(self, x, uc, triples, iteration, c=None):
         assert self.world == 1
         st = self._plan_for(uc, triples, c)
@@ -279,7 +326,7 @@ class ShapeDenoiser:
                 return all_gather_rows(st['x'], st['O'], self.world, self.group).clone()
             self._cur, self._use_graph = st, use_graph
             return loop(self, st['O'], n_steps, self.world, self.group).clone()
-        if self.world == 1 or not self.w.mp:
+        if (self.world == 1 and not self.force_exchange) or not self.w.mp:
             st['plan'].sample(st['step'], 0, n_steps, use_graph=use_graph)
             if self.world == 1:
                 return st['x'].clone()

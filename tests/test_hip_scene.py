@@ -390,6 +390,21 @@ def test_configs4_rank_shapes_on_one_gpu():
         assert e < 2e-3
 
 
+def test_sharded_step_is_one_captured_graph_with_rccl_exchange():
+    """SURVEY.md section 8(e) / VERDICT r2 #6: a sharded DDIM step = this rank's stem ops -> RCCL all-gather of the codes ->
+    everything else, captured as ONE graph (samplers.ShapeDenoiser.step_graph).  One-GPU form: a 1-rank NCCL group and the
+    sharded step structure forced at world == 1 (tools/probe_step_graph.py, own process: it owns a process group); the captured loop
+    must reproduce the ordinary single-graph run bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probe_step_graph.py')], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert 'STEP_GRAPH_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks
     sharing the one GPU of the test box over gloo (ES_DIST_BACKEND=gloo: NCCL refuses two ranks on one device; the exchange is
