@@ -184,3 +184,235 @@ extern "C" int es_sampler_run(es_plan* p, int32_t* step, int first_step, int n_s
     }
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Model files (include/echoscene_hip.h): a plan + the device buffers it references, relocatable.
+// ---------------------------------------------------------------------------------------------
+#include <cstddef>
+#include <string>
+#include <algorithm>
+
+#define ES_PTR(member) offsetof(es_op, u.member)
+
+extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
+    std::vector<size_t> v;
+    switch (kind) {
+        case ES_OP_LINEAR:
+            for (int s = 0; s < 3; ++s) {
+                const size_t b = offsetof(es_op, u.linear.seg) + s * sizeof(es_seg);
+                for (size_t f : {offsetof(es_seg, ptr), offsetof(es_seg, idx), offsetof(es_seg, ent_row), offsetof(es_seg, ent_off),
+                                 offsetof(es_seg, step), offsetof(es_seg, gamma), offsetof(es_seg, beta)})
+                    v.push_back(b + f);
+            }
+            for (size_t f : {ES_PTR(linear.wpack), ES_PTR(linear.bias), ES_PTR(linear.gamma), ES_PTR(linear.beta), ES_PTR(linear.res),
+                             ES_PTR(linear.res2), ES_PTR(linear.out)})
+                v.push_back(f);
+            break;
+        case ES_OP_DDPM: case ES_OP_DDIM:
+            v = {ES_PTR(update.x), ES_PTR(update.eps), ES_PTR(update.noise), ES_PTR(update.coef), ES_PTR(update.step)};
+            break;
+        case ES_OP_COPY: v = {ES_PTR(copy.dst), ES_PTR(copy.src)}; break;
+        case ES_OP_CONV:
+            v = {ES_PTR(conv.a), ES_PTR(conv.w), ES_PTR(conv.a2), ES_PTR(conv.w2), ES_PTR(conv.bias), ES_PTR(conv.rowvec), ES_PTR(conv.res),
+                 ES_PTR(conv.out_f32), ES_PTR(conv.out_f16), ES_PTR(conv.workspace)};
+            break;
+        case ES_OP_GN:
+            v = {ES_PTR(gn.x1), ES_PTR(gn.x2), ES_PTR(gn.gamma), ES_PTR(gn.beta), ES_PTR(gn.stats), ES_PTR(gn.y_f16), ES_PTR(gn.raw_f16)};
+            break;
+        case ES_OP_LN: v = {ES_PTR(ln.x), ES_PTR(ln.gamma), ES_PTR(ln.beta), ES_PTR(ln.y_f16)}; break;
+        case ES_OP_ATTN: v = {ES_PTR(attn.qkv), ES_PTR(attn.out_f16)}; break;
+        case ES_OP_GEGLU: v = {ES_PTR(geglu.h_f32), ES_PTR(geglu.out_f16)}; break;
+        case ES_OP_TO_CL: v = {ES_PTR(tocl.x), ES_PTR(tocl.out)}; break;
+        case ES_OP_STEM:
+            v = {ES_PTR(stem.x), ES_PTR(stem.w0), ES_PTR(stem.b0), ES_PTR(stem.w1), ES_PTR(stem.b1), ES_PTR(stem.scratch), ES_PTR(stem.out)};
+            break;
+        case ES_OP_VQ: v = {ES_PTR(vq.z), ES_PTR(vq.codebook), ES_PTR(vq.lut), ES_PTR(vq.idx_out), ES_PTR(vq.out_f16)}; break;
+        case ES_OP_ROWSEL: v = {ES_PTR(rowsel.table), ES_PTR(rowsel.step), ES_PTR(rowsel.out)}; break;
+        case ES_OP_FORK: case ES_OP_JOIN: break;
+        default: return -1;
+    }
+    const int n = (int)v.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+    return n;
+}
+
+namespace {
+constexpr char ES_MODEL_MAGIC[8] = {'E', 'S', 'M', 'O', 'D', 'E', 'L', '1'};
+struct ModelHeader { char magic[8]; uint32_t abi, n_buffers, n_ops, n_regions, op_size, pad; };
+struct RegionRec { char name[32]; uint32_t buffer, pad; uint64_t offset, bytes; };
+constexpr uint64_t OFF_BITS = 40;
+
+// encoded reference: 0 = NULL, else ((buffer + 1) << 40) | offset
+bool encode_ptr(uint64_t p, const es_buffer_desc* bufs, int nb, uint64_t* out) {
+    if (!p) { *out = 0; return true; }
+    for (int i = 0; i < nb; ++i) {
+        const uint64_t b = (uint64_t)bufs[i].ptr;
+        if (p >= b && p < b + bufs[i].bytes) { *out = ((uint64_t)(i + 1) << OFF_BITS) | (p - b); return true; }
+    }
+    return false;
+}
+}  // namespace
+
+struct es_model {
+    std::vector<void*> bufs;
+    std::vector<size_t> sizes;
+    std::vector<RegionRec> regions;
+    es_plan* plan = nullptr;
+};
+
+extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buffer_desc* buffers, int n_buffers,
+                             const es_region_desc* regions, int n_regions) {
+    ES_REQUIRE(path && plan && buffers && n_buffers > 0, "es_model_save: bad args");
+    for (int i = 0; i < n_buffers; ++i)
+        ES_REQUIRE(buffers[i].bytes < (1ull << OFF_BITS), "es_model_save: buffer %d too large", i);
+    std::vector<es_op> ops = plan->ops;
+    size_t offs[64];
+    for (size_t k = 0; k < ops.size(); ++k) {
+        const int n = es_op_pointer_offsets(ops[k].kind, offs, 64);
+        ES_REQUIRE(n >= 0, "es_model_save: op %zu has unknown kind %d", k, ops[k].kind);
+        for (int j = 0; j < n; ++j) {
+            uint64_t* f = (uint64_t*)((char*)&ops[k] + offs[j]);
+            uint64_t enc;
+            ES_REQUIRE(encode_ptr(*f, buffers, n_buffers, &enc), "es_model_save: op %zu (kind %d) field at +%zu points outside every buffer (%p)",
+                       k, ops[k].kind, offs[j], (void*)*f);
+            *f = enc;
+        }
+    }
+    FILE* fp = fopen(path, "wb");
+    ES_REQUIRE(fp, "es_model_save: cannot open %s", path);
+    ModelHeader h{};
+    memcpy(h.magic, ES_MODEL_MAGIC, 8);
+    h.abi = ES_ABI_VERSION; h.n_buffers = (uint32_t)n_buffers; h.n_ops = (uint32_t)ops.size(); h.n_regions = (uint32_t)n_regions;
+    h.op_size = (uint32_t)sizeof(es_op);
+    bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
+    for (int i = 0; i < n_buffers && ok; ++i) { const uint64_t b = buffers[i].bytes; ok = fwrite(&b, 8, 1, fp) == 1; }
+    for (int i = 0; i < n_regions && ok; ++i) {
+        RegionRec r{};
+        memcpy(r.name, regions[i].name, 32);
+        r.name[31] = 0;
+        uint64_t enc;
+        if (!encode_ptr((uint64_t)regions[i].ptr, buffers, n_buffers, &enc) || !enc) { fclose(fp); ES_REQUIRE(false, "es_model_save: region %s outside every buffer", r.name); }
+        r.buffer = (uint32_t)((enc >> OFF_BITS) - 1); r.offset = enc & ((1ull << OFF_BITS) - 1); r.bytes = regions[i].bytes;
+        ok = fwrite(&r, sizeof(r), 1, fp) == 1;
+    }
+    ok = ok && fwrite(ops.data(), sizeof(es_op), ops.size(), fp) == ops.size();
+    std::vector<char> host;
+    for (int i = 0; i < n_buffers && ok; ++i) {
+        host.resize(buffers[i].bytes);
+        if (hipMemcpy(host.data(), buffers[i].ptr, buffers[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(host.data(), 1, host.size(), fp) == host.size();
+    }
+    fclose(fp);
+    ES_REQUIRE(ok, "es_model_save: write to %s failed", path);
+    return 0;
+}
+
+extern "C" void es_model_free(es_model* m) {
+    if (!m) return;
+    if (m->plan) es_plan_destroy(m->plan);
+    for (void* p : m->bufs) if (p) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" es_model* es_model_load(const char* path) {
+    FILE* fp = path ? fopen(path, "rb") : nullptr;
+    if (!fp) { es_set_error("es_model_load: cannot open %s", path ? path : "(null)"); return nullptr; }
+    es_model* m = new es_model();
+    auto fail = [&](const char* why) -> es_model* { es_set_error("es_model_load(%s): %s", path, why); fclose(fp); es_model_free(m); return nullptr; };
+    ModelHeader h{};
+    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, ES_MODEL_MAGIC, 8)) return fail("not a model file");
+    if (h.abi != ES_ABI_VERSION || h.op_size != sizeof(es_op)) return fail("written by another ABI version");
+    m->sizes.resize(h.n_buffers);
+    for (uint32_t i = 0; i < h.n_buffers; ++i) { uint64_t b; if (fread(&b, 8, 1, fp) != 1) return fail("truncated buffer table"); m->sizes[i] = (size_t)b; }
+    m->regions.resize(h.n_regions);
+    if (h.n_regions && fread(m->regions.data(), sizeof(RegionRec), h.n_regions, fp) != h.n_regions) return fail("truncated region table");
+    std::vector<es_op> ops(h.n_ops);
+    if (fread(ops.data(), sizeof(es_op), h.n_ops, fp) != h.n_ops) return fail("truncated op list");
+    m->bufs.assign(h.n_buffers, nullptr);
+    std::vector<char> host;
+    for (uint32_t i = 0; i < h.n_buffers; ++i) {
+        if (hipMalloc(&m->bufs[i], m->sizes[i] ? m->sizes[i] : 1) != hipSuccess) return fail("hipMalloc failed");
+        host.resize(m->sizes[i]);
+        if (fread(host.data(), 1, host.size(), fp) != host.size()) return fail("truncated buffer contents");
+        if (hipMemcpy(m->bufs[i], host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
+    }
+    size_t offs[64];
+    for (es_op& op : ops) {
+        const int n = es_op_pointer_offsets(op.kind, offs, 64);
+        if (n < 0) return fail("unknown op kind");
+        for (int j = 0; j < n; ++j) {
+            uint64_t* f = (uint64_t*)((char*)&op + offs[j]);
+            if (!*f) continue;
+            const uint64_t bi = (*f >> OFF_BITS) - 1, off = *f & ((1ull << OFF_BITS) - 1);
+            if (bi >= h.n_buffers || off >= m->sizes[bi]) return fail("pointer reference out of range");
+            *f = (uint64_t)m->bufs[bi] + off;
+        }
+    }
+    for (const RegionRec& r : m->regions)
+        if (r.buffer >= h.n_buffers || r.offset + r.bytes > m->sizes[r.buffer]) return fail("region out of range");
+    fclose(fp);
+    m->plan = es_plan_create(ops.data(), (int)ops.size());
+    if (!m->plan) { es_model_free(m); return nullptr; }
+    return m;
+}
+
+extern "C" int es_model_region(const es_model* m, const char* name, void** dev_ptr, size_t* bytes) {
+    ES_REQUIRE(m && name, "es_model_region: bad args");
+    for (const RegionRec& r : m->regions)
+        if (!strncmp(r.name, name, 32)) {
+            if (dev_ptr) *dev_ptr = (char*)m->bufs[r.buffer] + r.offset;
+            if (bytes) *bytes = (size_t)r.bytes;
+            return 0;
+        }
+    ES_REQUIRE(false, "es_model_region: the model has no region '%s'", name);
+}
+
+extern "C" int es_model_num_ops(const es_model* m) { return m && m->plan ? (int)m->plan->ops.size() : 0; }
+
+extern "C" int es_model_run(es_model* m, int first_step, int n_steps, es_stream stream) {
+    ES_REQUIRE(m && m->plan, "es_model_run: null model");
+    void* step = nullptr;
+    if (int rc = es_model_region(m, "step", &step, nullptr)) return rc;
+    return es_sampler_run(m->plan, (int32_t*)step, first_step, n_steps, 1, stream);
+}
+
+extern "C" int es_layout_sample(es_model* m, const float* noise, int noise_rows, int n_steps, float* x_out, es_stream stream) {
+    ES_REQUIRE(m && noise && x_out && n_steps >= 0 && noise_rows >= n_steps + 1, "es_layout_sample: bad args (noise rows %d, steps %d)", noise_rows, n_steps);
+    void *x = nullptr, *nz = nullptr;
+    size_t xb = 0, nb = 0;
+    if (int rc = es_model_region(m, "x", &x, &xb)) return rc;
+    if (int rc = es_model_region(m, "noise", &nz, &nb)) return rc;
+    ES_REQUIRE((size_t)noise_rows * xb <= nb, "es_layout_sample: %d noise rows exceed the model's schedule (%zu rows)", noise_rows, nb / xb);
+    hipStream_t s = (hipStream_t)stream;
+    ES_CHECK_HIP(hipMemcpyAsync(nz, noise, (size_t)noise_rows * xb, hipMemcpyDeviceToDevice, s));
+    ES_CHECK_HIP(hipMemcpyAsync(x, noise, xb, hipMemcpyDeviceToDevice, s));               // x_T = row 0
+    if (int rc = es_model_run(m, 0, n_steps, stream)) return rc;
+    ES_CHECK_HIP(hipMemcpyAsync(x_out, x, xb, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int es_shape_sample(es_model* m, const float* z_T, int n_steps, float* z_out, es_stream stream) {
+    ES_REQUIRE(m && z_T && z_out && n_steps >= 0, "es_shape_sample: bad args");
+    void* x = nullptr;
+    size_t xb = 0;
+    if (int rc = es_model_region(m, "x", &x, &xb)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ES_CHECK_HIP(hipMemcpyAsync(x, z_T, xb, hipMemcpyDeviceToDevice, s));
+    if (int rc = es_model_run(m, 0, n_steps, stream)) return rc;
+    ES_CHECK_HIP(hipMemcpyAsync(z_out, x, xb, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int es_vq_decode(es_model* m, const float* z, float* sdf_out, es_stream stream) {
+    ES_REQUIRE(m && m->plan && z && sdf_out, "es_vq_decode: bad args");
+    void *zi = nullptr, *so = nullptr;
+    size_t zb = 0, sb = 0;
+    if (int rc = es_model_region(m, "z", &zi, &zb)) return rc;
+    if (int rc = es_model_region(m, "sdf", &so, &sb)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ES_CHECK_HIP(hipMemcpyAsync(zi, z, zb, hipMemcpyDeviceToDevice, s));
+    if (int rc = es_plan_run(m->plan, stream)) return rc;
+    ES_CHECK_HIP(hipMemcpyAsync(sdf_out, so, sb, hipMemcpyDeviceToDevice, s));
+    return 0;
+}

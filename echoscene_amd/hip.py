@@ -112,6 +112,14 @@ class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('lane', C.c_int32), ('u', _OpU)]
 
 
+class BufferDesc(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('bytes', C.c_size_t)]
+
+
+class RegionDesc(C.Structure):
+    _fields_ = [('name', C.c_char * 32), ('ptr', C.c_void_p), ('bytes', C.c_size_t)]
+
+
 EXPORTS = {
     'es_abi_version': (C.c_int, []),
     'es_last_error': (C.c_char_p, []),
@@ -154,6 +162,16 @@ EXPORTS = {
     'es_plan_run': (C.c_int, [C.c_void_p, C.c_void_p]),
     'es_plan_capture': (C.c_int, [C.c_void_p, C.c_void_p]),
     'es_sampler_run': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'es_op_pointer_offsets': (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.c_int]),
+    'es_model_save': (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(BufferDesc), C.c_int, C.POINTER(RegionDesc), C.c_int]),
+    'es_model_load': (C.c_void_p, [C.c_char_p]),
+    'es_model_free': (None, [C.c_void_p]),
+    'es_model_region': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    'es_model_num_ops': (C.c_int, [C.c_void_p]),
+    'es_model_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'es_layout_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_shape_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_vq_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -375,6 +375,55 @@ class Plan:
             pass
 
 
+def save_model(plan, path, regions):
+    """Serialise ``plan`` and every device allocation it references into a model file that a host WITHOUT Python loads with
+    ``es_model_load`` and runs with ``es_layout_sample`` / ``es_shape_sample`` / ``es_vq_decode`` (include/echoscene_hip.h).
+    ``regions``: name -> tensor, the caller's I/O areas ("x", "noise", "step", "z", "sdf").  The pointer fields of the ops are
+    found through ``es_op_pointer_offsets`` (one table, in the library) and mapped to the allocator blocks that contain them;
+    the library rewrites them as (buffer, offset) and dumps the buffers."""
+    import bisect
+    L = hip.lib()
+    torch.cuda.synchronize()
+    ptrs = set()
+    offs = (C.c_size_t * 64)()
+    for op in plan._arr:
+        n = L.es_op_pointer_offsets(op.kind, offs, 64)
+        if n < 0:
+            raise RuntimeError('save_model: op kind %d has no pointer table' % op.kind)
+        base = C.addressof(op)
+        for j in range(n):
+            v = C.c_uint64.from_address(base + offs[j]).value
+            if v:
+                ptrs.add(v)
+    for t in regions.values():
+        ptrs.add(t.data_ptr())
+    blocks = []
+    for sg in torch.cuda.memory_snapshot():
+        a = sg['address']
+        for blk in sg['blocks']:
+            if blk['state'] == 'active_allocated':
+                blocks.append((a, blk['size']))
+            a += blk['size']
+    blocks.sort()
+    starts = [b0 for b0, _ in blocks]
+    used = {}
+    for p in sorted(ptrs):
+        i = bisect.bisect_right(starts, p) - 1
+        if i < 0 or p >= blocks[i][0] + blocks[i][1]:
+            raise RuntimeError('save_model: pointer 0x%x is not inside a live torch allocation' % p)
+        used[i] = blocks[i]
+    bl = [used[i] for i in sorted(used)]
+    bufs = (hip.BufferDesc * len(bl))()
+    for k, (a, n) in enumerate(bl):
+        bufs[k].ptr, bufs[k].bytes = a, n
+    regs = (hip.RegionDesc * len(regions))()
+    for k, (name, t) in enumerate(regions.items()):
+        regs[k].name = name.encode()
+        regs[k].ptr, regs[k].bytes = t.data_ptr(), t.numel() * t.element_size()
+    hip.check(L.es_model_save(str(path).encode(), C.c_void_p(plan.handle), bufs, len(bl), regs, len(regions)), 'es_model_save')
+    return sum(n for _, n in bl)
+
+
 def combine_plans(device, main, side, side_repeat=1):
     """One plan = ``main``'s ops on lane 0 and ``side_repeat`` copies of ``side``'s ops on lane 1 (forked before, joined after):
     captured as ONE hipGraph with two parallel branches, so the latency-bound layout chain (32 workgroups per launch) can run

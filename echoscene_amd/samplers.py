@@ -99,6 +99,12 @@ class LayoutDenoiser:
     def weight_bytes_per_step(self):
         return self._last['plan'].weight_bytes
 
+    def save_model(self, path, obj_embed, triples):
+        """The layout loop of this scene graph as a model file for hosts without Python (es_model_load + es_layout_sample)."""
+        from .plan import save_model
+        st = self._plan_for(obj_embed, triples)
+        return save_model(st['plan'], path, dict(x=st['x'], noise=st['noise'], step=st['step']))
+
     def eps(self, x, obj_embed, triples, iteration):
         """One UNet1DModel.forward at loop iteration ``iteration`` (t = T-1-iteration)."""
         st = self._plan_for(obj_embed, triples)
@@ -263,6 +269,13 @@ class ShapeDenoiser:
     def latents_local(self):
         return self._cur['x']
 
+    def save_model(self, path, uc, triples, c=None):
+        """The DDIM loop of this scene (single GPU) as a model file for hosts without Python (es_model_load + es_shape_sample)."""
+        from .plan import save_model
+        assert self.world == 1 and not self.force_exchange
+        st = self._plan_for(uc, triples, c)
+        return save_model(st['plan'], path, dict(x=st['x'], step=st['step']))
+
     def step_graph(self, group=None):
         """ONE graph per DDIM step of the sharded loop ("RCCL on a dedicated stream, or direct peer
         writes for the 8 KB"): this rank's stem ops -> the RCCL all-gather of the [block, 64] codes -> everything else, captured
@@ -394,6 +407,12 @@ class VQDecoder:
             assert tuple(dm) == od, (dm, od)
             self._plans = {key: dict(plan=b.finish(), z=z, sdf=sdf)}
         return self._plans[key]
+
+    def save_model(self, path, n_objects, zdims=(16, 16, 16)):
+        """The decoder for ``n_objects`` latents as a model file for hosts without Python (es_model_load + es_vq_decode)."""
+        from .plan import save_model
+        st = self._plan(n_objects, tuple(zdims))
+        return save_model(st['plan'], path, dict(z=st['z'], sdf=st['sdf']))
 
     def decode_no_quant(self, z, sync=True):
         """``sync=False``: everything is only enqueued on the current stream (the caller orders consumers)."""

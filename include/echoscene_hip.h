@@ -352,6 +352,40 @@ int es_init(void);
  *   shape : DDIMSampler.ddim_sampling           (samplers/ddim.py:127-181),   100 iterations   */
 int es_sampler_run(es_plan* plan, int32_t* step, int first_step, int n_steps, int use_graph, es_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Model files: a plan built once (by the Python planner, echoscene_amd/plan*.py) serialised together with every device
+ * buffer it references, so that a host WITHOUT Python can load it and run the sampling loops (the
+ * coarse entry points es_layout_sample / es_shape_sample / es_vq_decode a non-Python binding of model/SGDiff.py would
+ * call, SGDiff.py:87-95 -> echo2layout.py:96-124, echo2shape.py:484-525, vqvae_networks/network.py:95-103).
+ *
+ * File = header, buffer table, named regions, the op list with every pointer field rewritten as (buffer, offset), buffer
+ * contents.  es_model_save is called by the planner (it knows the allocation ranges); es_model_load allocates the buffers with
+ * hipMalloc, uploads the contents, rebases the pointers and creates the plan.  Named regions give the caller its I/O:
+ *   layout model:  "x" [O,8] state, "noise" [T+1,O,8] (row 0 = x_T, row 1+i = draw of iteration i), "step" int32
+ *   shape model :  "x" [O,3,16,16,16] latents, "step" int32
+ *   vq model    :  "z" [O,3,16,16,16] input latents, "sdf" [O,1,64,64,64] output
+ * ---------------------------------------------------------------------------------------- */
+typedef struct es_model es_model;
+typedef struct es_buffer_desc { const void* ptr; size_t bytes; } es_buffer_desc;
+typedef struct es_region_desc { char name[32]; const void* ptr; size_t bytes; } es_region_desc;
+/* byte offsets (inside es_op) of the device-pointer fields of an op of `kind`; returns their number (<= cap) */
+int es_op_pointer_offsets(int kind, size_t* offsets, int cap);
+int es_model_save(const char* path, const es_plan* plan, const es_buffer_desc* buffers, int n_buffers,
+                  const es_region_desc* regions, int n_regions);
+es_model* es_model_load(const char* path);
+void es_model_free(es_model* model);
+int es_model_region(const es_model* model, const char* name, void** dev_ptr, size_t* bytes);
+int es_model_num_ops(const es_model* model);
+/* `n_steps` replays of the model's (captured) plan starting at loop iteration `first_step` (es_sampler_run on its own plan) */
+int es_model_run(es_model* model, int first_step, int n_steps, es_stream stream);
+/* GaussianDiffusion.p_sample_loop_sg (diffusion_ddpm.py:330-345): noise [n_rows >= n_steps + 1][O*8] device fp32 (row 0 = x_T);
+ * x_out [O*8] device fp32 = x after n_steps ancestral steps */
+int es_layout_sample(es_model* model, const float* noise, int noise_rows, int n_steps, float* x_out, es_stream stream);
+/* DDIMSampler.ddim_sampling (samplers/ddim.py:127-181): z_T [O,3,16,16,16] device fp32 -> z_out after n_steps DDIM steps */
+int es_shape_sample(es_model* model, const float* z_T, int n_steps, float* z_out, es_stream stream);
+/* VQVAE.decode_no_quant (vqvae_networks/network.py:95-103): z [O,3,16,16,16] -> sdf_out [O,1,64,64,64], device fp32 */
+int es_vq_decode(es_model* model, const float* z, float* sdf_out, es_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
