@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
-timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1
+timeout 2700 python -m pytest tests -m gpu -x -q -s > $OUT/tests_gpu.log 2>&1
 echo "gpu tests rc=$?" > $OUT/summary.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 echo "smoke rc=$?" >> $OUT/summary.txt
@@ -12,4 +12,4 @@ timeout 300 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
 bash tools/gpu_session_profile.sh ${1:-final}
 timeout 600 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
 timeout 600 python tools/emulate_shards.py --steps 20 --deterministic 2>&1 | grep "^world" > $OUT/shards_det.txt
-cat $OUT/summary.txt; tail -3 $OUT/tests_gpu.log; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -4; cat $OUT/shards_default.txt $OUT/shards_det.txt
+cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; cat $OUT/shards_default.txt $OUT/shards_det.txt
