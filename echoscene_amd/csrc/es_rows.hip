@@ -102,7 +102,7 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
             const long sstr = sg.slab_stride;
             const int pro = sg.pro;
             const bool relu_in = sg.pre_act == ES_ACT_RELU;
-            if (CSR && sg.mode == ES_SEG_CSRMEAN) {
+            if (CSR && (sg.mode == ES_SEG_CSRMEAN || sg.mode == ES_SEG_CSRSUM)) {
                 const int e0 = sg.idx[mc], e1 = sg.idx[mc + 1];
                 for (int c4 = cl; c4 < w4; c4 += LPR) {
                     f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -131,8 +131,9 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
                             if (e + u < e1) v += t[u];
                         }
                     }
+                    const float den = sg.mode == ES_SEG_CSRMEAN ? (float)max(e1 - e0, 1) : 1.0f;     // 'avg' pooling divides by the clamped count
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = row_ok ? v[q] / (float)max(e1 - e0, 1) : 0.f;
+                    for (int q = 0; q < 4; ++q) v[q] = row_ok ? v[q] / den : 0.f;
                     *(f4*)(dst + 4 * c4) = v;
                 }
             } else {
@@ -559,7 +560,7 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) 
         const int pro = a.seg[s].pro;
         if (pro == ES_PRO_GN || pro == ES_PRO_GN_SILU) proc = proc < 1 ? 1 : proc;
         if (pro == ES_PRO_SILU || pro == ES_PRO_GEGLU) proc = 2;
-        csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN;
+        csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN || a.seg[s].mode == ES_SEG_CSRSUM;
     }
     const bool gepi = a.act == ES_ACT_GEGLU;
     // kernel table: lean instantiations for what the sampling path launches, one general kernel per slab bound for the rest

@@ -13,7 +13,7 @@ c_f32p = C.c_void_p
 c_i32p = C.c_void_p
 
 # enums (include/echoscene_hip.h)
-SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN = 0, 1, 2
+SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN, SEG_CSRSUM = 0, 1, 2, 3
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
 CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW, CONV_DOWN_DHW = 0, 1, 2, 3, 4

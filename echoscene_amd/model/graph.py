@@ -11,10 +11,11 @@ class GraphTripleConv(_Holder):
     def __init__(self, input_dim_obj, input_dim_pred, output_dim=None, hidden_dim=512,
                  pooling='avg', mlp_normalization='none', residual=True):
         super().__init__()
-        if pooling != 'avg':
-            # 'sum'/'wAvg' exist in the reference (graph.py:105) but no shipped config
-            # selects them; refuse rather than mis-compute.
-            raise NotImplementedError("pooling=%r: only 'avg' is on the hot path" % pooling)
+        if pooling not in ('avg', 'sum'):
+            # 'wAvg' exists in the reference (graph.py:105, a learned weighting net) but no shipped config
+            # selects it; refuse rather than mis-compute.
+            raise NotImplementedError("pooling=%r: 'avg' and 'sum' are on the hot path" % pooling)
+        self.pooling = pooling
         output_dim = input_dim_obj if output_dim is None else output_dim
         self.input_dim_obj, self.input_dim_pred = input_dim_obj, input_dim_pred
         self.output_dim, self.hidden_dim, self.residual = output_dim, hidden_dim, residual

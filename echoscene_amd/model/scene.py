@@ -275,7 +275,8 @@ class _SceneModel(nn.Module):
                                    'pred_embeddings_man_dc.'))}
             # (the embedding tables live on the device: the lookups below are device-side row gathers, the CLIP features are
             #  never copied to the host -- VERDICT r2 #9)
-            self._setup_w = (GCNWeights(sd, 'gconv_net_ec', dev), GCNWeights(sd, 'gconv_net_manipulation', dev),
+            pool = self.gconv_net_ec.gconvs[0].pooling          # 'avg' (every shipped args.json) or 'sum'
+            self._setup_w = (GCNWeights(sd, 'gconv_net_ec', dev, pool), GCNWeights(sd, 'gconv_net_manipulation', dev, pool),
                              {k: sd[k + '.weight'].float().to(dev) for k in ('obj_embeddings_ec', 'pred_embeddings_ec',
                                                                              'pred_embeddings_man_dc')})
         w_ec, w_man, tabs = self._setup_w

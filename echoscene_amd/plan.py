@@ -460,7 +460,10 @@ def combine_plans(device, main, side, side_repeat=1):
 class GCNWeights:
     """Packed weights of one GraphTripleConvNet: BatchNorm folded into the Linears."""
 
-    def __init__(self, sd, prefix, device):
+    def __init__(self, sd, prefix, device, pooling='avg'):
+        if pooling not in ('avg', 'sum'):
+            raise NotImplementedError("GraphTripleConv pooling=%r: 'avg' and 'sum' are implemented ('wAvg' needs its weighting net)" % pooling)
+        self.pooling = pooling
         self.layers = []
         i = 0
         while f'{prefix}.gconvs.{i}.net1.0.weight' in sd:
@@ -518,7 +521,8 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
             proj = None
             newp = View(t2.t, col=H, ld=W2, width=Dp)
         ptr, rows, offs = g.csr(0, H + Dp)
-        n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRMEAN, idx=ptr, ent_row=rows, ent_off=offs)],
+        n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRSUM if getattr(gw, 'pooling', 'avg') == 'sum' else hip.SEG_CSRMEAN,
+                           idx=ptr, ent_row=rows, ent_off=offs)],
                       L['n2a'], O)                                                           # relu deferred
         dst = out if (last and out is not None) else View(b.buf(O, Dout))
         if proj is not None:

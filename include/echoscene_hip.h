@@ -48,7 +48,7 @@ int es_device_info(char* name_out, int name_cap, int* cu_count);
  *   Chip-wide parallelism for M = 32: grid = (16-column tiles x K slices, 16-row tiles); split-K partial sums are
  *   never reduced by a kernel of their own -- they are "slab tensors" summed by whoever reads them next.
  * ---------------------------------------------------------------------------------------- */
-enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2 };
+enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2, ES_SEG_CSRSUM = 3 };   /* CSRSUM: pooling='sum' (graph.py:186-199 without the division) */
 enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
 enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2, ES_ACT_GEGLU = 3 };
 /* ES_ACT_GEGLU: W/bias rows are interleaved per 16-row tile as [8 value rows | 8 gate rows] (es_pack_linear_geglu_f32);

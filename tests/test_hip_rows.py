@@ -126,6 +126,10 @@ def test_linear_gather_and_csr_mean(dev):
                                  ent_row=torch.tensor(rows), ent_off=torch.tensor(offs))], W2, None, O)
     _close(out, F.linear(pooled, W2), 2e-5)
     assert out[O - 1].abs().max() == 0          # isolated node pools to exactly zero
+    # pooling='sum' (graph.py:105,186: the scatter_add result without the division)
+    out = _run_linear(dev, [dict(src=msg, width=H, ld=2 * H + Dp, mode=hip.SEG_CSRSUM, idx=torch.tensor(ptr),
+                                 ent_row=torch.tensor(rows), ent_off=torch.tensor(offs))], W2, None, O)
+    _close(out, F.linear(pooled * cnt[:, None], W2), 2e-5)
 
 
 def test_bad_args_raise(dev):
