@@ -259,21 +259,35 @@ __device__ __forceinline__ void stage_ln(const es_linear_args& a, float* x, int 
 
 // grid.x = column tiles x K slices (slice fastest: with the observed block -> XCD b % 8 placement the column tiles of one
 // slice share an XCD, i.e. one L2 copy of that slice of A -- speed only), grid.y = row tiles, grid.z = batch.
+// One launch = up to 3 INDEPENDENT problems (es_linear_rows_multi_f32): problem i owns the blockIdx.x range [wg0[i], wg0[i+1]) and
+// the first ny[i] row tiles.
+struct RowsLaunch {
+    es_linear_args p[3];
+    int S[3], kbps[3], wg0[3], ny[3];
+    int n, ldx, dbg;
+};
+
 // NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
 // unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
 template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI>
-__global__ __launch_bounds__(NTHREAD) void k_linear_rows(const es_linear_args a, int S, int kbps, int ldx, int dbg) {
+__global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ldx = L.ldx, dbg = L.dbg;
     float* x = smem;                                     // [MT][ldx]
     float* red = smem + MT * ldx;                        // [NKG][256]
     if (dbg & 4) return;                                 // (calibration of the launch floor, tools/microbench_rows.py)
+    const int pi = (L.n > 1 && (int)blockIdx.x >= L.wg0[1] ? 1 : 0) + (L.n > 2 && (int)blockIdx.x >= L.wg0[2] ? 1 : 0);
+    const es_linear_args& a = L.p[pi];
+    if ((int)blockIdx.y >= L.ny[pi]) return;
+    const int S = L.S[pi], kbps = L.kbps[pi];
+    const int bx = (int)blockIdx.x - L.wg0[pi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.x % S, nt = blockIdx.x / S;
+    const int slice = bx % S, nt = bx / S;
     const int m0 = blockIdx.y * MT;
     const int nkb_total = (a.K + 15) >> 4;
     const int kb0 = slice * kbps, kb1 = slice == S - 1 ? nkb_total : kb0 + kbps;
     const int bz = blockIdx.z;                           // batched launch: z-th problem of identical shape
-    const int nct = gridDim.x / S;
+    const int nct = (a.N + 15) >> 4;
     const f4* wp = (const f4*)a.wpack + ((size_t)bz * nct + nt) * nkb_total * 64;
     f4 acc0 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, q = lane >> 4;
@@ -484,7 +498,11 @@ extern "C" int es_linear_rows_auto_slices(int K, int N, int kalign_cols) {
     return kbps >= nkb ? 0 : kbps;
 }
 
-extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) {
+namespace {
+struct RowsPrep { es_linear_args a; int S, kbps, nsmax, proc, nb; bool has_ln, csr, gepi; };
+
+// validation + normalisation of one problem (op-level prologue -> segments; slice choice)
+int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
     es_linear_args a = *a_in;
     ES_REQUIRE(a.nseg >= 1 && a.nseg <= 3, "es_linear_rows_f32: nseg=%d", a.nseg);
     int ksum = 0;
@@ -545,15 +563,10 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) 
     const int S = es_linear_rows_slices(&a, &kbps);
     ES_REQUIRE(S == 1 || (a.act == ES_ACT_NONE && nb == 1 && a.out_slab_stride >= a.M * a.out_ld),
                "es_linear_rows_f32: a K split (%d slices) needs no activation epilogue, no batching and out_slab_stride >= M * out_ld", S);
-    const int kcmax = kbps * 16 < KCH ? kbps * 16 : KCH;
-    const int ldx = kcmax + 8;
-    const size_t lds = (size_t)(MT * ldx + NWAVE * 256) * sizeof(float);
     int nsmax = 1;
     for (int s = 0; s < a.nseg; ++s) if (a.seg[s].nslab > nsmax) nsmax = a.seg[s].nslab;
     ES_REQUIRE(nsmax <= 8, "es_linear_rows_f32: a segment with %d slabs (max 8)", nsmax);
     ES_REQUIRE(!has_ln || nsmax <= 2, "es_linear_rows_f32: the LayerNorm operand may have at most 2 slabs (%d)", nsmax);
-    dim3 grid((unsigned)(((a.N + 15) / 16) * S), (a.M + MT - 1) / MT, nb);
-    hipStream_t st = (hipStream_t)stream;
     int proc = 0;
     bool csr = false;
     for (int s = 0; s < a.nseg; ++s) {
@@ -562,7 +575,34 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) 
         if (pro == ES_PRO_SILU || pro == ES_PRO_GEGLU) proc = 2;
         csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN || a.seg[s].mode == ES_SEG_CSRSUM;
     }
-    const bool gepi = a.act == ES_ACT_GEGLU;
+    out->a = a; out->S = S; out->kbps = kbps; out->nsmax = nsmax; out->proc = proc; out->nb = nb;
+    out->has_ln = has_ln; out->csr = csr; out->gepi = a.act == ES_ACT_GEGLU;
+    return 0;
+}
+
+int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
+    RowsLaunch L;
+    memset(&L, 0, sizeof(L));
+    int nsmax = 1, proc = 0, kcmax = 16, gx = 0, gy = 1;
+    bool csr = false, has_ln = false, gepi = false;
+    for (int i = 0; i < n; ++i) {
+        L.p[i] = pr[i].a; L.S[i] = pr[i].S; L.kbps[i] = pr[i].kbps;
+        L.wg0[i] = gx;
+        L.ny[i] = (pr[i].a.M + MT - 1) / MT;
+        gx += ((pr[i].a.N + 15) / 16) * pr[i].S;
+        gy = L.ny[i] > gy ? L.ny[i] : gy;
+        nsmax = pr[i].nsmax > nsmax ? pr[i].nsmax : nsmax;
+        proc = pr[i].proc > proc ? pr[i].proc : proc;
+        csr = csr || pr[i].csr; has_ln = has_ln || pr[i].has_ln; gepi = gepi || pr[i].gepi;
+        const int kc = pr[i].kbps * 16 < KCH ? pr[i].kbps * 16 : KCH;
+        kcmax = kc > kcmax ? kc : kcmax;
+    }
+    ES_REQUIRE(n == 1 || (!has_ln && !gepi && pr[0].nb == 1 && pr[1].nb == 1 && (n < 3 || pr[2].nb == 1)),
+               "es_linear_rows_multi_f32: fused problems take no LayerNorm prologue, no GEGLU epilogue and no batching");
+    L.n = n;
+    L.ldx = kcmax + 8;
+    const size_t lds = (size_t)(MT * L.ldx + NWAVE * 256) * sizeof(float);
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)pr[0].nb);
     // kernel table: lean instantiations for what the sampling path launches, one general kernel per slab bound for the rest
     static const void* const k_plain[4][2] = {
         {(const void*)k_linear_rows<1, 0, false, 0, false>, (const void*)k_linear_rows<1, 1, false, 0, false>},
@@ -578,11 +618,11 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) 
     static const void* const k_csr = (const void*)k_linear_rows<1, 0, true, 0, false>;
     const int nsi = nsmax <= 1 ? 0 : nsmax <= 2 ? 1 : nsmax <= 4 ? 2 : 3;
     const void* fn = nullptr;
-    if (has_ln) fn = k_ln[a.K <= 512 ? 0 : 1][nsi];
+    if (has_ln) fn = k_ln[pr[0].a.K <= 512 ? 0 : 1][nsi];
     else if (csr && proc == 0 && nsmax == 1 && !gepi) fn = k_csr;
     else if (!csr && proc <= 1 && !gepi) fn = k_plain[nsi][proc];
     else fn = k_general[nsi];
-    {   // one-off per process, thread-safe: dynamic LDS limit (a 512-column chunk needs 73 KiB)
+    {   // one-off per process, thread-safe: dynamic LDS limit (a 1024-column chunk needs 73 KiB)
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
@@ -598,11 +638,25 @@ extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) 
         ES_REQUIRE(attr_err == hipSuccess, "es_linear_rows_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
     static const char* dbg_env = getenv("ES_ROWS_DBG");          // ablation switches of tools/microbench_rows.py (1: no weight loads, 2: no staging)
-    int dbg = dbg_env ? atoi(dbg_env) : 0;
-    void* kargs[] = {(void*)&a, (void*)&S, (void*)&kbps, (void*)&ldx, (void*)&dbg};
-    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, lds, st));
+    L.dbg = dbg_env ? atoi(dbg_env) : 0;
+    void* kargs[] = {(void*)&L};
+    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, lds, (hipStream_t)stream));
     ES_CHECK_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) {
+    RowsPrep pr;
+    if (int rc = rows_prepare(a_in, &pr)) return rc;
+    return rows_launch(&pr, 1, stream);
+}
+
+extern "C" int es_linear_rows_multi_f32(const es_linear_args* const* args, int n, es_stream stream) {
+    ES_REQUIRE(args && n >= 1 && n <= 3, "es_linear_rows_multi_f32: n=%d (1..3)", n);
+    RowsPrep pr[3];
+    for (int i = 0; i < n; ++i) if (int rc = rows_prepare(args[i], &pr[i])) return rc;
+    return rows_launch(pr, n, stream);
 }
 
 extern "C" int es_row_select(const es_rowsel_args* a, es_stream stream) {

@@ -115,7 +115,9 @@ static int ensure_lane(es_plan* p, int lane) {
 extern "C" int es_plan_run(es_plan* p, es_stream stream) {
     ES_REQUIRE(p != nullptr, "es_plan_run: null plan");
     hipStream_t main = (hipStream_t)stream;
+    int skip = 0;
     for (const es_op& op : p->ops) {
+        if (skip > 0) { --skip; continue; }
         if (op.kind == ES_OP_FORK) {
             ES_REQUIRE(op.lane >= 1, "FORK needs lane >= 1");
             if (int rc = ensure_lane(p, op.lane)) return rc;
@@ -143,6 +145,24 @@ extern "C" int es_plan_run(es_plan* p, es_stream stream) {
                         op.u.linear.prologue, op.u.linear.nseg, op.u.linear.seg[0].mode, op.u.linear.seg[1].mode, op.u.linear.seg[2].mode);
             fprintf(stderr, "\n");
             fflush(stderr);
+        }
+        static const char* fuse_env = getenv("ES_ROWS_FUSE");       // A/B switch: 0 = one launch per product
+        if (op.kind == ES_OP_LINEAR && op.u.linear.fuse_next && !(fuse_env && atoi(fuse_env) == 0)) {
+            // independent row products marked by the planner: one launch for up to 3 of them
+            const es_op* q = &op;
+            const es_linear_args* group[3];
+            int n = 0;
+            while (n < 3 && q < p->ops.data() + p->ops.size() && q->kind == ES_OP_LINEAR && q->lane == op.lane) {
+                group[n++] = &q->u.linear;
+                if (!q->u.linear.fuse_next) break;
+                ++q;
+            }
+            if (n > 1) {
+                if (int rc = es_linear_rows_multi_f32(group, n, s)) return rc;
+                if (dbg) ES_CHECK_HIP(hipStreamSynchronize(s));
+                skip = n - 1;
+                continue;
+            }
         }
         if (int rc = dispatch(op, s)) return rc;
         if (dbg) ES_CHECK_HIP(hipStreamSynchronize(s));

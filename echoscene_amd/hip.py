@@ -37,7 +37,7 @@ class LinearArgs(C.Structure):
                 ('res_ld', C.c_int32), ('res_nslab', C.c_int32), ('res_slab_stride', C.c_int32),
                 ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
                 ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32),
-                ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32)]
+                ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32), ('fuse_next', C.c_int32)]
 
 
 class UpdateArgs(C.Structure):
@@ -128,6 +128,7 @@ EXPORTS = {
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    'es_linear_rows_multi_f32': (C.c_int, [C.POINTER(C.POINTER(LinearArgs)), C.c_int, C.c_void_p]),
     'es_linear_rows_slices': (C.c_int, [C.POINTER(LinearArgs), C.POINTER(C.c_int)]),
     'es_linear_rows_auto_slices': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),

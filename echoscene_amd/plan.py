@@ -247,10 +247,11 @@ class Builder:
         self.ops.append(op)
 
     def linear(self, segs, pl, M, out=None, prologue=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, act=hip.ACT_NONE,
-               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0, split=None):
+               res=None, res2=None, lane=0, use_bias=True, a_bstride=0, out_bstride=0, split=None, fuse_next=False):
         """out = act(prologue(A) @ W^T + b) + res (+ res2).  ``out`` None: the output buffer is allocated here and, when the op
         allows it (no activation epilogue, no batching) and ``split`` is not False, K is split over workgroups -- the returned
-        View is then a slab tensor.  ``split`` = int: k-blocks (16 columns) per slice; True / None: the library's choice."""
+        View is then a slab tensor.  ``split`` = int: k-blocks (16 columns) per slice; True / None: the library's choice.
+        ``fuse_next``: the NEXT linear op emitted is independent of this one -- the runtime launches both as one grid."""
         a = LinearArgs()
         for i, s in enumerate(segs):
             a.seg[i] = s
@@ -292,6 +293,7 @@ class Builder:
             assert out.nslab <= 1
         a.out = out.ptr
         a.out_ld = out.ld
+        a.fuse_next = 1 if (fuse_next and not self.use_lanes) else 0
         op = Op()
         op.kind, op.lane = hip.OP_LINEAR, (lane if self.use_lanes else 0)
         op.u.linear = a
@@ -505,25 +507,29 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
     for li, L in enumerate(gw.layers):
         H, Dout = L['H'], L['Dout']
         W2 = 2 * H + Dp
-        t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
-                       seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T)          # relu deferred
-        t2 = View(b.buf(T, W2))
-        b.linear([seg(t1, pre_act=hip.ACT_RELU)], L['n1b'], T, t2, act=hip.ACT_RELU)
         last = li == n - 1
-        if 'proj' in L:
-            # residual projections depend only on the layer input: side lane 2, joined before the last linear
+        has_proj = 'proj' in L
+        need_newp = has_proj and (not last or want_pred)
+        # net1's first Linear over the gathered triples and the residual projection of the node vectors depend only on the
+        # layer input: ONE launch (fuse_next); likewise net2's first Linear over the pooled messages and the predicate projection.
+        t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
+                       seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, fuse_next=has_proj)      # relu deferred
+        if has_proj:
             b.fork(2)
             proj = b.linear([seg(obj, width=Dobj)], L['proj'], O, lane=2)                     # slab tensor: read as a residual
-            if not last or want_pred:
-                newp = View(b.buf(T, Dp))
-                b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp), lane=2)
         else:
             proj = None
-            newp = View(t2.t, col=H, ld=W2, width=Dp)
+        t2 = View(b.buf(T, W2))
+        b.linear([seg(t1, pre_act=hip.ACT_RELU)], L['n1b'], T, t2, act=hip.ACT_RELU)
         ptr, rows, offs = g.csr(0, H + Dp)
         n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRSUM if getattr(gw, 'pooling', 'avg') == 'sum' else hip.SEG_CSRMEAN,
                            idx=ptr, ent_row=rows, ent_off=offs)],
-                      L['n2a'], O)                                                           # relu deferred
+                      L['n2a'], O, fuse_next=need_newp)                                      # relu deferred
+        if need_newp:
+            newp = View(b.buf(T, Dp))
+            b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp), lane=2)
+        elif not has_proj:
+            newp = View(t2.t, col=H, ld=W2, width=Dp)
         dst = out if (last and out is not None) else View(b.buf(O, Dout))
         if proj is not None:
             b.join(2)
@@ -584,7 +590,7 @@ class UNet1DWeights:
         names += [(f'output_blocks.{i}.{j}', it) for i, blk in enumerate(out) for j, it in enumerate(blk)]
         self.items = {}
         emb_w, emb_b, self.emb_slices, off = [], [], {}, 0
-        ca_v, self.ca = [], {}
+        ca_v, ca_b, self.ca = [], [], {}
         for name, it in names:
             kind = it[0]
             d = {}
@@ -637,8 +643,11 @@ class UNet1DWeights:
                 d['ff2po'] = PackedLinear(torch.cat([Wpo @ Wf2, Wpo], 1).float(),
                                           (Wpo @ sd[tb + '.ff.net.2.bias'].double() + sd[name + '.proj_out.bias'].double()).float(),
                                           device)
+                # cross-attention with ONE key: out = to_out2(to_v2(ctx)) -- linear in ctx, so the two matrices fold into one
+                # [C x ctx_dim] matrix per block (fp64): all blocks' vectors are ONE product per step
                 self.ca[name] = (len(ca_v), it[1])
-                ca_v.append(sd[tb + '.attn2.to_v.weight'])
+                ca_v.append((sd[tb + '.attn2.to_out.0.weight'].double() @ sd[tb + '.attn2.to_v.weight'].double()).float())
+                ca_b.append(sd[tb + '.attn2.to_out.0.bias'])
             elif kind == 'down':
                 d['conv'] = P(name + '.op.weight', name + '.op.bias')
             elif kind == 'up':
@@ -647,12 +656,7 @@ class UNet1DWeights:
         # all ResBlock emb projections / all cross-attention value projections as ONE product each
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
         if not self.concat:
-            self.cav_all = PackedLinear(torch.cat(ca_v, 0), None, device)
-            # the 11 cross-attention output projections have identical shapes -> one batched launch
-            names_ca = list(self.ca.keys())
-            assert len({self.ca[n][1] for n in names_ca}) == 1, 'batched cross-attention projections need equal widths'
-            self.o2_all = PackedLinearBatch([self.items[n]['o2'][0] for n in names_ca],
-                                            [self.items[n]['o2'][1] for n in names_ca], device)
+            self.cav_all = PackedLinear(torch.cat(ca_v, 0), torch.cat(ca_b, 0), device)
         self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
         self.out_conv = P('out.2.weight', 'out.2.bias')
 
@@ -699,15 +703,13 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
         b.tags['emb'] = emb
     cavo = {}
     if not w.concat:
-        # batched per-step side products
+        # the cross-attention vectors of all transformer blocks: one product (folded to_out2 . to_v2 matrices)
         cav = b.buf(O, w.cav_all.N)
         b.linear([seg(ctx)], w.cav_all, O, View(cav))
-        nca = len(w.ca)
-        Cca = next(iter(w.ca.values()))[1]
-        cavo_all = b.buf(nca, O, Cca)
-        b.linear([seg(View(cav, ld=w.cav_all.N, width=Cca))], w.o2_all, O, View(cavo_all.view(nca * O, Cca)),
-                 a_bstride=Cca, out_bstride=O * Cca)
-        cavo = {name: View(cavo_all[k]) for name, (k, _) in w.ca.items()}
+        coff = 0
+        for name, (k, Cc) in w.ca.items():
+            cavo[name] = View(cav, col=coff, ld=w.cav_all.N, width=Cc)
+            coff += Cc
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
     # Every trunk product writes a slab tensor (K split over workgroups) unless its consumer needs whole rows cheaply:

@@ -76,7 +76,7 @@ class UNet3DWeights:
         names += [(f'middle_block.{j}', it) for j, it in enumerate(mid)]
         names += [(f'output_blocks.{i}.{j}', it) for i, blk in enumerate(out) for j, it in enumerate(blk)]
         self.items, self.emb_slices, self.ca = {}, {}, {}
-        emb_w, emb_b, ca_v, off = [], [], [], 0
+        emb_w, emb_b, ca_v, ca_b, off = [], [], [], [], 0
         for name, it in names:
             kind, d = it[0], {}
             if kind == 'conv_in':
@@ -118,15 +118,17 @@ class UNet3DWeights:
                 d['ff1'] = PackedConv(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
                 d['ff2'] = PC(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
                 d['proj_out'] = PackedConv(sd[name + '.proj_out.weight'].flatten(1), sd[name + '.proj_out.bias'], device)
+                # cross-attention with one key: to_out2(to_v2(ctx)) folded into one matrix per block (fp64)
                 self.ca[name] = (len(ca_v), it[1])
-                ca_v.append(sd[tb + '.attn2.to_v.weight'])
+                ca_v.append((sd[tb + '.attn2.to_out.0.weight'].double() @ sd[tb + '.attn2.to_v.weight'].double()).float())
+                ca_b.append(sd[tb + '.attn2.to_out.0.bias'])
             elif kind == 'down':
                 d['conv'] = PC(name + '.op.weight', name + '.op.bias')
             elif kind == 'up':
                 d['conv'] = PC(name + '.conv.weight', name + '.conv.bias')
             self.items[name] = d
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), device)
-        self.cav_all = None if self.concat else PackedLinear(torch.cat(ca_v, 0), None, device)
+        self.cav_all = None if self.concat else PackedLinear(torch.cat(ca_v, 0), torch.cat(ca_b, 0), device)
         self.out_gn = (dv('out.0.weight'), dv('out.0.bias'))
         self.out_conv = PC('out.2.weight', 'out.2.bias')
         self.in_ch, self.out_ch = net.in_channels, net.out_channels
@@ -323,11 +325,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             b.copy(xc[:, 4].data_ptr(), ctx.ptr + lo * ctx.ld * 4, V0 * 4, rows=Ol, dst_pitch=5 * V0 * 4, src_pitch=ctx.ld * 4)
         else:
             cav = b.buf(O, w.cav_all.N)
-            b.linear([seg(ctx)], w.cav_all, O, View(cav))
+            b.linear([seg(ctx)], w.cav_all, O, View(cav))          # all blocks' cross-attention vectors: ONE product
             for name, (k, Cc) in w.ca.items():
-                o = View(b.buf(O, Cc))
-                b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
-                cavo[name] = o
+                cavo[name] = View(cav, col=coff, ld=w.cav_all.N, width=Cc)
                 coff += Cc
     else:
         # No echo message passing (sdfusion-txt2shape.yaml / sdfusion-txt2shape_concat.yaml): objects are independent and
@@ -355,11 +355,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             ctx = View(b.dev(c_dev))
             b.cdev = ctx.t                       # refreshed by the caller for every sample
             cav = b.buf(O, w.cav_all.N)
-            b.linear([seg(ctx)], w.cav_all, O, View(cav))
+            b.linear([seg(ctx)], w.cav_all, O, View(cav))          # all blocks' cross-attention vectors: ONE product
             for name, (k, Cc) in w.ca.items():
-                o = View(b.buf(O, Cc))
-                b.linear([seg(View(cav, col=coff, ld=w.cav_all.N, width=Cc))], w.items[name]['o2'], O, o)
-                cavo[name] = o
+                cavo[name] = View(cav, col=coff, ld=w.cav_all.N, width=Cc)
                 coff += Cc
 
     # ---- side branch: the echo chain (conv-pool stem, 5-layer GCN, cross-attention vectors: ~45 dependent launches of a few
@@ -464,7 +462,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
                 t2 = b.buf(M, Cc)
-                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, row=row0), res=t0, out_f32=t2)
+                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, col=cavo[name].col, ld=cavo[name].ld, width=cavo[name].width, row=row0), res=t0, out_f32=t2)
                 l3 = b.buf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
                 gg = b.buf(M, 4 * Cc, dtype=f16)

@@ -284,7 +284,7 @@ class ShapeDenoiser:
         update.  Returns the graph, or None when the exchange cannot be captured (gloo test backend, an empty shard, eager mode,
         or a capture error) -- the loop then falls back to graph launch / collective / graph launch per step."""
         st = self._cur
-        if st.get('empty') or not self._use_graph or 'stem_plan' not in st:
+        if not self._use_graph or ('stem_plan' not in st and not st.get('empty')):
             return None
         if 'step_graph' in st:
             return st['step_graph']
@@ -294,6 +294,11 @@ class ShapeDenoiser:
             if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
                 return None
             send, recv = st['codes_local'], st['codes_all']
+            if st.get('empty'):
+                # a rank without objects captures nothing, but it must take part in the set-up collective the other ranks
+                # issue below (its loop then runs one eager all-gather per step, matching their captured ones)
+                dist.all_gather_into_tensor(recv, send, group=group)
+                return None
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):

@@ -107,6 +107,10 @@ typedef struct es_linear_args {
      * (K, N) only -- never on M -- so a row's arithmetic does not depend on the batch it is in. */
     int32_t kb_per_slice;
     int32_t out_slab_stride;  /* floats between output slabs (>= M * out_ld)                    */
+    /* plan hint: this op and the NEXT ES_OP_LINEAR of the plan are independent problems (e.g. net1's first Linear and the residual
+     * projection of a GraphTripleConv layer, model/graph.py:146-211) -- the runtime launches them as ONE grid
+     * (es_linear_rows_multi_f32; up to 3 problems), one dependent launch less per pair.  Ignored by es_linear_rows_f32 itself. */
+    int32_t fuse_next;
 } es_linear_args;
 
 /* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
@@ -118,6 +122,8 @@ int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
 int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int K, float* h_out, float* h_bias_out);
 
 int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
+/* n <= 3 independent problems as one launch (same kernel class: no LayerNorm prologue, no GEGLU epilogue, no batching) */
+int es_linear_rows_multi_f32(const es_linear_args* const* args, int n, es_stream stream);
 /* number of slices the launch will run for `args` (and the rounded kb_per_slice) -- the planner sizes the slab buffer with it */
 int es_linear_rows_slices(const es_linear_args* args, int* kb_per_slice);
 /* the library's default kb_per_slice for a [*, K] x [K, N] product whose slices must be multiples of kalign_cols columns
