@@ -72,34 +72,75 @@ __global__ __launch_bounds__(256) void k_gn_partial(const es_gn_args a, float* p
     }
 }
 
-// Pass 2: finalize statistics (fixed order, double), fold them with the affine into per-channel scale/shift in LDS,
-// then y = x*scale + shift (+SiLU/GELU) -> fp16.  Thread (tx, ty): 8 channels at 8*(tx + 32k), voxels ty + 8k:
-// no integer divisions in the streaming loop, 32-B reads / 16-B writes per thread.
-__global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const float* part, int ntiles, int vox_per_block) {
+// Statistics of one object from the per-tile partials: 256/groups slices of the tile list per group, combined in fixed order
+// (deterministic), in double.  Called by every k_gn_apply block when the tile list is short (the UNet: <= 64 tiles per object), or
+// once per object by k_gn_finalize when it is long (the VQ-VAE decoder at 32^3 / 64^3: 512 / 4096 tiles -- re-reducing 1 MB of
+// partials in each of 65536 apply blocks made k_gn_apply 48 % of the decode, 1.28 ms per call).
+__device__ __forceinline__ void gn_reduce_stats(const es_gn_args& a, const float* part, int ntiles, int o, float* smean, float* srstd) {
+    __shared__ double ds[256], dq[256];
+    const int C = a.C1 + a.C2, gs = C / a.groups;
+    const int gi = threadIdx.x % a.groups, sl = threadIdx.x / a.groups, nsl = 256 / a.groups;
+    double s = 0.0, q = 0.0;
+    if (sl < nsl)
+        for (int t = sl; t < ntiles; t += nsl) {
+            const float* p = part + (((long)o * ntiles + t) * a.groups + gi) * 2;
+            s += p[0]; q += p[1];
+        }
+    ds[threadIdx.x] = s; dq[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < a.groups) {
+        s = 0.0; q = 0.0;
+        for (int k = 0; k < nsl; ++k) { s += ds[threadIdx.x + k * a.groups]; q += dq[threadIdx.x + k * a.groups]; }
+        const double n = (double)gs * a.V;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        smean[threadIdx.x] = (float)mean;
+        srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
+// one block per (object, group): 256 threads stride the tile list, fixed-order tree in LDS (deterministic), double accumulation
+__global__ __launch_bounds__(256) void k_gn_finalize(const es_gn_args a, const float* part, int ntiles, float* fin) {
+    __shared__ double ds[256], dq[256];
+    const int o = blockIdx.y, g = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const float* p = part + (((long)o * ntiles + t) * a.groups + g) * 2;
+        s += p[0]; q += p[1];
+    }
+    ds[threadIdx.x] = s; dq[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { ds[threadIdx.x] += ds[threadIdx.x + w]; dq[threadIdx.x] += dq[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int gs = (a.C1 + a.C2) / a.groups;
+        const double n = (double)gs * a.V;
+        const double mean = ds[0] / n;
+        double var = dq[0] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        fin[((long)o * a.groups + g) * 2] = (float)mean;
+        fin[((long)o * a.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
+// Pass 2: statistics (above, or read from `fin`), folded with the affine into per-channel scale/shift in LDS,
+// then y = x*scale + shift (+SiLU/GELU) -> fp16.  Thread (tx, ty): 8 channels at 8*(tx + TX k), voxels ty + TY k, with TX = the
+// number of 8-channel groups rounded up to a power of two (<= 32) -- 64- and 128-channel tensors (VQ-VAE decoder) used a quarter / a
+// half of the lanes with TX fixed at 32.  No integer divisions in the streaming loop, 32-B reads / 16-B writes per thread.
+__global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const float* part, int ntiles, int vox_per_block, const float* fin) {
     __shared__ float smean[64], srstd[64];
     __shared__ float ssc[2048], ssh[2048];
     const int o = blockIdx.y, C = a.C1 + a.C2, gs = C / a.groups;
-    {   // statistics: 256/groups slices of the tile list per group, combined in fixed order (deterministic), in double
-        __shared__ double ds[256], dq[256];
-        const int gi = threadIdx.x % a.groups, sl = threadIdx.x / a.groups, nsl = 256 / a.groups;
-        double s = 0.0, q = 0.0;
-        if (sl < nsl)
-            for (int t = sl; t < ntiles; t += nsl) {
-                const float* p = part + (((long)o * ntiles + t) * a.groups + gi) * 2;
-                s += p[0]; q += p[1];
-            }
-        ds[threadIdx.x] = s; dq[threadIdx.x] = q;
-        __syncthreads();
+    if (fin) {
         if (threadIdx.x < a.groups) {
-            s = 0.0; q = 0.0;
-            for (int k = 0; k < nsl; ++k) { s += ds[threadIdx.x + k * a.groups]; q += dq[threadIdx.x + k * a.groups]; }
-            const double n = (double)gs * a.V;
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            smean[threadIdx.x] = (float)mean;
-            srstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+            smean[threadIdx.x] = fin[((long)o * a.groups + threadIdx.x) * 2];
+            srstd[threadIdx.x] = fin[((long)o * a.groups + threadIdx.x) * 2 + 1];
         }
+    } else {
+        gn_reduce_stats(a, part, ntiles, o, smean, srstd);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -110,14 +151,17 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
     }
     __syncthreads();
     const int c8n = C >> 3;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int lt = 5;                                          // log2(TX)
+    while (lt > 0 && (1 << (lt - 1)) >= c8n) --lt;
+    const int TX = 1 << lt, TY = 256 >> lt;
+    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> lt;
     const int v0 = blockIdx.x * vox_per_block;
-    for (int c8 = tx; c8 < c8n; c8 += 32) {
+    for (int c8 = tx; c8 < c8n; c8 += TX) {
         const int c = c8 * 8;
         const float* src; int ld, cc;
         if (c < a.C1) { src = a.x1; ld = a.C1; cc = c; } else { src = a.x2; ld = a.C2; cc = c - a.C1; }
         const f4 sc0 = *(const f4*)&ssc[c], sc1 = *(const f4*)&ssc[c + 4], sh0 = *(const f4*)&ssh[c], sh1 = *(const f4*)&ssh[c + 4];
-        for (int vl = ty; vl < vox_per_block; vl += 8) {
+        for (int vl = ty; vl < vox_per_block; vl += TY) {
             const int v = v0 + vl;
             if (v >= a.V) break;
             const float* p = src + ((long)o * a.V + v) * ld + cc;
@@ -1455,6 +1499,71 @@ __global__ __launch_bounds__(256) void k_conv_small_n(const es_conv_args a, cons
     }
 }
 
+// LDS-tiled version for volumes whose sides are multiples of 8 (the VQ-VAE's conv_out 64 -> 1 at 64^3): a workgroup owns an
+// 8x8x8 block of output voxels, stages its 10x10x10 halo (out-of-volume voxels as zeros) ONCE -- voxel stride Cin*2 + 16 bytes, which
+// spreads the 16 lanes of a ds_read_b128 group over all 64 banks -- and every thread accumulates 2 outputs with v_dot2_f32_f16
+// (fp32 accumulate).  The direct kernel above re-reads every input voxel 27 times through L2: 5.5 ms per call at 8 x 64^3 x 64
+// channels, 30 % of a scene's VQ-VAE decode.
+__global__ __launch_bounds__(256) void k_conv_small_n_tiled(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Cin = a.Cin, c8n = Cin >> 3, vstride = Cin * 2 + 16;
+    char* xt = smem;                                                   // [10][10][10] voxels x vstride bytes
+    _Float16* wl = (_Float16*)(smem + 1000 * vstride);                 // [N][27][Cin]
+    const int wn = a.N * 27 * Cin;
+    for (int i = threadIdx.x * 8; i < wn; i += 256 * 8) *(h8*)(wl + i) = *(const h8*)((const _Float16*)a.w + i);
+    const int tw = g.W >> 3, th = g.H >> 3, td = g.D >> 3;
+    int t = blockIdx.x;
+    const int bw = t % tw; t /= tw;
+    const int bh = t % th; t /= th;
+    const int bd = t % td;
+    const long o = t / td;
+    const _Float16* A = (const _Float16*)a.a + o * (long)g.D * g.H * g.W * Cin;
+    for (int i = threadIdx.x; i < 1000 * c8n; i += 256) {
+        const int c8 = i % c8n, v = i / c8n;
+        const int lw = v % 10, lh = (v / 10) % 10, ld_ = v / 100;
+        const int iw = bw * 8 + lw - 1, ih = bh * 8 + lh - 1, id = bd * 8 + ld_ - 1;
+        h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (iw >= 0 && iw < g.W && ih >= 0 && ih < g.H && id >= 0 && id < g.D)
+            x = *(const h8*)(A + (((long)id * g.H + ih) * g.W + iw) * Cin + c8 * 8);
+        *(h8*)(xt + v * vstride + c8 * 16) = x;
+    }
+    __syncthreads();
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // thread -> output voxels (lw = tid & 7, lh = (tid >> 3) & 7, ld = tid >> 6 and ld + 4)
+    const int lw = threadIdx.x & 7, lh = (threadIdx.x >> 3) & 7, ld0 = threadIdx.x >> 6;
+    for (int tap = 0; tap < 27; ++tap) {
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const char* p0 = xt + (((ld0 + kd) * 10 + lh + kh) * 10 + lw + kw) * vstride;
+        const char* p1 = p0 + 400 * vstride;                           // ld0 + 4
+        for (int c8 = 0; c8 < c8n; ++c8) {
+            const h8 x0 = *(const h8*)(p0 + c8 * 16), x1 = *(const h8*)(p1 + c8 * 16);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n < a.N) {
+                    const h8 wv = *(const h8*)(wl + (n * 27 + tap) * Cin + c8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const h2v w2 = {wv[2 * e], wv[2 * e + 1]};
+                        acc[0][n] = __builtin_amdgcn_fdot2(h2v{x0[2 * e], x0[2 * e + 1]}, w2, acc[0][n], false);
+                        acc[1][n] = __builtin_amdgcn_fdot2(h2v{x1[2 * e], x1[2 * e + 1]}, w2, acc[1][n], false);
+                    }
+                }
+            }
+        }
+    }
+    const long V = (long)g.D * g.H * g.W;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const long vox = (((long)(bd * 8 + ld0 + 4 * k) * g.H) + bh * 8 + lh) * g.W + bw * 8 + lw;
+        for (int n = 0; n < a.N; ++n) {
+            const float v = acc[k][n] + (a.bias ? a.bias[n] : 0.f);
+            if (ncdhw) a.out_f32[(o * a.N + n) * V + vox] = v;
+            else a.out_f32[(o * V + vox) * a.out_ld + n] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // VQ nearest-codebook lookup (quantizer.py:68-119): d_j = |z|^2 + |e_j|^2 - 2 z.e_j, argmin_j
 // (first minimum), output = lut[argmin] written as channels-last f16 padded to Cpad.  lut is the
@@ -1635,8 +1744,18 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     if (a->N <= 4 && a->taps == 27 && a->Cin <= 64) {
         ES_REQUIRE(a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16,
                    "es_conv_mfma_f16: the N<=4, Cin<=64 direct kernel takes SAME mode, fp32 output, no fusions");
-        hipLaunchKernelGGL(k_conv_small_n, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->N * 27 * a->Cin * 2,
-                           (hipStream_t)stream, *a, g, ncdhw);
+        const size_t lds_t = (size_t)1000 * (a->Cin * 2 + 16) + (size_t)a->N * 27 * a->Cin * 2;
+        if (a->D % 8 == 0 && a->H % 8 == 0 && a->W % 8 == 0 && a->Cin % 8 == 0 && lds_t <= 160 * 1024) {
+            static std::once_flag once_t;
+            static hipError_t attr_t = hipSuccess;
+            std::call_once(once_t, [] { attr_t = hipFuncSetAttribute((const void*)k_conv_small_n_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+            ES_REQUIRE(attr_t == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_t));
+            const unsigned nblk = (unsigned)((long)a->O * (a->D / 8) * (a->H / 8) * (a->W / 8));
+            hipLaunchKernelGGL(k_conv_small_n_tiled, dim3(nblk), dim3(256), lds_t, (hipStream_t)stream, *a, g, ncdhw);
+        } else {
+            hipLaunchKernelGGL(k_conv_small_n, dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)a->N * 27 * a->Cin * 2,
+                               (hipStream_t)stream, *a, g, ncdhw);
+        }
         ES_CHECK_HIP(hipGetLastError());
         return 0;
     }
@@ -1798,7 +1917,16 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
     int vpb = 32;
     while (vpb > 8 && (long)a->O * ((a->V + vpb - 1) / vpb) < 512) vpb >>= 1;
-    hipLaunchKernelGGL(k_gn_apply, dim3((a->V + vpb - 1) / vpb, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, vpb);
+    while (vpb < 1024 && (long)a->O * ((a->V + vpb - 1) / vpb) > 16384) vpb <<= 1;     // (64^3 volumes: fewer, larger blocks)
+    // long tile lists (VQ-VAE decoder at 32^3 / 64^3): the statistics are reduced ONCE per object; the final [O][groups][2] floats
+    // sit behind the partials in the caller's scratch (es_gn_args.stats)
+    const float* fin = nullptr;
+    if (ntiles > 128) {
+        float* f = part + (size_t)a->O * ntiles * a->groups * 2;
+        hipLaunchKernelGGL(k_gn_finalize, dim3(a->groups, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, f);
+        fin = f;
+    }
+    hipLaunchKernelGGL(k_gn_apply, dim3((a->V + vpb - 1) / vpb, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, vpb, fin);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

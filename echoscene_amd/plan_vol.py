@@ -190,7 +190,7 @@ class VolBuilderMixin:
         a.x2, a.C2 = (x2.data_ptr(), C2) if x2 is not None else (None, 0)
         a.O, a.V, a.groups, a.eps = O, V, groups, eps
         a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), int(silu)
-        need = O * ((V + 7) // 8) * groups * 2          # es_groupnorm_vol: scratch for the smallest voxel tile (8)
+        need = O * ((V + 7) // 8) * groups * 2 + O * groups * 2     # es_groupnorm_vol: partials at the smallest voxel tile (8) + final stats
         st = getattr(self, '_gn_stats', None)           # one scratch shared by all GroupNorms (same stream, in order)
         if st is None or st.numel() < need:
             st = self._gn_stats = self.buf(need)

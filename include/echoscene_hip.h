@@ -226,7 +226,7 @@ typedef struct es_gn_args {
     int32_t groups; float eps;
     const float* gamma; const float* beta;   /* [C1+C2]                                         */
     int32_t silu;                    /* 0 none, 1 SiLU, 2 GELU (VQ-VAE norm_out, vqvae_modules.py:404-406) */
-    float* stats;                    /* scratch, O*ceil(V/8)*groups*2 floats (per-tile partials)  */
+    float* stats;                    /* scratch, O*ceil(V/8)*groups*2 + O*groups*2 floats (per-tile partials, final statistics) */
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
     int32_t O_hint;                  /* 0, or the object count of the whole problem (sharding): partial-sum tiling as unsharded */
