@@ -36,7 +36,7 @@ class PackedConv:
             raise ValueError('conv kernel must be 1x1x1 or 3x3x3')
         self.Cin = (cin + 31) // 32 * 32
         L = hip.lib()
-        if self.N <= 4 and self.taps == 27 and self.Cin <= 64:   # consumed by the direct small-N kernel (VQ-VAE conv_out)
+        if self.N <= 4 and self.taps == 27 and self.Cin <= 64:   # consumed by the small-N kernels (VQ-VAE conv_out)
             out = torch.empty(self.N * self.taps * self.Cin, dtype=torch.int16)
             hip.check(L.es_pack_conv_rows_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps,
                                               C.c_void_p(out.data_ptr())), 'es_pack_conv_rows_f16')

@@ -173,7 +173,7 @@ enum { ES_CONV_SAME = 0, ES_CONV_DOWN_HW = 1, ES_CONV_UP_HW = 2, ES_CONV_UP_DHW 
 typedef struct es_conv_args {
     const void* a;            /* f16 [O, D, Hi, Wi, Cin] (channels-last)                         */
     const void* w;            /* f16 weights packed by es_pack_conv_f16 (tiled LDS-image order); for N <= 4,
-                                 Cin <= 64 3x3x3 convs: es_pack_conv_rows_f16 ([N][27][Cin])        */
+                                 Cin <= 64 3x3x3 convs: es_pack_conv_rows_f16 ([N][27][Cin]) -- LDS-tiled dot2 kernel */
     int32_t O, D, H, W;       /* OUTPUT spatial size                                             */
     int32_t Cin, N;           /* N = true number of output channels                              */
     int32_t taps;             /* 27 (3x3x3, pad 1) or 1 (1x1x1 / linear)                         */
