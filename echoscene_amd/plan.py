@@ -512,8 +512,14 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         need_newp = has_proj and (not last or want_pred)
         # net1's first Linear over the gathered triples and the residual projection of the node vectors depend only on the
         # layer input: ONE launch (fuse_next); likewise net2's first Linear over the pooled messages and the predicate projection.
+        # (the triple products have ~4x the rows of the node products, i.e. 4x the workgroups per slice: 2-4 slices instead of the
+        #  8 the (K, N) rule would pick -- the consumer reads S slabs of [T x H]; a planner constant, not a function of M)
+        import os
+        gs_ = int(os.environ.get('ES_ROWS_GCN_SLICES', '2'))         # A/B on one box: 8 -> 1048, 4 -> 1066, 2 -> ~1090 layout steps/s
+        nkb1 = (2 * Dobj + Dp + 15) // 16
         t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
-                       seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, fuse_next=has_proj)      # relu deferred
+                       seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, fuse_next=has_proj,
+                      split=max(8, (nkb1 + gs_ - 1) // gs_) if gs_ > 1 else False)                        # relu deferred
         if has_proj:
             b.fork(2)
             proj = b.linear([seg(obj, width=Dobj)], L['proj'], O, lane=2)                     # slab tensor: read as a residual
@@ -734,10 +740,16 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
+                skip_early = 'skip' in d and os.environ.get('ES_ROWS_SKIP_EARLY', '0') != '0'     # measured -1.1 %: off
                 h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
-                              res=View(emb_all, col=eo, ld=emb_ld, width=cout))
+                              res=View(emb_all, col=eo, ld=emb_ld, width=cout), fuse_next=skip_early)
                 gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
-                if 'skip' in d and len(h_segs) <= 2:
+                if skip_early:
+                    # skip_connection(x) depends only on the block input: it rides on conv1's launch as a second, independent problem
+                    # (one grid), and conv2 shrinks from K = cout + cin to K = cout with the projection as its (slab) residual
+                    resv = b.linear([seg(v) for v in h_segs], d['skip'], O)
+                    o = b.linear(gn2, d['conv2'], O, res=resv)
+                elif 'skip' in d and len(h_segs) <= 2:
                     # out = conv2(silu(GN2(h1))) + skip(x): ONE op over the K-concatenation [h1 | x] with weights [W2 | Wskip],
                     # the norm being the prologue of the first segment only
                     o = b.linear(gn2 + [seg(v) for v in h_segs], d['conv2skip'], O)
