@@ -305,7 +305,8 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
     if (first && a.res && ok_res && !(dbg & 8))
         e_res = load_slabs1(a.res + (long)m_e * a.res_ld + nres, a.res_nslab > 1 ? a.res_nslab : 1, a.res_slab_stride);
-    if (first && a.res2 && ok_res && !(dbg & 8)) e_res2 = a.res2[(long)m_e * a.res2_ld + nres];
+    if (first && a.res2 && ok_res && !(dbg & 8))
+        e_res2 = load_slabs1(a.res2 + (long)m_e * a.res2_ld + nres, a.res2_nslab > 1 ? a.res2_nslab : 1, a.res2_slab_stride);
     if (first && bias && n_e < a.N && !(dbg & 8)) e_bias = bias[n_e];
     const int kg = wave;
 

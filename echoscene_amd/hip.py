@@ -35,7 +35,8 @@ class LinearArgs(C.Structure):
                 ('wpack', C.c_void_p), ('bias', C.c_void_p), ('prologue', C.c_int32), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('eps', C.c_float), ('act', C.c_int32), ('res', C.c_void_p),
                 ('res_ld', C.c_int32), ('res_nslab', C.c_int32), ('res_slab_stride', C.c_int32),
-                ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('out', C.c_void_p),
+                ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('res2_nslab', C.c_int32), ('res2_slab_stride', C.c_int32),
+                ('out', C.c_void_p),
                 ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32),
                 ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32), ('fuse_next', C.c_int32)]
 

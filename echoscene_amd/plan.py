@@ -269,9 +269,9 @@ class Builder:
         a.res = res.ptr if res is not None else None
         a.res_ld = res.ld if res is not None else 0
         a.res_nslab, a.res_slab_stride = (res.nslab, res.slab_stride) if res is not None else (0, 0)
-        assert res2 is None or res2.nslab <= 1
         a.res2 = res2.ptr if res2 is not None else None
         a.res2_ld = res2.ld if res2 is not None else 0
+        a.res2_nslab, a.res2_slab_stride = (res2.nslab, res2.slab_stride) if res2 is not None else (0, 0)
         if out is None:
             Nout = pl.N // 2 if pl.geglu else pl.N
             S, kbps = 1, 0
@@ -710,11 +710,16 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     cavo = {}
     if not w.concat:
         # the cross-attention vectors of all transformer blocks: one product (folded to_out2 . to_v2 matrices)
-        cav = b.buf(O, w.cav_all.N)
-        b.linear([seg(ctx)], w.cav_all, O, View(cav))
+        import os
+        cs_ = int(os.environ.get('ES_ROWS_CAV_SLICES', '1'))
+        if cs_ > 1:
+            cavv = b.linear([seg(ctx)], w.cav_all, O, split=max(8, ((w.cav_all.K + 15) // 16 + cs_ - 1) // cs_))
+        else:
+            cavv = View(b.buf(O, w.cav_all.N))
+            b.linear([seg(ctx)], w.cav_all, O, cavv)
         coff = 0
         for name, (k, Cc) in w.ca.items():
-            cavo[name] = View(cav, col=coff, ld=w.cav_all.N, width=Cc)
+            cavo[name] = cavv.cols(coff, Cc)
             coff += Cc
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
 
@@ -773,8 +778,10 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
                 # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
+                vs_ = int(os.environ.get('ES_ROWS_VO1_SLICES', str(ln_split)))
                 t2 = b.linear([seg(t0, pro=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5, gs=C)], d['vo1'], O,
-                              res=t0, res2=cavo[name], split=ln_kbps(C))
+                              res=t0, res2=cavo[name],
+                              split=(False if vs_ <= 1 else max(8, ((C + 15) // 16 + vs_ - 1) // vs_)))
                 b.tags[name + '.transformer_blocks.0:in'] = t0
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
                 # GEGLU applied in the ff1 epilogue (needs finished sums: one slice, 16 * 4C / 16 column tiles)

@@ -95,6 +95,7 @@ typedef struct es_linear_args {
     int32_t res_nslab, res_slab_stride;   /* the residual may itself be a slab tensor (see es_seg)  */
     const float* res2;        /* optional second residual (cross-attention-with-one-key vector) */
     int32_t res2_ld;
+    int32_t res2_nslab, res2_slab_stride;
     float* out;               /* [M, N]  (ES_ACT_GEGLU: [M, N/2])                              */
     int32_t out_ld;
     /* batched launch (grid.z = nbatch): batch z uses seg[0].ptr + z*a_bstride, the z-th packed weight image
