@@ -283,8 +283,9 @@ class ShapeDenoiser:
         host round trip between its three parts.  The step counter lives on the device and is advanced by the captured DDIM
         update.  Returns the graph, or None when the exchange cannot be captured (gloo test backend, an empty shard, eager mode,
         or a capture error) -- the loop then falls back to graph launch / collective / graph launch per step."""
+        import os
         st = self._cur
-        if not self._use_graph or ('stem_plan' not in st and not st.get('empty')):
+        if not self._use_graph or ('stem_plan' not in st and not st.get('empty')) or os.environ.get('ES_STEP_GRAPH', '1') == '0':
             return None
         if 'step_graph' in st:
             return st['step_graph']

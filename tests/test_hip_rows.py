@@ -366,6 +366,37 @@ def test_linear_split_k_slab_chain_and_rowsel(dev):
     assert torch.equal(out[:, 8:308].cpu(), table[4].cpu().expand(5, 300)) and float(out[:, :8].abs().sum()) == 0.0
 
 
+def test_linear_multi_problem_launch(dev):
+    """Independent products marked ``fuse_next`` run as ONE grid (es_linear_rows_multi_f32): different M / K / N / slice counts, a
+    gathered operand next to a direct one -- results identical to launching them one by one (ES_ROWS_FUSE semantics)."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg
+    rs = np.random.RandomState(21)
+    O, T = 11, 45
+    obj = torch.from_numpy(rs.standard_normal((O, 96)).astype(np.float32))
+    pred = torch.from_numpy(rs.standard_normal((T, 32)).astype(np.float32))
+    si = torch.from_numpy(rs.randint(0, O, T)).long()
+    W1 = torch.from_numpy((rs.standard_normal((80, 128)) / 11).astype(np.float32))
+    W2 = torch.from_numpy((rs.standard_normal((48, 96)) / 10).astype(np.float32))
+    W3 = torch.from_numpy((rs.standard_normal((32, 32)) / 6).astype(np.float32))
+    R = torch.from_numpy(rs.standard_normal((T, 32)).astype(np.float32))
+    outs = []
+    for fuse in (True, False):
+        b = Builder(dev)
+        o_, p_, s_ = b.dev(obj), b.dev(pred), b.dev(si, torch.int32)
+        a1 = b.linear([seg(View(o_), hip.SEG_GATHER, idx=s_, width=96), seg(View(p_))], PackedLinear(W1, None, dev), T, fuse_next=fuse)
+        a2 = b.linear([seg(View(o_))], PackedLinear(W2, torch.ones(48), dev), O, fuse_next=fuse)
+        a3 = b.linear([seg(View(p_))], PackedLinear(W3, None, dev), T, res=View(b.dev(R)))
+        b.finish().run()
+        torch.cuda.synchronize()
+        outs.append([a1.value().cpu(), a2.value().cpu(), a3.value().cpu()])
+    _close(outs[0][0], F.linear(torch.cat([obj[si], pred], 1), W1), 2e-5)
+    _close(outs[0][1], F.linear(obj, W2) + 1.0, 2e-5)
+    _close(outs[0][2], F.linear(pred, W3) + R, 2e-5)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+
+
 def test_plan_reuse_across_scene_graphs(dev):
     """eval_3dfront.py visits a different scene graph on every call: plans are cached by (node count, triple-row capacity)
     and a new graph of the same size class only rewrites index arrays in place -- same plan object, same captured hipGraph,
