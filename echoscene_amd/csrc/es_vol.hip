@@ -243,58 +243,73 @@ __global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int
 //   stage 1: Conv3d(3|4->32,k3,p1) @16^3 then MaxPool3d(2,2)  -> [O,32,8,8,8]   (4 input channels: 'concat' family)
 //   stage 2: Conv3d(32->64,k3,p1) @8^3 then MaxPool3d(k=2,s=4) -> [O,64,2,2,2] -> flatten(512)
 // ---------------------------------------------------------------------------------------------
-// One workgroup per (object, pooled depth pd): the 4 input depth slices 2pd-1 .. 2pd+2 (zero halo) sit in LDS with a
-// one-voxel border, the 32 x Cx x 27 weights too; thread (c = tid / 8, 8 threads per channel) produces 8 of the 64
-// pooled (ph, pw) outputs of channel c.  (The first version read every tap from global: 648 dependent loads per thread,
-// 220 us per step at O = 32; this one ~15 us.)
+// One workgroup per (object, pooled depth pd, pooled row ph): the 4 x 4 input (depth slice, row) lines 2pd-1 .. 2pd+2 x 2ph-1 .. 2ph+2
+// (zero halo) sit in LDS with a one-voxel border, the 32 x Cx x 27 weights too; thread (c = tid / 8, pw = tid & 7) produces ONE pooled
+// output of channel c (8 conv voxels x Cx x 27 taps).  (History: every tap from global: 220 us per step at O = 32; one workgroup per
+// (object, pd) with 8 pooled outputs per thread: ~120 us whatever O -- hidden on the side branch of the single-GPU step, but on the
+// critical path in front of the all-gather of a sharded step, where 4 objects gave only 32 workgroups.)
 __global__ __launch_bounds__(256) void k_stem1(const es_stem_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Cx = a.Cin ? a.Cin : 3;
-    float* xs = (float*)smem;                    // [Cx][4 slices][18][18]
-    float* ws = xs + Cx * 4 * 324;               // [32][Cx*27]
-    const int o = blockIdx.y, pd = blockIdx.x, tid = threadIdx.x;
+    float* xs = (float*)smem;                    // [Cx][4 slices][4 rows][18]
+    float* ws = xs + Cx * 4 * 4 * 18;            // [32][Cx*27]
+    const int o = blockIdx.y, pd = blockIdx.x >> 3, ph = blockIdx.x & 7, tid = threadIdx.x;
     const float* x = a.x + (long)o * (a.x_ostride ? a.x_ostride : Cx * 4096);
-    for (int i = tid; i < Cx * 4 * 324; i += 256) {
-        const int ww = i % 18, hh = (i / 18) % 18, sl = (i / 324) & 3, ci = i / 1296;
-        const int d = 2 * pd - 1 + sl, h = hh - 1, w = ww - 1;
+    for (int i = tid; i < Cx * 288; i += 256) {
+        const int ww = i % 18, rr = (i / 18) & 3, sl = (i / 72) & 3, ci = i / 288;
+        const int d = 2 * pd - 1 + sl, h = 2 * ph - 1 + rr, w = ww - 1;
         xs[i] = (d >= 0 && d < 16 && h >= 0 && h < 16 && w >= 0 && w < 16) ? x[ci * 4096 + d * 256 + h * 16 + w] : 0.f;
     }
     for (int i = tid; i < 32 * Cx * 27; i += 256) ws[i] = a.w0[i];
     __syncthreads();
-    const int c = tid >> 3, sub = tid & 7;       // channel, and which 8 of the 64 (ph, pw) positions
+    const int c = tid >> 3, pw = tid & 7;
     const float* w = ws + c * Cx * 27;
     const float bias = a.b0[c];
-    for (int k = 0; k < 8; ++k) {
-        const int pp = sub * 8 + k, ph = pp >> 3, pw = pp & 7;
-        float best = -INFINITY;
-        for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
-            // conv output voxel (2pd+dz, 2ph+dy, 2pw+dx); LDS coordinates: slice dz+kd, row 2ph+dy+kh, col 2pw+dx+kw
-            float sacc = bias;
-            for (int ci = 0; ci < Cx; ++ci)
+    float best = -INFINITY;
+    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx) {
+        // conv output voxel (2pd+dz, 2ph+dy, 2pw+dx); LDS coordinates: slice dz+kd, row dy+kh, col 2pw+dx+kw.  Same summation order as
+        // before (bias first, then ci, kd, kh, kw), so the result is bit-identical to the previous kernel.
+        float sacc = bias;
+        for (int ci = 0; ci < Cx; ++ci)
 #pragma unroll
-                for (int kd = 0; kd < 3; ++kd)
+            for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw)
-                            sacc += xs[((ci * 4 + dz + kd) * 18 + 2 * ph + dy + kh) * 18 + 2 * pw + dx + kw] * w[ci * 27 + kd * 9 + kh * 3 + kw];
-            best = fmaxf(best, sacc);
-        }
-        a.scratch[(((long)o * 32 + c) * 8 + pd) * 64 + ph * 8 + pw] = best;
+                    for (int kw = 0; kw < 3; ++kw)
+                        sacc += xs[((ci * 4 + dz + kd) * 4 + dy + kh) * 18 + 2 * pw + dx + kw] * w[ci * 27 + kd * 9 + kh * 3 + kw];
+        best = fmaxf(best, sacc);
     }
+    a.scratch[(((long)o * 32 + c) * 8 + pd) * 64 + ph * 8 + pw] = best;
 }
 
 __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
     // 8 lanes per output [o][c=64][2][2][2] (each lane 4 of the 32 input channels, all 8 window positions);
-    // pooling windows start at 0 and 4 (kernel 2, stride 4)
+    // pooling windows start at 0 and 4 (kernel 2, stride 4).  A workgroup = 32 consecutive outputs = 4 channels of ONE object: the
+    // object's pooled stage-1 map [32][8][8][8] (64 KB) is staged in LDS once -- the first version issued its 864 loads per thread
+    // against global memory (50 us per step whatever O).  Same arithmetic and summation order.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                    // [32][513]: channel stride 513 -> the 8 lanes of an output (4 channels apart) hit 8 banks
     const long n = (long)a.O * 512;
     const long gi = ((long)blockIdx.x * 256 + threadIdx.x);
     const long i = gi >> 3;
     const int sl = (int)(gi & 7);
+    const long o = ((long)blockIdx.x * 32) >> 9;          // object of this workgroup
+    {
+        const f4* src = (const f4*)(a.scratch + o * 32 * 512);
+        f4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[threadIdx.x + 256 * u];       // 16 loads in flight per thread
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = (threadIdx.x + 256 * u) * 4, ci = e >> 9, off = e & 511;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[ci * 513 + off + q] = v[u][q];
+        }
+    }
+    __syncthreads();
     if (i >= n) return;
     const int pw = i & 1, ph = (i >> 1) & 1, pd = (i >> 2) & 1, c = (i >> 3) & 63;
-    const long o = i >> 9;
-    const float* x = a.scratch + o * 32 * 512;
     const float* w = a.w1 + c * 32 * 27;
     float s[8];
 #pragma unroll
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(256) void k_stem2(const es_stem_args a) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int id = 4 * pd + (k >> 2) + kd - 1, ih = 4 * ph + ((k >> 1) & 1) + kh - 1, iw = 4 * pw + (k & 1) + kw - 1;
-                if (id >= 0 && id < 8 && ih >= 0 && ih < 8 && iw >= 0 && iw < 8) s[k] += x[ci * 512 + id * 64 + ih * 8 + iw] * wv;
+                if (id >= 0 && id < 8 && ih >= 0 && ih < 8 && iw >= 0 && iw < 8) s[k] += xs[ci * 513 + id * 64 + ih * 8 + iw] * wv;
             }
         }
     }
@@ -1975,8 +1990,14 @@ extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
     const int Cx = a->Cin ? a->Cin : 3;
     ES_REQUIRE(Cx >= 1 && Cx <= 4, "es_shape_stem: Cin=%d (3 or 4)", Cx);
     (void)n1;
-    hipLaunchKernelGGL(k_stem1, dim3(8, a->O), dim3(256), (size_t)(Cx * 4 * 324 + 32 * Cx * 27) * 4, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(k_stem1, dim3(64, a->O), dim3(256), (size_t)(Cx * 288 + 32 * Cx * 27) * 4, (hipStream_t)stream, *a);
+    {
+        static std::once_flag once_s;
+        static hipError_t attr_s = hipSuccess;
+        std::call_once(once_s, [] { attr_s = hipFuncSetAttribute((const void*)k_stem2, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 513 * 4); });
+        ES_REQUIRE(attr_s == hipSuccess, "es_shape_stem: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_s));
+    }
+    hipLaunchKernelGGL(k_stem2, dim3((unsigned)((n2 * 8 + 255) / 256)), dim3(256), 32 * 513 * 4, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
