@@ -54,6 +54,61 @@ def test_struct_sizes_match_header(L, tmp_path):
         assert sizes[n] == C.sizeof(cls), '%s: C %d vs ctypes %d' % (n, sizes[n], C.sizeof(cls))
 
 
+def test_rows_slice_choice_depends_on_k_and_n_only(L):
+    """Host logic of the split-K rows launches (no device work): the default slice width is a function of (K, N) -- never of M,
+    so a row's arithmetic does not depend on the batch it is in -- slices are whole multiples of the GroupNorm group, a LayerNorm /
+    activation epilogue refuses a split, and es_linear_rows_slices reports the slab count the planner must allocate."""
+    from echoscene_amd import hip
+    assert L.es_linear_rows_auto_slices(512, 512, 16) == 8          # 32 k-blocks, 32 column tiles -> 4 slices of 8 k-blocks
+    assert L.es_linear_rows_auto_slices(1024, 512, 32) == 16        # slices of 256 columns = 8 GroupNorm groups of 32
+    assert L.es_linear_rows_auto_slices(512, 4096, 16) == 0         # 256 column tiles already: no split
+    assert L.es_linear_rows_auto_slices(64, 512, 16) == 0           # a slice is at least 128 columns
+    a = hip.LinearArgs()
+    a.nseg, a.K, a.N = 1, 1536, 512
+    a.seg[0].width = 1536
+    got = C.c_int(0)
+    for M in (1, 32, 2048):
+        a.M = M
+        a.kb_per_slice = L.es_linear_rows_auto_slices(a.K, a.N, 16)
+        assert L.es_linear_rows_slices(C.byref(a), C.byref(got)) == 4 and got.value == 24
+    a.kb_per_slice = 7
+    a.seg[0].pro, a.seg[0].gs = hip.PRO_GN_SILU, 32               # groups of 32 channels = 2 k-blocks: 7 -> 8
+    assert L.es_linear_rows_slices(C.byref(a), C.byref(got)) == 12 and got.value == 8
+    a.kb_per_slice = 0
+    assert L.es_linear_rows_slices(C.byref(a), C.byref(got)) == 1 and got.value == 96
+
+
+def test_op_pointer_table_covers_every_pointer_field(L):
+    """Model files relocate the device pointers of an op through es_op_pointer_offsets: the table must list exactly the c_void_p
+    fields of the op's argument struct (ctypes mirror), or a saved plan would keep a stale address."""
+    from echoscene_amd import hip
+
+    def ptr_offsets(struct, base=0):
+        out = []
+        for name, typ in struct._fields_:
+            off = base + getattr(struct, name).offset
+            if typ is C.c_void_p:
+                out.append(off)
+            elif isinstance(typ, type) and issubclass(typ, C.Array) and issubclass(typ._type_, C.Structure):
+                for k in range(typ._length_):
+                    out += ptr_offsets(typ._type_, off + k * C.sizeof(typ._type_))
+            elif isinstance(typ, type) and issubclass(typ, C.Structure):
+                out += ptr_offsets(typ, off)
+        return out
+
+    u_off = hip.Op.u.offset
+    kinds = {hip.OP_LINEAR: hip.LinearArgs, hip.OP_DDPM: hip.UpdateArgs, hip.OP_DDIM: hip.UpdateArgs, hip.OP_COPY: hip.CopyArgs,
+             hip.OP_CONV: hip.ConvArgs, hip.OP_GN: hip.GNArgs, hip.OP_LN: hip.LNArgs, hip.OP_ATTN: hip.AttnArgs,
+             hip.OP_GEGLU: hip.GegluArgs, hip.OP_TO_CL: hip.ToClArgs, hip.OP_STEM: hip.StemArgs, hip.OP_VQ: hip.VQArgs,
+             hip.OP_ROWSEL: hip.RowSelArgs}
+    buf = (C.c_size_t * 64)()
+    for kind, struct in kinds.items():
+        n = L.es_op_pointer_offsets(kind, buf, 64)
+        assert n >= 0
+        assert sorted(buf[i] for i in range(n)) == sorted(u_off + o for o in ptr_offsets(struct)), (kind, struct.__name__)
+    assert L.es_op_pointer_offsets(hip.OP_FORK, buf, 64) == 0 and L.es_op_pointer_offsets(99, buf, 64) == -1
+
+
 def test_pack_linear_layout(L):
     rs = np.random.RandomState(0)
     N, K = 21, 38
