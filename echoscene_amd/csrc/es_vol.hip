@@ -1614,15 +1614,32 @@ __global__ __launch_bounds__(256) void k_vq_lookup(const es_vq_args a) {
 
 
 // split-K reduction + epilogue: out = sum_z part[z] (fixed order) + bias + rowvec + res
+// The S slab loads of an element are independent: they are issued four at a time and added in slab order (with the slab count
+// only known at run time the plain loop waited for one load after the other -- 8-16 dependent round trips at the 16x4x4 level).
 __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a, long M, int V, int S) {
     const long n4 = M * (a.N >> 2);
     const int N4 = a.N >> 2;
+    const long MN = M * a.N;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long m = i / N4;
         const int n = (int)(i - m * N4) * 4;
         const float* p = (const float*)a.workspace + m * a.N + n;
         f4 v = *(const f4*)p;
-        for (int z = 1; z < S; ++z) v += *(const f4*)(p + (long)z * M * a.N);
+        int z = 1;
+        for (; z + 3 < S; z += 4) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN),
+                     t2 = *(const f4*)(p + (long)(z + 2) * MN), t3 = *(const f4*)(p + (long)(z + 3) * MN);
+            v += t0; v += t1; v += t2; v += t3;
+        }
+        if (z + 2 < S) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN), t2 = *(const f4*)(p + (long)(z + 2) * MN);
+            v += t0; v += t1; v += t2;
+        } else if (z + 1 < S) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN);
+            v += t0; v += t1;
+        } else if (z < S) {
+            v += *(const f4*)(p + (long)z * MN);
+        }
         if (a.bias) v += *(const f4*)&a.bias[n];
         if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
         if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
