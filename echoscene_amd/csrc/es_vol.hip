@@ -412,7 +412,8 @@ __device__ __forceinline__ void conv_tile_of(const es_conv_args& a, int& bx, int
 // all in flight (fully unrolled the epilogue spilled 100 registers there and cost more than the K loop gained).
 // EPI_: -1 = a.epilogue decides at run time (general kernels); ES_EPI_NONE / ES_EPI_GEGLU = compiled for that epilogue only
 // (k_conv_ws: with both paths in one function the register allocator spilled 150-250 dwords at the 168-register cap).
-template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false, int EPI_ = -1, bool NOSYNC = false>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
+// STATS_ (LOWREG only): besides storing the tile, form the row-group sums of es_conv_args.gn_stats_out from the stored values.
+template <int BM_, int NW_, bool ACTIVE = true, bool LOWREG = false, int EPI_ = -1, bool NOSYNC = false, bool STATS_ = false>      // ACTIVE = false: a producer wave of k_conv_ws, joins the barriers only
 __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvGeom& g, f4 (&acc)[BM_ / (NW_ / 2) / 16][7],
                                               char* smem, long M, long m0, int n0, int wave, int lane, int S, int bz,
                                               int ncdhw) {
@@ -515,6 +516,7 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                     if (use_res && n_ok && r < rows_left) rr[t] = *(const f4*)&a.res[off0 + (unsigned)(i * 16 + 2 * t) * ld];
                 }
             };
+            f4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};          // STATS_: this lane's rows (rsub, rsub + 2, ...) of the wave's 64-row group
             auto combine = [&](int i, const f4 (&rr)[8]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
@@ -532,6 +534,11 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                             if (a.out_f16) {
                                 h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                                 *(h4*)((_Float16*)a.out_f16 + off) = hv;
+                            }
+                            if constexpr (STATS_) {
+                                gs += v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) gq[e] = fmaf(v[e], v[e], gq[e]);
                             }
                         }
                     }
@@ -555,6 +562,20 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                 __builtin_amdgcn_sched_barrier(0);
                 if (i == 0 && MI > 1) load_res(1, rbuf[1]);                            // behind slab 1's LDS writes
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (STATS_) {
+                // One (sum, sum of squares) pair per column for the wave's 64 rows: the even rows were summed top to bottom by lanes
+                // 0..27, the odd rows by lanes 28..55; even + odd is the order k_rowgroup_stats repeats.
+                static_assert(WROWS == 64, "row groups of gn_stats_out are 64 rows");
+                f4 os, oq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { os[e] = __shfl(gs[e], lane + 28); oq[e] = __shfl(gq[e], lane + 28); }
+                if (lane < 28 && n_ok && rows_left > 0) {
+                    const unsigned nrg = (unsigned)((M + 63) >> 6);
+                    const unsigned so = (unsigned)(mw0 >> 6) * (unsigned)a.N + (unsigned)n;
+                    *(f4*)&a.gn_stats_out[so] = gs + os;
+                    *(f4*)&a.gn_stats_out[so + nrg * (unsigned)a.N] = gq + oq;
+                }
             }
         }
         return;
@@ -896,7 +917,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define ES_STAMP_AT(k) do { } while (0)
 #endif
 
-template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE>
+template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool STATS_ = false>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
     constexpr int NS = 3, UPS_ = 1;                               // ring depth; K units per barrier
     constexpr int WROWS = BM_ / (NC_ / 2);
@@ -1055,7 +1076,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         }
         ES_STAMP_AT(3);
         f4 dummy[MI][7];
-        conv_epilogue<BM_, NC_, false, true, EPI_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+        conv_epilogue<BM_, NC_, false, true, EPI_, false, STATS_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
         ES_STAMP_AT(4);
         return;
     }
@@ -1117,7 +1138,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         ws_mma<MI>(acc, af, bfr);                                               // last unit
     }
     ES_STAMP_AT(3);
-    conv_epilogue<BM_, NC_, true, true, EPI_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
+    conv_epilogue<BM_, NC_, true, true, EPI_, false, STATS_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
     ES_STAMP_AT(4);
 }
 
@@ -1651,6 +1672,67 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a
     }
 }
 
+// Row-group sums of es_conv_args.gn_stats_out for the routes whose epilogue does not form them (64- / 128-row tiles, k_linear_ws,
+// split K): one thread per (64-row group, column quad), the summation order of conv_epilogue<STATS_> -- the even rows of the group
+// top to bottom, the odd rows top to bottom, then the two halves -- so that every route leaves the same bits.
+__global__ __launch_bounds__(256) void k_rowgroup_stats(const float* x, long M, int N, int ld, float* st) {
+    const int N4 = N >> 2;
+    const long nrg = (M + 63) >> 6;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nrg * N4; i += (long)gridDim.x * 256) {
+        const long rg = i / N4;
+        const int n = (int)(i - rg * N4) * 4;
+        const float* p = x + rg * 64 * ld + n;
+        const int nv = (int)((M - rg * 64) < 64 ? (M - rg * 64) : 64);
+        f4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, q[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            f4 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = r0 + r < nv ? *(const f4*)(p + (long)(r0 + r) * ld) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r0 + r < nv) {
+                    s[r & 1] += v[r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[r & 1][e] = fmaf(v[r][e], v[r][e], q[r & 1][e]);
+                }
+        }
+        *(f4*)&st[rg * N + n] = s[0] + s[1];
+        *(f4*)&st[(nrg + rg) * N + n] = q[0] + q[1];
+    }
+}
+
+// (object, group) statistics from the producers' row-group sums (es_gn_args.stats1 / stats2): V/64 row groups x channels-per-group
+// values per block, double accumulation, fixed-order tree -- independent of how many objects the launch holds.
+__global__ __launch_bounds__(256) void k_gn_finalize_rg(const es_gn_args a, float* fin) {
+    __shared__ double ds[256], dq[256];
+    const int o = blockIdx.y, g = blockIdx.x;
+    const int C = a.C1 + a.C2, gs = C / a.groups, nrgo = a.V >> 6;
+    const long nrg = (long)a.O * nrgo;
+    double s = 0.0, q = 0.0;
+    for (int e = threadIdx.x; e < nrgo * gs; e += 256) {
+        const int rgi = e / gs, c = g * gs + (e - rgi * gs);
+        const float* st; int Cs, cc;
+        if (c < a.C1) { st = a.stats1; Cs = a.C1; cc = c; } else { st = a.stats2; Cs = a.C2; cc = c - a.C1; }
+        const long idx = ((long)o * nrgo + rgi) * Cs + cc;
+        s += st[idx];
+        q += st[nrg * Cs + idx];
+    }
+    ds[threadIdx.x] = s; dq[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { ds[threadIdx.x] += ds[threadIdx.x + w]; dq[threadIdx.x] += dq[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)gs * a.V;
+        const double mean = ds[0] / n;
+        double var = dq[0] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        fin[((long)o * a.groups + g) * 2] = (float)mean;
+        fin[((long)o * a.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
 int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -1716,7 +1798,8 @@ extern "C" int es_pack_conv_rows_f16(const float* h_w, int N, int CinW, int taps
     return 0;
 }
 
-extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
+// emits != nullptr: dry run -- report whether this launch would form gn_stats_out in its epilogue, launch nothing
+static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     ES_REQUIRE(a->Cin % 32 == 0 && a->Cin > 0, "es_conv_mfma_f16: Cin=%d must be a positive multiple of 32", a->Cin);
     ES_REQUIRE(a->taps == 27 || a->taps == 1, "es_conv_mfma_f16: taps=%d", a->taps);
     ES_REQUIRE(!a->a2 || (a->Cin2 % 32 == 0 && a->Cin2 > 0), "es_conv_mfma_f16: Cin2=%d", a->Cin2);
@@ -1750,6 +1833,7 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         if (per_obj_in2 > 0) omax = std::min(omax, lim / per_obj_in2);
         ES_REQUIRE(omax >= 1, "es_conv_mfma_f16: one object exceeds 2 GiB of input (%ld bytes)", per_obj_in);
         if (omax < a->O) {
+            if (emits) { *emits = 0; return 0; }
             const long V = (long)a->D * a->H * a->W;
             for (long o0 = 0; o0 < a->O; o0 += omax) {
                 es_conv_args c = *a;
@@ -1765,7 +1849,15 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
                     if (a->out_f32) c.out_f32 = a->out_f32 + o0 * V * a->out_ld;
                     if (a->out_f16) c.out_f16 = (char*)a->out_f16 + o0 * V * a->out_ld * 2;
                 }
-                if (int rc = es_conv_mfma_f16(&c, stream)) return rc;
+                c.gn_stats_out = nullptr;                  // (the planes are laid out for the whole tensor: one pass below)
+                if (int rc = conv_dispatch(&c, stream, nullptr)) return rc;
+            }
+            if (a->gn_stats_out) {
+                ES_REQUIRE(a->out_f32 && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && V % 64 == 0, "es_conv_mfma_f16: gn_stats_out needs a channels-last fp32 output");
+                const long Mt = (long)a->O * V, n4 = ((Mt + 63) / 64) * (a->N / 4);
+                const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+                hipLaunchKernelGGL(k_rowgroup_stats, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)a->out_f32, Mt, a->N, a->out_ld, a->gn_stats_out);
+                ES_CHECK_HIP(hipGetLastError());
             }
             return 0;
         }
@@ -1774,7 +1866,8 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     // inputs (UNet eps conv 224 -> 3) go through the MFMA tile: 98 % column padding, but the direct kernel's 756
     // dependent 16-B loads per voxel cost 2.4x (O=32) to 10x (O=4) more than the padded tile.
     if (a->N <= 4 && a->taps == 27 && a->Cin <= 64) {
-        ES_REQUIRE(a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16,
+        if (emits) { *emits = 0; return 0; }
+        ES_REQUIRE(a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec && !a->out_f16 && !a->gn_stats_out,
                    "es_conv_mfma_f16: the N<=4, Cin<=64 direct kernel takes SAME mode, fp32 output, no fusions");
         const size_t lds_t = (size_t)1000 * (a->Cin * 2 + 16) + (size_t)a->N * 27 * a->Cin * 2;
         if (a->D % 8 == 0 && a->H % 8 == 0 && a->W % 8 == 0 && a->Cin % 8 == 0 && lds_t <= 160 * 1024) {
@@ -1802,29 +1895,12 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
     const int nks = a->taps * (a->Cin / 32) + (a->a2 ? a->Cin2 / 32 : 0);
     constexpr int LDS256 = 3 * (256 * BK * 2 + BNP * BK * 2), LDS128 = 3 * (128 * BK * 2 + BNP * BK * 2),
                   LDS64 = 3 * (64 * BK * 2 + BNP * BK * 2);
-    {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
-        static std::once_flag once;
-        static hipError_t attr_err = hipSuccess;
-        std::call_once(once, [] {
-            auto set = [](const void* f, int bytes) {
-                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-                if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
-            };
-            set((const void*)k_conv_lean<256, 8>, LDS256);
-            set((const void*)k_conv_lean<128, 4>, LDS128);
-            set((const void*)k_conv_lean<64, 4>, LDS64);
-            set((const void*)k_conv_lean<256, 8, true>, LDS256);
-            set((const void*)k_conv_lean<128, 4, true>, LDS128);
-            set((const void*)k_conv_lean<64, 4, true>, LDS64);
-            set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
-            set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
-            set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
-        });
-        ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
-    }
     hipStream_t st = (hipStream_t)stream;
+    const bool want_stats = a->gn_stats_out != nullptr;
+    bool stats_done = false;
+    ES_REQUIRE(!want_stats || (a->out_f32 && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (a->D * a->H * a->W) % 64 == 0 &&
+                               a->epilogue == ES_EPI_NONE),
+               "es_conv_mfma_f16: gn_stats_out needs a channels-last fp32 output, N %% 4 == 0 and voxels per object %% 64 == 0");
     int S = a->splitk;
     const bool can_split = a->workspace && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0);
     if (S < 0) {                                           // auto
@@ -1895,16 +1971,46 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    if ((wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split) {
+    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
+    static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
+    int ncb = 1;
+    if (route256 && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
+        static const int cand[5] = {8, 6, 4, 3, 2};
+        for (int k = 0; k < 5; ++k)
+            if (ntn % cand[k] == 0 && ((M + 255) / 256) * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
+    }
+    // the producer/consumer 256-row kernel forms the row-group sums of gn_stats_out in its epilogue; every other route runs
+    // k_rowgroup_stats over the finished output
+    const bool epi_stats = route256 && ncb == 1 && ws && !geglu && S == 1 && a->out_f32 && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
+                           (a->D * a->H * a->W) % 64 == 0;
+    if (emits) { *emits = epi_stats ? 1 : 0; return 0; }
+    {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            auto set = [](const void* f, int bytes) {
+                const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+            };
+            set((const void*)k_conv_lean<256, 8>, LDS256);
+            set((const void*)k_conv_lean<128, 4>, LDS128);
+            set((const void*)k_conv_lean<64, 4>, LDS64);
+            set((const void*)k_conv_lean<256, 8, true>, LDS256);
+            set((const void*)k_conv_lean<128, 4, true>, LDS128);
+            set((const void*)k_conv_lean<64, 4, true>, LDS64);
+            set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, LDS256);
+            set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
+            set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
+            set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
+        });
+        ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    }
+    if (route256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
-        // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
-        static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
-        int ncb = 1;
-        if (ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
-            static const int cand[5] = {8, 6, 4, 3, 2};
-            for (int k = 0; k < 5; ++k)
-                if (ntn % cand[k] == 0 && (long)grid.x * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
-        }
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
             constexpr int LDSLIN = LDS256 + 8 * 16 * 116 * 4;
@@ -1912,6 +2018,11 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
             else hipLaunchKernelGGL((k_linear_ws<ES_EPI_NONE>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
         } else if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            else if (want_stats && epi_stats) {       // row-group sums for the next GroupNorm from the epilogue's own values
+                if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+                else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+                stats_done = true;
+            }
             else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
             else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
         }
@@ -1931,8 +2042,23 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) {
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
     }
+    if (want_stats && !stats_done) {
+        const long n4 = ((M + 63) / 64) * (a->N / 4);
+        const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(k_rowgroup_stats, dim3(blocks), dim3(256), 0, st, (const float*)a->out_f32, M, a->N, a->out_ld, a->gn_stats_out);
+    }
     ES_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) { return conv_dispatch(a, stream, nullptr); }
+
+// 1 when es_conv_mfma_f16(args) would form gn_stats_out inside its own epilogue (the planner only asks a conv for the sums then:
+// behind any other route they would cost a pass over the output, i.e. what the GroupNorm's own statistics pass costs), 0 when
+// not, -1 on invalid arguments.  Host-only: launches nothing.
+extern "C" int es_conv_emits_gn_stats(const es_conv_args* a) {
+    int e = 0;
+    return conv_dispatch(a, nullptr, &e) == 0 ? e : -1;
 }
 
 extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
@@ -1946,14 +2072,19 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     while (vt > 8 && Oh * ((a->V + vt - 1) / vt) < 512) vt >>= 1;
     const int ntiles = (a->V + vt - 1) / vt;
     float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats
-    hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
+    static const char* rg_env = getenv("ES_GN_RG");            // A/B switch: 0 = always the statistics pass over x
+    const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && !(rg_env && atoi(rg_env) == 0);
+    if (!from_rg) hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
     int vpb = 32;
     while (vpb > 8 && (long)a->O * ((a->V + vpb - 1) / vpb) < 512) vpb >>= 1;
     while (vpb < 1024 && (long)a->O * ((a->V + vpb - 1) / vpb) > 16384) vpb <<= 1;     // (64^3 volumes: fewer, larger blocks)
     // long tile lists (VQ-VAE decoder at 32^3 / 64^3): the statistics are reduced ONCE per object; the final [O][groups][2] floats
     // sit behind the partials in the caller's scratch (es_gn_args.stats)
     const float* fin = nullptr;
-    if (ntiles > 128) {
+    if (from_rg) {                 // statistics from the producers' row-group sums: no pass over x1 / x2
+        hipLaunchKernelGGL(k_gn_finalize_rg, dim3(a->groups, a->O), dim3(256), 0, (hipStream_t)stream, *a, part);
+        fin = part;
+    } else if (ntiles > 128) {
         float* f = part + (size_t)a->O * ntiles * a->groups * 2;
         hipLaunchKernelGGL(k_gn_finalize, dim3(a->groups, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, f);
         fin = f;

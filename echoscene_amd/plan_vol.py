@@ -8,6 +8,7 @@ dimension runs on the "volume" path (channels-last, fp16 MFMA operands, fp32 acc
 fp32 residual stream).
 """
 import ctypes as C
+import os
 import torch
 
 from . import hip
@@ -182,7 +183,47 @@ class VolBuilderMixin:
         self.keep += [pc, bt, skip]
         self.weight_bytes += pc.weight_bytes
         self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
-        return self._push(hip.OP_CONV, 'conv', a)
+        idx = self._push(hip.OP_CONV, 'conv', a)
+        if out_f32 is not None and not ncdhw and not epilogue and (out_ld is None or out_ld == pc.N):
+            # a GroupNorm that reads this tensor later asks the conv for its row-group sums (groupnorm() below)
+            if not hasattr(self, '_conv_of'):
+                self._conv_of = {}
+            self._conv_of[out_f32.data_ptr()] = (idx, M, pc.N)
+        return idx
+
+    def _rowgroup_producer(self, x, Cx, M, V):
+        """The conv op of this plan that writes the fp32 tensor x and would form its row-group sums in its own epilogue
+        (es_conv_emits_gn_stats), or None: x comes from elsewhere (stem output, another plan), the shapes do not allow it, or the
+        conv takes a route behind which the sums would cost a pass over the output -- what the GroupNorm's statistics pass costs."""
+        if os.environ.get('ES_GN_RG', '1') == '0' or V % 64 or x is None:
+            return None
+        ent = getattr(self, '_conv_of', {}).get(x.data_ptr())
+        if ent is None or ent[1] != M or ent[2] != Cx:
+            return None
+        op = self.ops[ent[0]]
+        if op.kind != hip.OP_CONV or op.u.conv.out_f32 != x.data_ptr():
+            return None
+        # (ES_GN_RG_ANY=1, tests: ask whatever the route -- the sums then come from k_rowgroup_stats behind the conv)
+        if os.environ.get('ES_GN_RG_ANY', '0') != '1':
+            q = ConvArgs.from_buffer_copy(op.u.conv)
+            if q.O_hint > q.O:
+                # a deterministic shard takes the decision of the WHOLE problem: where the unsharded run reduces row-group sums
+                # the shard must too (its own launch may be too small for the producer/consumer kernel -- k_rowgroup_stats then
+                # leaves the same bits), or the two runs would normalise with differently rounded statistics
+                q.O, q.O_hint = q.O_hint, 0
+            if hip.lib().es_conv_emits_gn_stats(C.byref(q)) != 1:
+                return None
+        return op
+
+    def _rowgroup_stats(self, op, x, Cx, M):
+        """Row-group sums [2][M/64][Cx] of x, requested from its producer op (es_conv_args.gn_stats_out)."""
+        st = getattr(self, '_rg_stats', None)
+        if st is None:
+            st = self._rg_stats = {}
+        if x.data_ptr() not in st:
+            st[x.data_ptr()] = self.buf(2 * (M // 64) * Cx)
+            op.u.conv.gn_stats_out = st[x.data_ptr()].data_ptr()
+        return st[x.data_ptr()]
 
     def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None, groups=32):
         a = GNArgs()
@@ -198,6 +239,12 @@ class VolBuilderMixin:
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)
+        # statistics from the producing convs' epilogues instead of a pass over x1 / x2 (both sources must have them)
+        p1 = self._rowgroup_producer(x1, C1, O * V, V)
+        p2 = self._rowgroup_producer(x2, C2, O * V, V) if x2 is not None else None
+        if p1 is not None and (x2 is None or p2 is not None):
+            a.stats1 = self._rowgroup_stats(p1, x1, C1, O * V).data_ptr()
+            a.stats2 = self._rowgroup_stats(p2, x2, C2, O * V).data_ptr() if x2 is not None else None
         self.keep += [gamma, beta]
         return self._push(hip.OP_GN, 'gn', a)
 
@@ -509,7 +556,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     return objbuf
 
 
-for _n in ('_push', 'conv', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
+for _n in ('_push', 'conv', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
     setattr(Builder, _n, getattr(VolBuilderMixin, _n))
 
 

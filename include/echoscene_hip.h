@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 3
+#define ES_ABI_VERSION 4
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -210,9 +210,22 @@ typedef struct es_conv_args {
                                  16-column MFMA tile carries 8 outputs' value and gate columns -- N = 8C (a multiple of
                                  224), the only output is out_f16 [M, 4C] = (value + b) * gelu(gate + b), out_ld = leading
                                  dim of that (a multiple of 8)                                              */
+    float* gn_stats_out;      /* NULL, or [2][ceil(M/64)][N] fp32: per (64-row group, output column) the sum (plane 0) and
+                                 the sum of squares (plane 1) of the FINAL fp32 output (after bias / rowvec / res), for the
+                                 GroupNorm that reads this tensor next (es_gn_args.stats1 / stats2): the statistics pass
+                                 of that GroupNorm -- a re-read of the whole tensor -- becomes a reduction of this 64x
+                                 smaller array.  The 256-row producer/consumer kernel forms the sums in its epilogue from
+                                 the values it stores (es_conv_emits_gn_stats() == 1); behind the other routes (64- /
+                                 128-row tiles, k_linear_ws, split K, object chunks) a small kernel passes over the output
+                                 instead.  One summation order for all routes (even rows of the group top to bottom, odd
+                                 rows top to bottom, then the two halves): the same bits whichever route ran.
+                                 Requires voxels per object % 64 == 0, out_f32 != NULL, channels-last output         */
 } es_conv_args;
 enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
+/* host-only: 1 when es_conv_mfma_f16(args) would form gn_stats_out inside its own epilogue, 0 when it would need the extra pass,
+ * -1 on invalid arguments (es_last_error()).  Launches nothing. */
+int es_conv_emits_gn_stats(const es_conv_args* args);
 /* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
  * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
  * block per K step.  h_out holds uint16 bit patterns. */
@@ -231,9 +244,15 @@ typedef struct es_gn_args {
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
     int32_t O_hint;                  /* 0, or the object count of the whole problem (sharding): partial-sum tiling as unsharded */
+    const float* stats1;             /* NULL, or the [2][O*V/64][C1] row-group sums written by the conv that produced x1
+                                        (es_conv_args.gn_stats_out); with x2, stats2 [2][O*V/64][C2] must be given too.  When
+                                        present the statistics pass over x1 / x2 is skipped: (object, group) statistics are
+                                        reduced from these sums (double, fixed order)                                */
+    const float* stats2;
 } es_gn_args;
 /* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
- * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats, apply. */
+ * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats (a pass over x, or a reduction of
+ * the producer's row-group sums), apply. */
 int es_groupnorm_vol(const es_gn_args* args, es_stream stream);
 
 typedef struct es_ln_args {

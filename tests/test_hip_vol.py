@@ -8,6 +8,7 @@ stream and statistics.  Two references are used:
   * the exact fp32 oracle / the reference-generated golden vectors -> the stated precision of the
     fp16 path: 2e-2 relative to the tensor scale (measured values are printed with -s).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -409,6 +410,59 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
+def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
+    """es_conv_args.gn_stats_out: the conv leaves per (64-row group, column) sums of its fp32 output, and the GroupNorm that reads the
+    tensor reduces them instead of passing over it.  Checks (a) the sums against the stored output for both ways they are formed
+    (in the epilogue of the 256-row producer/consumer tiles -- 17 objects x 16^3 = 272 tiles, es_conv_emits_gn_stats() == 1; by
+    k_rowgroup_stats behind a small problem, which the planner only asks for under ES_GN_RG_ANY=1), (b) GroupNorm(+SiLU) over
+    [conv output | second conv output] with the sums against F.group_norm of the stored fp32 tensors, and (c) the same GroupNorm
+    from a pass over the tensors (stats1 = NULL): equal within fp16 rounding.
+    (`ES_CONV_WS=0` in test_conv_alternate_kernels runs this test with every sum coming from k_rowgroup_stats.)"""
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    from echoscene_amd import hip
+    monkeypatch.setenv('ES_GN_RG_ANY', '1')
+    for O, dims, Cin, N, epi in [(17, (16, 16, 16), 32, 224, 1), (2, (4, 8, 8), 64, 448, 0)]:
+        D, H, W = dims
+        V = D * H * W
+        x = _rnd((O, Cin) + dims, 1)
+        wa = (_rnd((N, Cin, 3, 3, 3), 2) / np.sqrt(Cin * 27)).half().float()
+        wb = (_rnd((N, Cin, 1, 1, 1), 3) / np.sqrt(Cin)).half().float()
+        ba = 0.3 * _rnd((N,), 4)
+        rv = 0.5 * _rnd((O, N), 5)
+        b = Builder(dev)
+        xcl = b.dev(_cl(x), torch.float16)
+        oa, ob = b.buf(O * V, N, zero=True), b.buf(O * V, N, zero=True)
+        ia = b.conv(xcl, PackedConv(wa, ba, dev), O, dims, rowvec=View(b.dev(rv)), out_f32=oa)
+        ib = b.conv(xcl, PackedConv(wb, None, dev), O, dims, res=oa, out_f32=ob)
+        if not any(k.startswith('ES_CONV_') for k in os.environ):     # (the A/B switches of test_conv_alternate_kernels re-route)
+            import ctypes
+            assert hip.lib().es_conv_emits_gn_stats(ctypes.byref(b.ops[ia].u.conv)) == epi
+        ga, be = 1 + 0.1 * _rnd((2 * N,), 6), 0.1 * _rnd((2 * N,), 7)
+        y = b.buf(O * V, 2 * N, dtype=torch.float16, zero=True)
+        ig = b.groupnorm(oa, N, ob, N, O, V, b.dev(ga), b.dev(be), 1e-5, True, y)
+        assert b.ops[ia].u.conv.gn_stats_out and b.ops[ib].u.conv.gn_stats_out and b.ops[ig].u.gn.stats1 and b.ops[ig].u.gn.stats2
+        sa, sb = b._rg_stats[oa.data_ptr()], b._rg_stats[ob.data_ptr()]
+        b.finish().run()
+        torch.cuda.synchronize()
+        for o_, s_ in ((oa, sa), (ob, sb)):
+            g64 = o_.double().view(O * V // 64, 64, N)
+            st = s_.view(2, O * V // 64, N).double()
+            assert _rel(st[0], g64.sum(1)) < 1e-5 and _rel(st[1], (g64 * g64).sum(1)) < 1e-5
+        cat = torch.cat([oa.view(O, V, N), ob.view(O, V, N)], 2).permute(0, 2, 1).reshape(O, 2 * N, D, H, W).cpu()
+        ref = F.silu(F.group_norm(cat, 32, ga, be, 1e-5))
+        assert _rel(y, _cl(ref)) < 2e-3
+        monkeypatch.setenv('ES_GN_RG', '0')              # (read by the planner at build time: this GroupNorm passes over the tensors)
+        b2 = Builder(dev)
+        y2 = b2.buf(O * V, 2 * N, dtype=torch.float16, zero=True)
+        i2 = b2.groupnorm(oa, N, ob, N, O, V, b2.dev(ga), b2.dev(be), 1e-5, True, y2)
+        assert not b2.ops[i2].u.gn.stats1
+        b2.finish().run()
+        torch.cuda.synchronize()
+        monkeypatch.delenv('ES_GN_RG')
+        assert (y.float() - y2.float()).abs().max() <= 2e-3 * max(1.0, float(y2.float().abs().max()))
+
+
 @pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}, {'ES_CONV_WSSPLIT': '0'}, {'ES_CONV_LINWS': '0'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
@@ -423,7 +477,7 @@ def test_conv_alternate_kernels(env):
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
     sel = 'test_conv_mfma or test_conv_fused_skip or unet3d_full_eps or vqvae or test_conv_ws_at'
-    sel += ' or test_conv_down_dhw'
+    sel += ' or test_conv_down_dhw or rowgroup_stats'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_vol.py'), '-m', 'gpu', '-q', '-x', '-k', sel],
                        env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
