@@ -402,6 +402,14 @@ __device__ __forceinline__ void conv_tile_of(const es_conv_args& a, int& bx, int
     }
 }
 
+// a wave-uniform pointer the compiler can keep in SGPRs (buffer descriptors must be scalar; a descriptor it cannot prove uniform
+// is applied through a waterfall loop around every buffer instruction)
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (void*)(((unsigned long)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue shared by the conv kernels.
 // MFMA D layout: lane holds D[row = q*4 + r][col = i16].  A direct store is 112 four-byte stores (+112 residual
@@ -449,7 +457,8 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
         }
         constexpr int HLD = 72;                               // halfs per slab row (56 + pad; 144 B keeps the 16-byte reads aligned)
         _Float16* hslab = (_Float16*)smem + wave * (16 * HLD);
-        _Float16* outp = (_Float16*)a.out_f16 + (n0 >> 1) + wn * 56;     // first output column of this wave
+        typedef unsigned int u4g __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rOg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out_f16), (short)0, (int)0x80000000u, 0x00020000);
         const int rr = q * 4 + (lo ? 0 : 2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -467,10 +476,15 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {                     // 16 rows x 7 pieces of 16 bytes
-                const int idx = lane + 64 * t;
-                const int row = idx / 7, c8 = idx - row * 7;
-                const long m = m0 + wm * WROWS + i * 16 + row;
-                if (idx < 112 && m < M) *(h8*)(outp + m * a.out_ld + c8 * 8) = *(const h8*)&hslab[row * HLD + c8 * 8];
+                // (buffer stores with an out-of-range offset for idle lanes / rows past M instead of a branch: behind a branch the
+                //  compiler waits for the previous store -- s_waitcnt vmcnt(0) -- before every store, 8 serialised round trips per tile)
+                const int idx = lane + 64 * t, idl = idx < 112 ? idx : 0;
+                const int row = idl / 7, c8 = idl - row * 7;
+                const long mrow = m0 + wm * WROWS + i * 16;
+                const bool ok = idx < 112 && mrow + row < M;
+                const unsigned vo = ok ? ((unsigned)row * (unsigned)a.out_ld + (unsigned)((n0 >> 1) + wn * 56 + c8 * 8)) * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4g, *(const h8*)&hslab[row * HLD + c8 * 8]), rOg, (int)vo,
+                                                       (int)((unsigned)mrow * (unsigned)a.out_ld * 2u), 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -494,73 +508,81 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
             const bool n_ok = lane < 56 && n < a.N;
             const long mw0 = m0 + wm * WROWS;
             const int rows_left = (int)((M - mw0) < (long)WROWS ? (M - mw0 > 0 ? M - mw0 : 0) : (long)WROWS);   // valid rows of this wave
-            const bool one_obj = rows_left > 0 && (mw0 >> vsh) == ((mw0 + rows_left - 1) >> vsh);
             f4 bias4 = {0.f, 0.f, 0.f, 0.f}, rv4 = {0.f, 0.f, 0.f, 0.f};
             if (!part && a.bias && n_ok) bias4 = *(const f4*)&a.bias[n];
-            if (!part && a.rowvec && n_ok && one_obj) rv4 = *(const f4*)&a.rowvec[(mw0 >> vsh) * a.rowvec_ld + n];
+            if (!part && a.rowvec && n_ok && rows_left > 0) rv4 = *(const f4*)&a.rowvec[(mw0 >> vsh) * a.rowvec_ld + n];
             const bool use_res = a.res && !part;
             const unsigned ld = (unsigned)a.out_ld;
-            const unsigned off0 = (unsigned)(mw0 + rsub) * ld + (unsigned)n;            // element offset of (row rsub, column n)
-            const unsigned poff0 = (unsigned)(mw0 + rsub) * (unsigned)a.N + (unsigned)n;
             auto write_slab = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
             };
-            auto load_res = [&](int i, f4 (&rr)[8]) __attribute__((always_inline)) {
+            f4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};          // STATS_: this lane's rows (rsub, rsub + 2, ...) of the wave's 64-row group
+            // STRAIGHT-LINE row passes.  The first version tested the operands inside the pass (`if (a.res) v += ...; if (a.out_f32)
+            // ...`, a per-row rowvec load when a wave straddled two objects): with loads and stores on different paths the compiler
+            // cannot keep the in-order vmcnt budget and put s_waitcnt vmcnt(0) in front of EVERY row pass -- 32 serialised store
+            // round trips per tile (tools/linear_stamps.py: 12.9 us for a 114 KB fp16 tile, the same 11.5 us for a 229 KB fp32
+            // one; rounds 1-3 read that as an HBM-bound burst).  Here absent operands are buffer descriptors with zero records
+            // (loads return 0, stores are dropped) and invalid lanes / rows carry an out-of-range offset, so a row pass is LDS read
+            // -> three adds -> two buffer stores without control flow, and no store is ever waited for.  The host routes a launch
+            // here only when a wave's 64 rows lie in ONE object (voxels per object % 64 == 0, or no rowvec): rv4 is per wave.
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+            constexpr unsigned OOBV = 0x80000000u;
+            float* const o32 = part ? part : a.out_f32;
+            const unsigned ldp = part ? (unsigned)a.N : ld;
+            const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(o32), (short)0, o32 ? (int)OOBV : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rO16 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(part ? nullptr : a.out_f16), (short)0, (!part && a.out_f16) ? (int)OOBV : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(use_res ? a.res : nullptr), (short)0, use_res ? (int)OOBV : 0, 0x00020000);
+            const int rsub_l = lane < 56 ? rsub : 0;                              // (idle lanes read a valid LDS row)
+            const unsigned vrow32 = n_ok ? ((unsigned)rsub * ldp + (unsigned)n) * 4u : OOBV;
+            const unsigned vrow16 = n_ok ? ((unsigned)rsub * ld + (unsigned)n) * 2u : OOBV;
+            auto load_res_s = [&](int i, f4 (&rr)[8]) __attribute__((always_inline)) {
+                const unsigned so = (unsigned)(mw0 + i * 16) * ld * 4u;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int r = i * 16 + rsub + 2 * t;
-                    rr[t] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (use_res && n_ok && r < rows_left) rr[t] = *(const f4*)&a.res[off0 + (unsigned)(i * 16 + 2 * t) * ld];
+                    const unsigned vo = (i * 16 + rsub + 2 * t < rows_left) ? vrow32 + (unsigned)(2 * t) * ld * 4u : OOBV;
+                    rr[t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rRes, (int)vo, (int)so, 0));
                 }
             };
-            f4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};          // STATS_: this lane's rows (rsub, rsub + 2, ...) of the wave's 64-row group
-            auto combine = [&](int i, const f4 (&rr)[8]) __attribute__((always_inline)) {
+            auto combine_s = [&](int i, const f4 (&rr)[8]) __attribute__((always_inline)) {
+                const unsigned so32 = (unsigned)(mw0 + i * 16) * ldp * 4u, so16 = (unsigned)(mw0 + i * 16) * ld * 2u;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int row = rsub + 2 * t, r = i * 16 + row;
-                    if (n_ok && r < rows_left) {
-                        f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
-                        if (part) {
-                            *(f4*)&part[poff0 + (unsigned)(i * 16 + 2 * t) * (unsigned)a.N] = v;
-                        } else {
-                            const unsigned off = off0 + (unsigned)(i * 16 + 2 * t) * ld;
-                            if (a.bias) v += bias4;
-                            if (a.rowvec) v += one_obj ? rv4 : *(const f4*)&a.rowvec[((mw0 + r) >> vsh) * a.rowvec_ld + n];
-                            if (a.res) v += rr[t];
-                            if (a.out_f32) *(f4*)&a.out_f32[off] = v;
-                            if (a.out_f16) {
-                                h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                                *(h4*)((_Float16*)a.out_f16 + off) = hv;
-                            }
-                            if constexpr (STATS_) {
-                                gs += v;
+                    const bool ok = i * 16 + rsub + 2 * t < rows_left;
+                    f4 v = *(const f4*)&slab[(rsub_l + 2 * t) * 116 + c4 * 4];
+                    v += bias4;
+                    v += rv4;
+                    v += rr[t];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rO32, (int)(ok ? vrow32 + (unsigned)(2 * t) * ldp * 4u : OOBV), (int)so32, 0);
+                    const h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), rO16, (int)(ok ? vrow16 + (unsigned)(2 * t) * ld * 2u : OOBV), (int)so16, 0);
+                    if constexpr (STATS_) {
+                        gs += v;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) gq[e] = fmaf(v[e], v[e], gq[e]);
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) gq[e] = fmaf(v[e], v[e], gq[e]);
                     }
                 }
             };
             f4 rbuf[2][8];
             write_slab(0);
             __builtin_amdgcn_sched_barrier(0);
-            load_res(0, rbuf[0]);
+            load_res_s(0, rbuf[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): own slab writes visible to own wave
                 __builtin_amdgcn_wave_barrier();
-                if (i >= 1 && i + 1 < MI) load_res(i + 1, rbuf[(i + 1) & 1]);       // two slabs already released
+                if (i >= 1 && i + 1 < MI) load_res_s(i + 1, rbuf[(i + 1) & 1]);       // two slabs already released
                 __builtin_amdgcn_sched_barrier(0);
-                combine(i, rbuf[i & 1]);
+                combine_s(i, rbuf[i & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
                 if (i + 1 < MI) write_slab(i + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == 0 && MI > 1) load_res(1, rbuf[1]);                            // behind slab 1's LDS writes
+                if (i == 0 && MI > 1) load_res_s(1, rbuf[1]);                            // behind slab 1's LDS writes
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (STATS_) {
@@ -1142,13 +1164,6 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     ES_STAMP_AT(4);
 }
 
-// a wave-uniform pointer the compiler can keep in SGPRs (buffer descriptors must be scalar; a descriptor it cannot prove uniform
-// is applied through a waterfall loop around every buffer instruction)
-__device__ __forceinline__ void* uniform_ptr(const void* p) {
-    const unsigned long v = (unsigned long)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (void*)(((unsigned long)hi << 32) | lo);
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_linear_ws: k_conv_ws for the 1x1 / linear launches with several column tiles (qkv: 6, FeedForward: 16-24), where a tile has only
@@ -1170,6 +1185,11 @@ __global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long M = (long)g.O * g.D * g.H * g.W;
+#ifdef ES_STAMP
+    // (tools/linear_stamps.py) 0 entry, then per column tile: 1 + 2 cb = K loop done, 2 + 2 cb = epilogue done (first three tiles)
+    unsigned long long* stamp = g_stamp_buf ? g_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * (NC_ + NP_) + wave) * 8 : nullptr;
+#endif
+    ES_STAMP_AT(0);
     // tile mapping as conv_tile_of (XCD-contiguous ranges, column GROUPS fastest inside ~3 MiB weight panels)
     int bx, byg;
     {
@@ -1281,7 +1301,13 @@ __global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, cons
             __builtin_amdgcn_sched_barrier(0);
         }
         ws_mma<MI>(acc, af, bfr);
+#ifdef ES_STAMP
+        if (cb < 3) ES_STAMP_AT(1 + 2 * cb);
+#endif
         conv_epilogue<BM_, NC_, true, true, EPI_, true>(a, g, acc, smem + RING_BYTES, M, m0, (by0 + cb) * BN, wave, lane, 1, 0, 0);
+#ifdef ES_STAMP
+        if (cb < 3) ES_STAMP_AT(2 + 2 * cb);
+#endif
     }
 }
 
@@ -1937,7 +1963,8 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     static const char* ws_env = getenv("ES_CONV_WS");             // A/B switch: 0 = no warp specialisation
     // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
     const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
-                                M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30);
+                                M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) &&
+                                (!a->rowvec || (a->D * a->H * a->W) % 64 == 0);      // a wave's 64 rows in one object: rowvec per wave
     const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
     const bool geglu = a->epilogue == ES_EPI_GEGLU;
     // Small problems (few objects per GPU: the strong-scaling regime, or the 16x4x4 level): fewer than 256 tiles of 256 rows.  The
