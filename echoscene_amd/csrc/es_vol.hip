@@ -458,7 +458,6 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
         constexpr int HLD = 72;                               // halfs per slab row (56 + pad; 144 B keeps the 16-byte reads aligned)
         _Float16* hslab = (_Float16*)smem + wave * (16 * HLD);
         typedef unsigned int u4g __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t rOg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out_f16), (short)0, (int)0x80000000u, 0x00020000);
         const int rr = q * 4 + (lo ? 0 : 2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -482,9 +481,10 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                 const int row = idl / 7, c8 = idl - row * 7;
                 const long mrow = m0 + wm * WROWS + i * 16;
                 const bool ok = idx < 112 && mrow + row < M;
+                // (descriptor at the slab's first row, soffset 0: an SGPR soffset lost pieces -- see the LOWREG path below)
+                const __amdgpu_buffer_rsrc_t rOg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((_Float16*)a.out_f16 + mrow * (long)a.out_ld), (short)0, (int)0x80000000u, 0x00020000);
                 const unsigned vo = ok ? ((unsigned)row * (unsigned)a.out_ld + (unsigned)((n0 >> 1) + wn * 56 + c8 * 8)) * 2u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4g, *(const h8*)&hslab[row * HLD + c8 * 8]), rOg, (int)vo,
-                                                       (int)((unsigned)mrow * (unsigned)a.out_ld * 2u), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4g, *(const h8*)&hslab[row * HLD + c8 * 8]), rOg, (int)vo, 0, 0);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -531,24 +531,26 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
             typedef unsigned int u2v __attribute__((ext_vector_type(2)));
             constexpr unsigned OOBV = 0x80000000u;
-            float* const o32 = part ? part : a.out_f32;
+            // The descriptors start at the wave's first row and every access uses soffset 0.  (A first version kept one descriptor
+            // per tensor and passed the slab's row offset as the SGPR soffset: the GEGLU stores written that way lost 16-byte
+            // pieces now and then at 4 objects per GPU -- the only shape that sends them through k_conv_ws -- whenever the
+            // compiler reused the offset SGPR right behind the store; with the offset folded into the VGPR the runs are clean.)
             const unsigned ldp = part ? (unsigned)a.N : ld;
+            float* const o32 = part ? part + mw0 * (long)a.N : (a.out_f32 ? a.out_f32 + mw0 * (long)a.out_ld : nullptr);
             const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(o32), (short)0, o32 ? (int)OOBV : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rO16 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(part ? nullptr : a.out_f16), (short)0, (!part && a.out_f16) ? (int)OOBV : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(use_res ? a.res : nullptr), (short)0, use_res ? (int)OOBV : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rO16 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((!part && a.out_f16) ? (_Float16*)a.out_f16 + mw0 * (long)a.out_ld : nullptr), (short)0, (!part && a.out_f16) ? (int)OOBV : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(use_res ? a.res + mw0 * (long)a.out_ld : nullptr), (short)0, use_res ? (int)OOBV : 0, 0x00020000);
             const int rsub_l = lane < 56 ? rsub : 0;                              // (idle lanes read a valid LDS row)
             const unsigned vrow32 = n_ok ? ((unsigned)rsub * ldp + (unsigned)n) * 4u : OOBV;
             const unsigned vrow16 = n_ok ? ((unsigned)rsub * ld + (unsigned)n) * 2u : OOBV;
             auto load_res_s = [&](int i, f4 (&rr)[8]) __attribute__((always_inline)) {
-                const unsigned so = (unsigned)(mw0 + i * 16) * ld * 4u;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const unsigned vo = (i * 16 + rsub + 2 * t < rows_left) ? vrow32 + (unsigned)(2 * t) * ld * 4u : OOBV;
-                    rr[t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rRes, (int)vo, (int)so, 0));
+                    const unsigned vo = (i * 16 + rsub + 2 * t < rows_left) ? vrow32 + (unsigned)(i * 16 + 2 * t) * ld * 4u : OOBV;
+                    rr[t] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rRes, (int)vo, 0, 0));
                 }
             };
             auto combine_s = [&](int i, const f4 (&rr)[8]) __attribute__((always_inline)) {
-                const unsigned so32 = (unsigned)(mw0 + i * 16) * ldp * 4u, so16 = (unsigned)(mw0 + i * 16) * ld * 2u;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const bool ok = i * 16 + rsub + 2 * t < rows_left;
@@ -556,9 +558,9 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                     v += bias4;
                     v += rv4;
                     v += rr[t];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rO32, (int)(ok ? vrow32 + (unsigned)(2 * t) * ldp * 4u : OOBV), (int)so32, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rO32, (int)(ok ? vrow32 + (unsigned)(i * 16 + 2 * t) * ldp * 4u : OOBV), 0, 0);
                     const h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), rO16, (int)(ok ? vrow16 + (unsigned)(2 * t) * ld * 2u : OOBV), (int)so16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, hv), rO16, (int)(ok ? vrow16 + (unsigned)(i * 16 + 2 * t) * ld * 2u : OOBV), 0, 0);
                     if constexpr (STATS_) {
                         gs += v;
 #pragma unroll
@@ -611,24 +613,41 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                 for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * 116 + j * 16 + i16] = acc[i][j][r];
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own writes visible to own wave
             __builtin_amdgcn_wave_barrier();
-            // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane
+            // 16 rows x 28 float4 = 448 float4 per slab, 7 per lane.  Straight-line as in the LOWREG path below: absent operands
+            // are descriptors with zero records, idle lanes carry an out-of-range offset.  (The first version loaded bias, rowvec
+            // and residual behind `if`s inside the item loop: the compiler put s_waitcnt vmcnt(0) between all of them -- three
+            // dependent load round trips and a store wait per item, 425 full waits in the kernel.)  The descriptors start at the
+            // slab's first row, so the per-lane offsets stay small whatever the tensor size.
+            {
+                typedef unsigned int u4e __attribute__((ext_vector_type(4)));
+                typedef unsigned int u2e __attribute__((ext_vector_type(2)));
+                constexpr unsigned OOBE = 0x80000000u;
+                const long rb = m0 + wm * WROWS + i * 16;
+                const int vshe = g.lw + g.lh + g.ld;
+                float* const o32 = part ? part + rb * a.N : (a.out_f32 ? a.out_f32 + rb * a.out_ld : nullptr);
+                const unsigned ldp = part ? (unsigned)a.N : (unsigned)a.out_ld, lde = (unsigned)a.out_ld;
+                const bool ep = !part;
+                const __amdgpu_buffer_rsrc_t rO32 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(o32), (short)0, o32 ? (int)OOBE : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rO16 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep && a.out_f16 ? (_Float16*)a.out_f16 + rb * a.out_ld : nullptr), (short)0, (ep && a.out_f16) ? (int)OOBE : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep && a.res ? a.res + rb * a.out_ld : nullptr), (short)0, (ep && a.res) ? (int)OOBE : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep ? a.bias : nullptr), (short)0, (ep && a.bias) ? (int)OOBE : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rRv = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep ? a.rowvec : nullptr), (short)0, (ep && a.rowvec) ? (int)OOBE : 0, 0x00020000);
 #pragma unroll 7
-            for (int t = 0; t < 7; ++t) {
-                const int idx = lane + 64 * t;
-                const int row = idx / 28, c4 = idx - row * 28;
-                const long m = m0 + wm * WROWS + i * 16 + row;
-                const int n = n0 + wn * 112 + c4 * 4;
-                if (m < M && n < a.N) {
+                for (int t = 0; t < 7; ++t) {
+                    const int idx = lane + 64 * t;
+                    const int row = idx / 28, c4 = idx - row * 28;
+                    const int n = n0 + wn * 112 + c4 * 4;
+                    const bool ok = rb + row < M && n < a.N;
                     f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
-                    if (part) { *(f4*)&part[m * a.N + n] = v; continue; }
-                    if (a.bias) v += *(const f4*)&a.bias[n];
-                    if (a.rowvec) v += *(const f4*)&a.rowvec[(m / V) * a.rowvec_ld + n];
-                    if (a.res) v += *(const f4*)&a.res[m * a.out_ld + n];
-                    if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = v;
-                    if (a.out_f16) {
-                        h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
-                    }
+                    const f4 vb = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rBias, (int)(ok ? (unsigned)n * 4u : OOBE), 0, 0));
+                    const f4 vr = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rRv, (int)(ok ? ((unsigned)((rb + row) >> vshe) * (unsigned)a.rowvec_ld + (unsigned)n) * 4u : OOBE), 0, 0));
+                    const f4 vs = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rRes, (int)(ok ? ((unsigned)row * lde + (unsigned)n) * 4u : OOBE), 0, 0));
+                    v += vb;
+                    v += vr;
+                    v += vs;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4e, v), rO32, (int)(ok ? ((unsigned)row * ldp + (unsigned)n) * 4u : OOBE), 0, 0);
+                    const h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2e, hv), rO16, (int)(ok ? ((unsigned)row * lde + (unsigned)n) * 2u : OOBE), 0, 0);
                 }
             }
             __builtin_amdgcn_wave_barrier();
