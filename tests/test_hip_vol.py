@@ -410,6 +410,32 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     assert _rel(out16, ref) < 2e-3
 
 
+def test_geglu_projection_at_4_objects_takes_the_producer_consumer_kernel(dev):
+    """FeedForward GEGLU projection 448 -> 3584 at 16x8x8 with 4 objects: 16 row tiles x 16 column tiles = 256 workgroups, the one
+    shape of the UNet that goes through k_conv_ws<GEGLU> (fewer objects: 128-row tiles; more: k_linear_ws).  Round 3 had a version
+    of its epilogue that lost 16-byte pieces of the output now and then (buffer stores with an SGPR soffset the compiler reused right
+    behind the store): the output is pre-filled with NaN and the launch repeated."""
+    from echoscene_amd.plan import Builder
+    from echoscene_amd.plan_vol import PackedConv
+    from echoscene_amd import hip
+    O, dims, K, N = 4, (16, 8, 8), 448, 3584
+    M = O * dims[0] * dims[1] * dims[2]
+    x = _rnd((M, K), 1).half()
+    w = (_rnd((N, K), 2) / np.sqrt(K)).half().float()
+    bias = 0.3 * _rnd((N,), 3)
+    a_, g_ = (x.float() @ w.t() + bias).chunk(2, -1)
+    ref = a_ * F.gelu(g_)
+    b = Builder(dev)
+    out = b.buf(M, N // 2, dtype=torch.float16)
+    b.conv(b.dev(x, torch.float16), PackedConv(w, bias, dev, geglu=True), O, dims, out_f16=out, epilogue=hip.EPI_GEGLU, out_ld=N // 2)
+    plan = b.finish()
+    for rep in range(5):
+        out.fill_(float('nan'))
+        plan.run()
+        torch.cuda.synchronize()
+        assert _rel(out, ref) < 2e-3, rep
+
+
 def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
     """es_conv_args.gn_stats_out: the conv leaves per (64-row group, column) sums of its fp32 output, and the GroupNorm that reads the
     tensor reduces them instead of passing over it.  Checks (a) the sums against the stored output for both ways they are formed
