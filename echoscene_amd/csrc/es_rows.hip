@@ -50,6 +50,21 @@ __device__ __forceinline__ float load_slabs1(const float* p, int nslab, long sla
     for (int j = 1; j < nslab; ++j) v += p[(long)j * slab_stride];
     return v;
 }
+// The same sum with the first four loads in flight at once and no control flow: slab j >= nslab re-reads the last slab (same cache
+// line) and is not added.  load_slabs1's run-time loop made every slab of an epilogue operand a dependent round trip IN FRONT of the weight and
+// staging loads of the slice-0 workgroups (a residual with 4 slabs: four serial L2 / Infinity-Cache round trips before anything else
+// was issued).  Same additions in the same order: the same bits.
+__device__ __forceinline__ void issue_slabs1(float (&r)[4], const float* p, int nslab, long slab_stride) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = p[(long)(j < nslab ? j : nslab - 1) * slab_stride];
+}
+__device__ __forceinline__ float sum_slabs1(const float (&r)[4], const float* p, int nslab, long slab_stride) {
+    float v = r[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v = j < nslab ? v + r[j] : v;
+    for (int j = 4; j < nslab; ++j) v += p[(long)j * slab_stride];      // (more than 4 slabs: not produced by the shipped planner)
+    return v;
+}
 
 // NS float4 loads of one slab tensor element issued together (slabs >= nslab are wave-uniformly skipped), summed in the fixed
 // order 0 .. nslab-1 by sum_slabs: the deferred split-K reduction of the producer.  These launches are pure latency chains: a
@@ -320,10 +335,13 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f;
     const bool ok_e = tid < 256 && m_e < a.M && n_e < a.N;
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
-    if (first && a.res && ok_res && !(dbg & 8))
-        e_res = load_slabs1(a.res + (long)m_e * a.res_ld + nres, a.res_nslab > 1 ? a.res_nslab : 1, a.res_slab_stride);
-    if (first && a.res2 && ok_res && !(dbg & 8))
-        e_res2 = load_slabs1(a.res2 + (long)m_e * a.res2_ld + nres, a.res2_nslab > 1 ? a.res2_nslab : 1, a.res2_slab_stride);
+    float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ns1 = a.res_nslab > 1 ? a.res_nslab : 1, ns2 = a.res2_nslab > 1 ? a.res2_nslab : 1;
+    const bool has1 = first && a.res && ok_res && !(dbg & 8), has2 = first && a.res2 && ok_res && !(dbg & 8);
+    const float* const pr1 = a.res + (long)m_e * a.res_ld + nres;
+    const float* const pr2 = a.res2 + (long)m_e * a.res2_ld + nres;
+    if (has1) issue_slabs1(r1, pr1, ns1, a.res_slab_stride);        // summed in the epilogue
+    if (has2) issue_slabs1(r2, pr2, ns2, a.res2_slab_stride);
     if (first && bias && n_e < a.N && !(dbg & 8)) e_bias = bias[n_e];
     const int kg = wave;
 
@@ -363,6 +381,8 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     float sres = 0.f;
 #pragma unroll
     for (int w = 0; w < NKG; ++w) sres += red[w * 256 + off];
+    if (has1) e_res = sum_slabs1(r1, pr1, ns1, a.res_slab_stride);
+    if (has2) e_res2 = sum_slabs1(r2, pr2, ns2, a.res2_slab_stride);
     float* out = a.out + (long)bz * a.out_bstride + (long)slice * a.out_slab_stride;
     if (GEGLU_EPI && geglu) {
         // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt + nl, lane nl + 8 its gate
