@@ -284,22 +284,6 @@ struct RowsLaunch {
 
 // NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
 // unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
-// The 1.4 KB argument block is read with scalar loads as the code reaches each field: a dozen s_load -> s_waitcnt -> branch steps
-// in a row at kernel entry, each a scalar-cache miss on a fresh launch.  Touch every 64-byte line of the kernarg segment at once
-// (one round trip), so that the loads the compiler emits later hit the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ void kernarg_warm() {
-    const unsigned long ka = (unsigned long)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int NL = (BYTES + 63) / 64;
-    static_assert(NL <= 24, "kernarg_warm: argument block larger than expected");
-    unsigned d[24];
-#define ES_KW(i) if (i < NL) asm volatile("s_load_dword %0, %1, %2" : "=s"(d[i]) : "s"(ka), "i"(i * 64));
-    ES_KW(0) ES_KW(1) ES_KW(2) ES_KW(3) ES_KW(4) ES_KW(5) ES_KW(6) ES_KW(7) ES_KW(8) ES_KW(9) ES_KW(10) ES_KW(11)
-    ES_KW(12) ES_KW(13) ES_KW(14) ES_KW(15) ES_KW(16) ES_KW(17) ES_KW(18) ES_KW(19) ES_KW(20) ES_KW(21) ES_KW(22) ES_KW(23)
-#undef ES_KW
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
