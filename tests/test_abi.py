@@ -146,3 +146,34 @@ def test_product_does_not_import_oracle():
                     if re.search(r'^\s*(from|import)\s+oracle\b', txt, re.M):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_conv_route_query_for_groupnorm_sums_is_host_only():
+    """es_conv_emits_gn_stats: the planner's question "would this conv launch form the next GroupNorm's row-group sums in its own
+    epilogue?" is answered on the host from the dispatcher's own routing (no launch, no device): yes for the 256-row
+    producer/consumer tiles of a 32-object scene, no for few objects (split K / small tiles), for the GEGLU projection, for volumes
+    with fewer than 64 voxels per object; a deterministic shard (O_hint) is asked about the WHOLE problem by the planner."""
+    import ctypes as C
+    from echoscene_amd import hip
+    L = hip.lib()
+
+    def args(O, dims, Cin, N, taps=27, epilogue=0, f32=True):
+        a = hip.ConvArgs()
+        a.a, a.w = 0x1000, 0x2000                      # never dereferenced by the query
+        a.O, a.D, a.H, a.W = O, dims[0], dims[1], dims[2]
+        a.Cin, a.N, a.taps, a.mode = Cin, N, taps, 0
+        a.out_f32 = 0x3000 if f32 else None
+        a.out_f16 = None if f32 else 0x4000
+        a.bias = 0x5000
+        a.out_ld = N if not epilogue else N // 2
+        a.workspace, a.splitk = 0x6000, -1
+        a.epilogue = epilogue
+        return a
+    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 16, 16), 224, 224))) == 1
+    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 8, 8), 448, 448))) == 1
+    assert L.es_conv_emits_gn_stats(C.byref(args(4, (16, 16, 16), 224, 224))) == 0        # 64 tiles: K split over workgroups
+    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 4, 4), 672, 672))) == 0         # 96 tiles at the 16x4x4 level
+    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 8, 8), 448, 3584, taps=1, epilogue=hip.EPI_GEGLU, f32=False))) == 0
+    assert L.es_conv_emits_gn_stats(C.byref(args(4096, (2, 4, 4), 64, 224))) == 0         # 32 voxels per object
+    bad = args(32, (16, 16, 16), 100, 224)                                                # Cin not a multiple of 32
+    assert L.es_conv_emits_gn_stats(C.byref(bad)) == -1 and b'Cin' in L.es_last_error()
