@@ -568,6 +568,23 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                     }
                 }
             };
+            if (part) {                              // split K: the raw partial tile (wave-uniform branch; nothing to load or add)
+                write_slab(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const bool ok = i * 16 + rsub + 2 * t < rows_left;
+                        const f4 v = *(const f4*)&slab[(rsub_l + 2 * t) * 116 + c4 * 4];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rO32, (int)(ok ? vrow32 + (unsigned)(i * 16 + 2 * t) * ldp * 4u : OOBV), 0, 0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i + 1 < MI) write_slab(i + 1);
+                }
+                return;
+            }
             f4 rbuf[2][8];
             write_slab(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -632,6 +649,17 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                 const __amdgpu_buffer_rsrc_t rRes = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep && a.res ? a.res + rb * a.out_ld : nullptr), (short)0, (ep && a.res) ? (int)OOBE : 0, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep ? a.bias : nullptr), (short)0, (ep && a.bias) ? (int)OOBE : 0, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rRv = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ep ? a.rowvec : nullptr), (short)0, (ep && a.rowvec) ? (int)OOBE : 0, 0x00020000);
+                if (part) {                          // split K: the raw partial tile, nothing to load (wave-uniform branch)
+#pragma unroll 7
+                    for (int t = 0; t < 7; ++t) {
+                        const int idx = lane + 64 * t;
+                        const int row = idx / 28, c4 = idx - row * 28;
+                        const int n = n0 + wn * 112 + c4 * 4;
+                        const bool ok = rb + row < M && n < a.N;
+                        const f4 v = *(const f4*)&slab[row * 116 + c4 * 4];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4e, v), rO32, (int)(ok ? ((unsigned)row * ldp + (unsigned)n) * 4u : OOBE), 0, 0);
+                    }
+                } else
 #pragma unroll 7
                 for (int t = 0; t < 7; ++t) {
                     const int idx = lane + 64 * t;
