@@ -770,7 +770,27 @@ def case_scene_e2e(concat=False):
     save('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny', **out)
 
 
-CASES = dict(box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+def case_gcn_ragged():
+    """GraphTripleConvNet on a ragged graph: a node without any triple (avg pooling divides by the clamped count, model/graph.py:
+    185-191), a hub that is subject or object of most triples, a repeated (s, o) pair with two predicates and a self-loop; and the
+    degenerate graph of ONE node with one self-loop triple."""
+    from model.graph import GraphTripleConvNet
+    tri = [[0, 1, 1], [0, 2, 2], [0, 3, 4], [0, 4, 5], [0, 5, 6], [2, 3, 0], [4, 1, 0], [1, 2, 2], [1, 5, 2], [6, 3, 6],
+           [5, 2, 4], [7, 1, 0], [0, 6, 7]]                       # node 3 has no triple; (1, 2) twice; (6, 6) is a self-loop
+    for tag, triples, O in (('ragged', torch.tensor(tri, dtype=torch.int64), 8), ('one_node', torch.tensor([[0, 1, 0]], dtype=torch.int64), 1)):
+        net = GraphTripleConvNet(input_dim_obj=96, input_dim_pred=32, num_layers=3, hidden_dim=64,
+                                 residual=True, pooling='avg', mlp_normalization='batch', output_dim=80)
+        fill(net, 'gcn_res_bn.')                                   # the weights of the 'res_bn' case
+        obj = rnd((O, 96), 21)
+        pred = rnd((triples.shape[0], 32), 22)
+        edges = torch.stack([triples[:, 0], triples[:, 2]], 1)
+        with torch.no_grad():
+            o, p = net(obj, pred, edges)
+        save('gcn_' + tag, obj=obj, pred=pred, triples=triples, out_obj=o, out_pred=p,
+             cfg=np.array([96, 32, 3, 64, 1, 1, 80]))
+
+
+CASES = dict(gcn_ragged=case_gcn_ragged, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

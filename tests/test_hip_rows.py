@@ -139,7 +139,7 @@ def test_bad_args_raise(dev):
         _run_linear(dev, [dict(src=X, width=6)], torch.zeros(8, 6), None, 4)
 
 
-@pytest.mark.parametrize('tag', ['res_bn', 'plain'])
+@pytest.mark.parametrize('tag', ['res_bn', 'plain', 'ragged', 'one_node'])
 def test_gcn_vs_reference_golden(dev, tag):
     from echoscene_amd.model.graph import GraphTripleConvNet
     from echoscene_amd.samplers import gcn_forward
@@ -147,7 +147,9 @@ def test_gcn_vs_reference_golden(dev, tag):
     din, dp, nl, H, res, bn, dout = [int(v) for v in g['cfg']]
     net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res),
                              mlp_normalization='batch' if bn else 'none', output_dim=dout)
-    sd = {'n.' + k: v for k, v in seeded_state_dict(net, 'gcn_%s.' % tag).items()}
+    # ('ragged': a node without triples -- avg pooling over an empty CSR row --, a hub, a repeated pair, a self-loop; 'one_node': one
+    #  node with one self-loop triple; both with the weights of 'res_bn')
+    sd = {'n.' + k: v for k, v in seeded_state_dict(net, 'gcn_%s.' % (tag if tag in ('res_bn', 'plain') else 'res_bn')).items()}
     o, p = gcn_forward(sd, 'n', g['obj'], g['pred'], g['triples'], dev)
     _close(o, g['out_obj'], 3e-5)
     _close(p, g['out_pred'], 3e-5)

@@ -24,13 +24,15 @@ def _close(a, b, atol, rtol=1e-5):
         err, b.abs().max().item())
 
 
-@pytest.mark.parametrize('tag', ['res_bn', 'plain'])
+@pytest.mark.parametrize('tag', ['res_bn', 'plain', 'ragged', 'one_node'])
 def test_gcn(tag):
+    """('ragged': a node without triples, a hub, a repeated pair, a self-loop; 'one_node': one node, one self-loop triple -- both with the
+    weights of 'res_bn')"""
     g = load_golden('gcn_' + tag)
     din, dp, nl, H, res, bn, dout = [int(v) for v in g['cfg']]
     net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res),
                              mlp_normalization='batch' if bn else 'none', output_dim=dout)
-    sd = seeded_state_dict(net, 'gcn_%s.' % tag)
+    sd = seeded_state_dict(net, 'gcn_%s.' % (tag if tag in ('res_bn', 'plain') else 'res_bn'))
     tri = g['triples']
     edges = torch.stack([tri[:, 0], tri[:, 2]], 1)
     o, p = orc.gcn_net({'n.' + k: v for k, v in sd.items()}, 'n', g['obj'], g['pred'], edges)
