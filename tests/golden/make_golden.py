@@ -695,7 +695,12 @@ def case_scene_e2e_concat():
     case_scene_e2e(concat=True)
 
 
-def case_scene_e2e(concat=False):
+def case_scene_e2e_O2():
+    """The smallest scene the dataset can produce: ONE object and the scene node, one triple."""
+    case_scene_e2e(concat=False, O=2, name='scene_e2e_O2_tiny')
+
+
+def case_scene_e2e(concat=False, O=8, name=None):
     """The full boundary: the reference's ``SGDiff`` API end to end on CPU (SURVEY.md section 8(c)
     recipe) with a tiny-width config -- setup GCNs, 100-step layout loop, 4-step DDIM, VQ-VAE decode."""
     import tempfile
@@ -722,7 +727,6 @@ def case_scene_e2e(concat=False):
             fill(m.diff.ShapeDiff.df, 'e2e.shape_df.')
             m.diff.ShapeDiff.ddim_steps = 4
         m.eval()
-        O = 8
         objs, triples = synth.synthetic_graph(O, seed=9)
         tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
         noise = synth.layout_noise(O, 8, 100, seed=7)
@@ -767,7 +771,7 @@ def case_scene_e2e(concat=False):
             if k == 'shapes':
                 out['%s_shapes_abs' % typ] = v.double().abs().sum()
     out.update(objs=objs, triples=triples)
-    save('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny', **out)
+    save(name or ('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny'), **out)
 
 
 def case_gcn_ragged():
@@ -790,7 +794,7 @@ def case_gcn_ragged():
              cfg=np.array([96, 32, 3, 64, 1, 1, 80]))
 
 
-CASES = dict(gcn_ragged=case_gcn_ragged, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

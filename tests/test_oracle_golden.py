@@ -144,13 +144,14 @@ def test_vqvae_decode(tag):
     assert abs(sdf.double().abs().sum().item() - g['sdf_abs'].item()) < 1e-4 * g['sdf_abs'].item()
 
 
-@pytest.mark.parametrize('concat', [False, True])
-def test_scene_e2e_tiny_oracle_vs_reference_api(concat):
+@pytest.mark.parametrize('concat,gold', [(False, 'scene_e2e_tiny'), (True, 'scene_e2e_concat_tiny'), (False, 'scene_e2e_O2_tiny')])
+def test_scene_e2e_tiny_oracle_vs_reference_api(concat, gold):
     """Whole boundary on the CPU oracle vs the reference's own ``SGDiff.sample_box_and_shape`` (tiny widths):
     setup GCNs -> 100-step layout loop -> rel_s_mlp -> 4-step DDIM -> VQ-VAE decode.  ``concat``: the
-    config/full_concat_mp.yaml family (c_s enters the shape denoiser as an input channel)."""
+    config/full_concat_mp.yaml family (c_s enters the shape denoiser as an input channel).  ``scene_e2e_O2_tiny``: the
+    smallest scene (one object + the scene node, one triple)."""
     from echoscene_amd.model.scene import SGDiff
-    g = load_golden('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny')
+    g = load_golden(gold)
     objs, triples = g['objs'], g['triples']
     O = objs.shape[0]
     tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
