@@ -539,16 +539,19 @@ def vqvae_decode_no_quant(sd, z):
 #      (EchoLayout differs only in the manipulator's predicate table, EchoLayout.py:154)
 # --------------------------------------------------------------------------------------
 def scene_setup(sd, objs, triples, text_feat, rel_feat, model_type='echoscene', change_noise=None,
-                embedding_dim=64):
-    """Returns obj_embed_ (uc_b) and latent (c_b) for a plain ``sample`` (no edits)."""
+                embedding_dim=64, clip=True):
+    """Returns obj_embed_ (uc_b) and latent (c_b) for a plain ``sample`` (no edits; with ``change_noise`` [O, 64] the manipulator
+    output of sample_with_changes, EchoScene.py:422-439).  ``clip=False``: no CLIP features, the node / predicate vectors are the
+    embeddings alone (EchoScene.py:151-153,188-190)."""
     edges, p = _edges(triples)
-    obj_embed = torch.cat([text_feat, sd['obj_embeddings_ec.weight'][objs]], dim=1)
-    pred_embed = torch.cat([rel_feat, sd['pred_embeddings_ec.weight'][p]], dim=1)
+    cat = (lambda f, e: torch.cat([f, e], dim=1)) if clip else (lambda f, e: e)
+    obj_embed = cat(text_feat, sd['obj_embeddings_ec.weight'][objs])
+    pred_embed = cat(rel_feat, sd['pred_embeddings_ec.weight'][p])
     latent, _ = gcn_net(sd, 'gconv_net_ec', obj_embed, pred_embed, edges)
     change = torch.zeros(objs.shape[0], embedding_dim) if change_noise is None else change_noise
     latent_ = torch.cat([latent, change], dim=1)
     ptab = 'pred_embeddings_ec.weight' if model_type == 'echoscene' else 'pred_embeddings_man_dc.weight'
-    pred_embed_m = torch.cat([rel_feat, sd[ptab][p]], dim=1)
+    pred_embed_m = cat(rel_feat, sd[ptab][p])
     man_in = torch.cat([latent_, obj_embed], dim=1)
     latent_m, _ = gcn_net(sd, 'gconv_net_manipulation', man_in, pred_embed_m, edges)
     return obj_embed, latent_m, latent

@@ -520,7 +520,10 @@ class _SGDiffHarness:
     """The reference's own SGDiff on CPU (SURVEY.md 8(c) recipe) with both loops' noise injected; shared by the
     end-to-end and the editing cases."""
 
-    def __init__(self, typ, concat, O=8, graph_seed=9):
+    def __init__(self, typ, concat, O=8, graph_seed=9, clip=True, residual=True, replace_latent=False, t_emb=True):
+        """``clip`` / ``residual`` / ``replace_latent``: the SGDiff constructor flags (SGDiff.py:8-9); ``clip=False`` also sets
+        ``denoiser_kwargs.using_clip`` as scripts/eval_3dfront.py:386 does.  ``t_emb=False``: the layout denoiser_kwargs carry no
+        ``enable_t_emb`` key (config/box.yaml, config/full.yaml): UNet1DModel then builds without box_time_emb (denoise_net.py:505)."""
         import tempfile
         self.tmp = tempfile.mkdtemp(prefix='golden_e2e_')
         vq = _vqvae(32, 64)
@@ -529,13 +532,16 @@ class _SGDiffHarness:
         torch.save(vq.state_dict(), vq_path)
         opt = escfg.tiny_diff_opt(device='cpu', logs_dir=self.tmp, vq_ckpt=vq_path, concat=concat)
         opt.misc.debug = 0
+        if not t_emb:
+            del opt.layout_branch.denoiser_kwargs['enable_t_emb']
+        opt.layout_branch.denoiser_kwargs.using_clip = clip              # scripts/eval_3dfront.py:386
         import model.networks.diffusion_shape.echo2shape as e2s
         e2s.init_mesh_renderer = lambda **k: None
         from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
         DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
         from model.SGDiff import SGDiff
-        m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
-                   gconv_pooling='avg', with_angles=True, clip=True, separated=False)
+        m = SGDiff(typ, opt, synth.VOCAB, replace_latent=replace_latent, with_changes=True, residual=residual,
+                   gconv_pooling='avg', with_angles=True, clip=clip, separated=False)
         synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), seed=0, prefix='e2e.diff.')
         if typ == 'echoscene':
             fill(m.diff.ShapeDiff.df, 'e2e.shape_df.')
@@ -629,6 +635,70 @@ def case_scene_edit():
         out.update(objs=h.objs, triples=h.triples)
     out.update(manipulated=np.array(manipulated), missing=np.array(missing))
     save('scene_edit_tiny', **out)
+
+
+def case_unet1d_no_temb():
+    """the layout denoiser as config/box.yaml and config/full.yaml build it -- their denoiser_kwargs carry NO
+    ``enable_t_emb`` key, so UNet1DModel takes its default False (denoise_net.py:505): no box_time_emb, the box GCN's node
+    vectors are [obj_embed 640 | box 64] (denoise_net.py:735-740, 758-771).  Full width: one forward at O = 8 and O = 32 and 10
+    steps of the 1000-step loop; tiny width: the whole 100-step loop (BASELINE configs[0] shape)."""
+    from model.networks.diffusion_layout.denoise_net import UNet1DModel
+    for tag, mc, ctx in (('full', 512, 1280), ('tiny', 128, 128)):
+        kw = dict(escfg.layout_denoiser_kwargs(mc))
+        kw['concat_dim'] = kw['crossattn_dim'] = ctx
+        del kw['enable_t_emb']
+        net = UNet1DModel(**kw)
+        assert not net.enable_t_emb and not hasattr(net, 'box_time_emb')
+        fill(net, 'unet1d_%s_no_temb.' % tag)
+        out = {}
+        if tag == 'full':
+            for O, sg in ((8, 4), (32, 5)):
+                objs, triples = synth.synthetic_graph(O, seed=sg)
+                box = rnd((O, 8), 30 + O)
+                oe = rnd((O, 640), 40 + O)
+                t = torch.full((O,), 617, dtype=torch.int64)
+                with torch.no_grad():
+                    eps = net(box, oe, triples, t).squeeze(-1)
+                out.update({'box%d' % O: box, 'obj_embed%d' % O: oe, 'triples%d' % O: triples, 'eps%d' % O: eps})
+            noise = synth.layout_noise(8, 8, 1000, seed=7)[:11]
+            oe, triples, x, traj, _ = _layout_loop(net, kw, 8, 4, 1000, 10, noise)
+            out.update({'loop_obj_embed': oe, 'loop_triples': triples, 'loop_x10': x, 'loop_x1': traj[0]})
+            save('unet1d_full_no_temb', **out)
+        else:
+            noise = synth.layout_noise(8, 8, 100, seed=7)
+            oe, triples, x, _, _ = _layout_loop(net, kw, 8, 3, 100, 100, noise)
+            save('layout_loop_tiny_no_temb', obj_embed=oe, triples=triples, x_final=x)
+
+
+def case_scene_flags():
+    """the other corner of the SGDiff flag matrix (SGDiff.py:8-30): ``clip=False`` (no CLIP features: node /
+    predicate vectors are the 128-d embeddings only, EchoScene.py:45-73,151-153; denoiser_kwargs.using_clip False as
+    eval_3dfront.py:386 sets it), ``residual=False`` (setup GCNs without the skip projections, model/graph.py:205-209),
+    ``replace_latent=True`` (editing: ALL latents come from the manipulator, EchoScene.py:440-448) and a layout denoiser
+    without ``enable_t_emb`` (config/full.yaml / box.yaml).  Through the reference's own API: sample_box_and_shape for both model
+    types and sample_boxes_and_shape_with_changes for echoscene (gen_shape=True)."""
+    out = {}
+    manipulated = [5, 2]
+    for typ in ('echoscene', 'echolayout'):
+        h = _SGDiffHarness(typ, False, clip=False, residual=False, replace_latent=True, t_emb=False)
+        m = h.m
+        assert not m.diff.clip and m.diff.replace_all_latent
+        d = h.call(lambda: m.sample_box_and_shape(h.objs, h.triples, h.tf, h.rf, gen_shape=(typ == 'echoscene')))
+        for k, v in d.items():
+            if v is not None:
+                out['%s_%s' % (typ, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+        dec = (h.objs, h.triples, h.tf, h.rf)
+        np.random.seed(123)
+        keep, d = h.call(lambda: m.sample_boxes_and_shape_with_changes(*dec, *dec, manipulated, **(
+            {} if typ == 'echolayout' else {'gen_shape': True})))
+        out['%s_chg_keep' % typ] = keep
+        out['%s_chg_rel' % typ] = m.diff.LayoutDiff.rel
+        for k, v in d.items():
+            if v is not None:
+                out['%s_chg_%s' % (typ, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+        out.update(objs=h.objs, triples=h.triples)
+    out.update(manipulated=np.array(manipulated))
+    save('scene_flags_tiny', **out)
 
 
 def case_temb():
@@ -794,7 +864,7 @@ def case_gcn_ragged():
              cfg=np.array([96, 32, 3, 64, 1, 1, 80]))
 
 
-CASES = dict(gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

@@ -155,11 +155,13 @@ def test_gcn_vs_reference_golden(dev, tag):
     _close(p, g['out_pred'], 3e-5)
 
 
-def _layout(dev, mc, ctx, prefix, time_num):
+def _layout(dev, mc, ctx, prefix, time_num, t_emb=True):
     from echoscene_amd.model.unet import UNet1DModel
     from echoscene_amd.samplers import LayoutDenoiser
     kw = dict(escfg.layout_denoiser_kwargs(mc))
     kw['concat_dim'] = kw['crossattn_dim'] = ctx
+    if not t_emb:
+        del kw['enable_t_emb']              # config/box.yaml, config/full.yaml: no key -> the constructor's default (False)
     net = UNet1DModel(**kw)
     synth.seeded_fill_(net, prefix=prefix)
     return LayoutDenoiser(net, escfg.layout_diffusion_kwargs(time_num), dev)
@@ -194,6 +196,24 @@ def test_unet1d_full_vs_reference_golden(dev):
         _close(eps, g['eps%d' % O], 1e-4)
     noise = synth.layout_noise(8, 8, 1000, seed=7)[:11]
     x = den.sample(g['loop_obj_embed'], g['loop_triples'], noise, n_steps=10)
+    _close(x, g['loop_x10'], 2e-4)
+
+
+def test_layout_denoiser_without_time_embedding_vs_reference_golden(dev):
+    """config/box.yaml / config/full.yaml build the layout denoiser without ``enable_t_emb`` (denoise_net.py:505,735-740,766-768):
+    the box GCN's node vectors are [obj_embed 640 | box 64], no box_time_emb.  Goldens from the reference module: the whole 100-step
+    tiny loop; full width: eps at O = 8 / O = 32 (BASELINE configs[1] size) and 10 steps of the 1000-step loop."""
+    g = load_golden('layout_loop_tiny_no_temb')
+    den = _layout(dev, 128, 128, 'unet1d_tiny_no_temb.', 100, t_emb=False)
+    assert not den.net.enable_t_emb and den.w.box_t is None
+    x = den.sample(g['obj_embed'], g['triples'], synth.layout_noise(8, 8, 100, seed=7))
+    _close(x, g['x_final'], 2e-4)
+    g = load_golden('unet1d_full_no_temb')
+    den = _layout(dev, 512, 1280, 'unet1d_full_no_temb.', 1000, t_emb=False)
+    for O in (8, 32):
+        eps = den.eps(g['box%d' % O], g['obj_embed%d' % O], g['triples%d' % O], iteration=999 - 617)
+        _close(eps, g['eps%d' % O], 1e-4)
+    x = den.sample(g['loop_obj_embed'], g['loop_triples'], synth.layout_noise(8, 8, 1000, seed=7)[:11], n_steps=10)
     _close(x, g['loop_x10'], 2e-4)
 
 

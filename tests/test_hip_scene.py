@@ -82,10 +82,11 @@ def test_sgdiff_api_end_to_end_vs_reference_golden(typ, concat, gold):
         assert 'shapes' not in d
 
 
-def _build_sgdiff(typ, concat):
+def _build_sgdiff(typ, concat, opt=None, **flags):
     from model.SGDiff import SGDiff
-    m = SGDiff(typ, escfg.tiny_diff_opt('cuda', concat=concat), synth.VOCAB, replace_latent=False, with_changes=True,
-               residual=True, gconv_pooling='avg', with_angles=True, clip=True, separated=False)
+    kw = dict(replace_latent=False, with_changes=True, residual=True, gconv_pooling='avg', with_angles=True, clip=True, separated=False)
+    kw.update(flags)
+    m = SGDiff(typ, opt or escfg.tiny_diff_opt('cuda', concat=concat), synth.VOCAB, **kw)
     synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), prefix='e2e.diff.')
     if typ == 'echoscene':
         synth.seeded_fill_(m.diff.ShapeDiff.df, prefix='e2e.shape_df.')
@@ -155,6 +156,41 @@ def test_sgdiff_editing_vs_reference_golden(fam, typ, concat):
         # the model-level call returns keep as a python list (EchoLayout.py:394-401)
         k2, _ = m.diff.sampleBoxes_with_additions(*enc, *dec, missing, layout_noise=kw['layout_noise'])
         assert isinstance(k2, list) and k2 == [0 if i in added else 1 for i in range(O)]
+
+
+@pytest.mark.parametrize('typ', ['echoscene', 'echolayout'])
+def test_sgdiff_flag_matrix_vs_reference_golden(typ):
+    """The other corner of the constructor's flag matrix (SGDiff.py:8-30; golden: make_golden.py case_scene_flags, the reference's own
+    API): clip=False (128-d node vectors, denoiser_kwargs.using_clip False as eval_3dfront.py:386 sets it), residual=False (setup
+    GCNs without skip projections), replace_latent=True (editing takes every latent from the manipulator, EchoScene.py:440-448) and a
+    layout denoiser WITHOUT enable_t_emb (config/full.yaml / box.yaml carry no such key).  Plain sampling and with_changes."""
+    g = load_golden('scene_flags_tiny')
+    objs, triples = g['objs'], g['triples']
+    O = objs.shape[0]
+    tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
+    opt = escfg.tiny_diff_opt('cuda')
+    del opt.layout_branch.denoiser_kwargs['enable_t_emb']
+    opt.layout_branch.denoiser_kwargs.using_clip = False
+    m = _build_sgdiff(typ, False, opt=opt, clip=False, residual=False, replace_latent=True)
+    assert not m.diff.LayoutDiff.df.model.enable_t_emb
+    kw = dict(layout_noise=synth.layout_noise(O, 8, 100, seed=7))
+    if typ == 'echoscene':
+        kw.update(shape_noise=synth.shape_noise(seed=7), gen_shape=True)
+    dec = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
+    d = m.sample_box_and_shape(*dec, **kw)
+    for k in ('sizes', 'translations', 'angles'):
+        assert _rel(d[k], g['%s_%s' % (typ, k)]) < 1e-4, k
+    if typ == 'echoscene':
+        _check_sdf(d['shapes'], g['echoscene_shapes'], 'flags: plain')
+    manipulated = [int(v) for v in g['manipulated']]
+    np.random.seed(123)
+    keep, d = m.sample_boxes_and_shape_with_changes(*dec, *dec, manipulated, **kw)
+    assert torch.equal(keep.cpu(), g[typ + '_chg_keep'])
+    assert _rel(m.diff.LayoutDiff.rel, g[typ + '_chg_rel']) < 1e-4
+    for k in ('sizes', 'translations', 'angles'):
+        assert _rel(d[k], g['%s_chg_%s' % (typ, k)]) < 1e-4, k
+    if typ == 'echoscene':
+        _check_sdf(d['shapes'], g['echoscene_chg_shapes'], 'flags: with_changes')
 
 
 def test_sgdiff_editing_index_edge_cases():

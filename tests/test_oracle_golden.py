@@ -40,9 +40,11 @@ def test_gcn(tag):
     _close(p, g['out_pred'], 1e-5)
 
 
-def _unet1d_sd(mc, ctx, prefix):
+def _unet1d_sd(mc, ctx, prefix, t_emb=True):
     kw = dict(escfg.layout_denoiser_kwargs(mc))
     kw['concat_dim'] = kw['crossattn_dim'] = ctx
+    if not t_emb:
+        del kw['enable_t_emb']              # config/box.yaml, config/full.yaml: no key -> the constructor's default (False)
     return seeded_state_dict(UNet1DModel(**kw), prefix)
 
 
@@ -86,6 +88,30 @@ def test_unet1d_full():
     x = orc.layout_sample_loop(sd, g['loop_obj_embed'], g['loop_triples'], noise, time_num=1000,
                                n_steps=10, trace=tr)
     _close(tr[0], g['loop_x1'], 5e-5)
+    _close(x, g['loop_x10'], 1e-4)
+
+
+def test_layout_loop_tiny_without_time_embedding():
+    """config/box.yaml / full.yaml: the layout denoiser without ``enable_t_emb`` (denoise_net.py:505,735-740,766-768): the box GCN's
+    node vectors are [obj_embed | box] only.  All 100 steps of the tiny loop vs the reference's own DiffusionPoint."""
+    g = load_golden('layout_loop_tiny_no_temb')
+    sd = _unet1d_sd(128, 128, 'unet1d_tiny_no_temb.', t_emb=False)
+    assert not any(k.startswith('box_time_emb') for k in sd)
+    x = orc.layout_sample_loop(sd, g['obj_embed'], g['triples'], synth.layout_noise(8, 8, 100, seed=7), time_num=100,
+                               enable_t_emb=False)
+    _close(x, g['x_final'], 1e-4)
+
+
+@pytest.mark.slow
+def test_unet1d_full_without_time_embedding():
+    g = load_golden('unet1d_full_no_temb')
+    sd = _unet1d_sd(512, 1280, 'unet1d_full_no_temb.', t_emb=False)
+    for O in (8, 32):
+        t = torch.full((O,), 617, dtype=torch.int64)
+        eps = orc.unet1d_forward(sd, g['box%d' % O], g['obj_embed%d' % O], g['triples%d' % O], t, enable_t_emb=False)
+        _close(eps, g['eps%d' % O], 5e-5)
+    noise = synth.layout_noise(8, 8, 1000, seed=7)[:11]
+    x = orc.layout_sample_loop(sd, g['loop_obj_embed'], g['loop_triples'], noise, time_num=1000, n_steps=10, enable_t_emb=False)
     _close(x, g['loop_x10'], 1e-4)
 
 
@@ -174,6 +200,55 @@ def test_scene_e2e_tiny_oracle_vs_reference_api(concat, gold):
             sdf = orc.vqvae_decode_no_quant(vsd, z)
             assert tuple(sdf.shape) == (O, 1, 64, 64, 64)
             _close(sdf[:, :, ::4, ::4, ::4], g['echoscene_shapes'], 2e-3)
+
+
+def _flags_opt(device):
+    """tiny_diff_opt as tests/golden/make_golden.py case_scene_flags builds it: no ``enable_t_emb`` key (config/full.yaml), using_clip
+    False (scripts/eval_3dfront.py:386)"""
+    opt = escfg.tiny_diff_opt(device)
+    del opt.layout_branch.denoiser_kwargs['enable_t_emb']
+    opt.layout_branch.denoiser_kwargs.using_clip = False
+    return opt
+
+
+@pytest.mark.parametrize('typ', ['echoscene', 'echolayout'])
+def test_scene_flag_matrix_oracle_vs_reference_api(typ):
+    """The other corner of the SGDiff flag matrix (SGDiff.py:8-30) -- clip=False, residual=False, replace_latent=True, layout denoiser
+    without enable_t_emb -- against the reference's own sample_box_and_shape and sample_boxes_and_shape_with_changes."""
+    import numpy as np
+    from echoscene_amd.model.scene import SGDiff
+    g = load_golden('scene_flags_tiny')
+    objs, triples = g['objs'], g['triples']
+    O = objs.shape[0]
+    tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
+    m = SGDiff(typ, _flags_opt('cpu'), synth.VOCAB, replace_latent=True, residual=False, with_angles=True, clip=False)
+    sd = seeded_state_dict(m.diff, 'e2e.diff.')
+    assert not any('linear_projection' in k for k in sd if k.startswith('gconv_net_')), 'residual=False: no skip projections in the setup GCNs'
+    lsd = {k[len('LayoutDiff.df.model.'):]: v for k, v in sd.items() if k.startswith('LayoutDiff.df.model.')}
+    noise = synth.layout_noise(O, 8, 100, seed=7)
+    manipulated = [int(v) for v in g['manipulated']]
+    np.random.seed(123)
+    change = torch.zeros(O, 64)
+    for i in sorted(manipulated):
+        change[i] = torch.from_numpy(np.random.normal(0, 1, 64)).float()
+    for tag, ch in (('', None), ('chg_', change)):
+        oe, latent_m, _ = orc.scene_setup(sd, objs, triples, tf, rf, model_type=typ, change_noise=ch, clip=False)
+        assert oe.shape[1] == 128
+        if ch is not None:                                   # replace_latent=True: every latent is the manipulator's (EchoScene.py:440-448)
+            _close(latent_m, g[typ + '_chg_rel'], 2e-5)
+        x = orc.layout_sample_loop(lsd, oe, triples, noise, time_num=100, enable_t_emb=False)
+        _close(x[:, 0:3], g[typ + '_' + tag + 'sizes'], 2e-4)
+        _close(x[:, 3:6], g[typ + '_' + tag + 'translations'], 2e-4)
+        _close(x[:, 6:8], g[typ + '_' + tag + 'angles'], 2e-4)
+        if typ == 'echoscene':
+            dsd = seeded_state_dict(m.diff.ShapeDiff.df, 'e2e.shape_df.')
+            dsd = {k[len('diffusion_net.'):]: v for k, v in dsd.items()}
+            z = orc.shape_sample_loop(dsd, orc.rel_s(sd, oe), triples, synth.shape_noise(seed=7), S=4)
+            sdf = orc.vqvae_decode_no_quant(seeded_state_dict(m.diff.ShapeDiff.vqvae, 'e2e.vqvae.'), z)
+            _close(sdf[:, :, ::4, ::4, ::4], g['echoscene_' + tag + 'shapes'], 2e-3)
+    if typ == 'echoscene':
+        keep = g['echoscene_chg_keep']
+        assert [int(v) for v in keep.flatten()] == [0 if i in manipulated else 1 for i in range(O)]
 
 
 # --------------------------------------------------------------------------------------------------------
