@@ -61,12 +61,20 @@ def build_shape(dev, O, seed, triples, rank=0, world=1, deterministic=True):
     return df, den, uc
 
 
-def time_dominant_kernel(ss, dev, reps=3):
+def _stats(xs, nd=4):
+    """median / min / max of a list of repetitions (the JSON shows the spread, VERDICT r3 #5)"""
+    xs = sorted(float(x) for x in xs)
+    n = len(xs)
+    med = xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+    return {'median': round(med, nd), 'min': round(xs[0], nd), 'max': round(xs[-1], nd), 'reps': n}
+
+
+def time_dominant_kernel(ss, dev, reps=5):
     """roofline.achieved for the dominant kernel: the step's conv launches that the library dispatches to the
     warp-specialised 256-row-tile kernel k_conv_ws -- >= 256 tiles of 256 rows (the 16^3 and 16x8x8 levels), or fewer tiles with K
     split over them (the 16x4x4 level; the rule below mirrors es_conv_mfma_f16) -- are replayed as their own plan and timed with
     HIP events on the stream they are launched on (split launches include their fixed-order reduction kernel).
-    Returns (TFLOP/s, avg us, launches)."""
+    ``reps`` separately timed replays; returns (TFLOP/s at the median replay, median avg us per launch, launches, _stats of the avg us)."""
     from echoscene_amd import hip
     from echoscene_amd.plan import Builder
     plan = ss['plan']
@@ -95,17 +103,20 @@ def time_dominant_kernel(ss, dev, reps=3):
     sub = b.finish()
     sub.run()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    per = []
     for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         sub.run()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    return flops / us / 1e6, us / len(ops), len(ops)
+        e1.record()
+        torch.cuda.synchronize()
+        per.append(e0.elapsed_time(e1) * 1e3)
+    st = _stats([u / len(ops) for u in per], 2)
+    us = st['median'] * len(ops)
+    return flops / us / 1e6, us / len(ops), len(ops), st
 
 
-PMC_TRAFFIC_FILES = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def _pmc_file():
@@ -262,6 +273,12 @@ def cpu_baseline(net, obj_embed, triples, O, full, df=None, uc=None):
             ts = cpu_baseline_shape(df, uc, triples, Os)
             r['shape_s_per_step_O%d' % Os] = round(ts, 3)
             r['full_steps_per_s'] = round(1.0 / (1.0 / v + ts * (O / Os)), 5)
+            if nt <= 8:
+                # linearity check of the extrapolation: the same protocol on twice the objects; per-object cost
+                # should match (it does not have to: the survey's probe of the reference at O = 32 was ~5x the scaled figure)
+                ts2 = cpu_baseline_shape(df, uc, triples, 2 * Os, timed=1)
+                r['shape_s_per_step_O%d' % (2 * Os)] = round(ts2, 3)
+                r['per_object_cost_ratio_O%d_vs_O%d' % (2 * Os, Os)] = round(ts2 / (2 * ts), 3)
         res[nt] = r
     torch.set_num_threads(default_threads)
     key = 'full_steps_per_s' if full else 'layout_steps_per_s'
@@ -271,6 +288,10 @@ def cpu_baseline(net, obj_embed, triples, O, full, df=None, uc=None):
                      (('shape: 1 warm-up + 2 timed DDIM steps on %d of the %d objects, scaled x%d (cost is linear in objects); '
                        % (Os, O, O // Os)) if full else '') + 'torch-CPU oracle fp32; value = the faster of the thread counts below',
            'by_threads': [res[k] for k in sorted(res, reverse=True)]}
+    if full:
+        out.update({'objects_timed': Os, 'objects_of_workload': O, 'extrapolated': True,
+                    'extrapolation': 'shape step timed on %d objects and scaled x%d; SURVEY.md 8(d) probe of the reference itself at O = 32 on 8 '
+                                     'threads of another host: 57.3 s per shape step (0.0175 steps/s)' % (Os, O // Os)})
     if 8 in res:
         out['cores_8'] = res[8][key]
     return out
@@ -287,12 +308,15 @@ def main():
     ap.add_argument('--scenes-per-gpu', type=int, default=2,
                     help='weak scaling: scenes per GPU (configs[4] is 8 per GPU; 2 keeps the default run inside ~20 GB)')
     ap.add_argument('--no-sub-records', action='store_true')
-    ap.add_argument('--deterministic', action='store_true',
-                    help='N > 1, strong scaling: shards reproduce the single-GPU latents bit for bit (split-K / GroupNorm tiling chosen '
-                         'from the global object count); off = every rank tunes them to its own share (faster at few objects per GPU)')
+    ap.add_argument('--deterministic', action='store_true', help='(the default since round 4; kept for old command lines)')
+    ap.add_argument('--tuned', action='store_true',
+                    help='N > 1, strong scaling: every rank tunes split-K / GroupNorm tiling to its own share of the objects.  Default '
+                         '(off): shards reproduce the single-GPU latents BIT FOR BIT (SURVEY.md 8(e)): the tiling is a function of the '
+                         'layer and the global object count only')
     ap.add_argument('--fuse-loops', type=int, default=-1,
                     help='1: one hipGraph per full step with the layout step as a parallel branch of the shape step; 0: two streams; '
                          '-1: the default of this build')
+    ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed K-step region (value = the median repetition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--check', action='store_true',
@@ -343,7 +367,7 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=a.deterministic)
+        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=not a.tuned)
         noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
         sden.sample(uc, triples_all, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
@@ -384,42 +408,63 @@ def main():
         ss['x'].copy_(xall[ss.get('lo', 0):ss.get('hi', O_all)])
         torch.cuda.synchronize()
     s_lay, s_shp = torch.cuda.Stream(), torch.cuda.Stream()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    t0 = time.perf_counter()
-    if fused is not None:
-        with torch.cuda.stream(s_shp):
-            ev[0].record(); ev[2].record()
-            done = 0
-            while done < a.steps:
-                n = min(a.steps - done, sden.S)
-                fused.sample(ss['step'], 0, n, use_graph=use_graph)
+
+    def timed_region():
+        """EXACTLY a.steps steps, bracketed by a barrier + device synchronisation on both sides; returns (wall s, layout-loop ms,
+        shape-loop ms) -- in the fused case both event pairs bracket the fused loop."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t0 = time.perf_counter()
+        if fused is not None:
+            with torch.cuda.stream(s_shp):
+                ev[0].record(); ev[2].record()
+                done = 0
+                while done < a.steps:
+                    n = min(a.steps - done, sden.S)
+                    fused.sample(ss['step'], 0, n, use_graph=use_graph)
+                    done += n
+                ev[1].record(); ev[3].record()
+        with torch.cuda.stream(s_lay):
+            ev[0].record() if fused is None else None
+            done = a.steps if (fused is not None or fused_sharded) else 0
+            while done < a.steps:                   # the layout loop is 1000 iterations long; K may exceed it
+                n = min(a.steps - done, den.T)
+                st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
                 done += n
-            ev[1].record(); ev[3].record()
-    with torch.cuda.stream(s_lay):
-        ev[0].record() if fused is None else None
-        done = a.steps if (fused is not None or fused_sharded) else 0
-        while done < a.steps:                   # the layout loop is 1000 iterations long; K may exceed it
-            n = min(a.steps - done, den.T)
-            st['plan'].sample(st['step'], 0, n, use_graph=use_graph)
-            done += n
-        ev[1].record() if fused is None else None
-    with torch.cuda.stream(s_shp):
-        ev[2].record() if fused is None else None
-        done = a.steps if fused is not None else 0
-        while full and done < a.steps:          # the DDIM loop is 100 iterations long
-            n = min(a.steps - done, sden.S)
-            if sh_world == 1:
-                ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
-            else:                               # per-step echo all-gather over RCCL (parallel.sharded_ddim_loop)
-                from echoscene_amd.parallel import sharded_ddim_loop
-                sden._cur, sden._use_graph = ss, use_graph
-                sharded_ddim_loop(sden, O_all, n, sh_world)
-            done += n
-        ev[3].record() if fused is None else None
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    wall = time.perf_counter() - t0
+            ev[1].record() if fused is None else None
+        with torch.cuda.stream(s_shp):
+            ev[2].record() if fused is None else None
+            done = a.steps if fused is not None else 0
+            while full and done < a.steps:          # the DDIM loop is 100 iterations long
+                n = min(a.steps - done, sden.S)
+                if sh_world == 1:
+                    ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph)
+                else:                               # per-step echo all-gather over RCCL (parallel.sharded_ddim_loop)
+                    from echoscene_amd.parallel import sharded_ddim_loop
+                    sden._cur, sden._use_graph = ss, use_graph
+                    sharded_ddim_loop(sden, O_all, n, sh_world)
+                done += n
+            ev[3].record() if fused is None else None
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        w = time.perf_counter() - t0
+        tm = torch.tensor([w], device=dev if backend == 'nccl' else 'cpu')
+        if dist is not None:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)          # max over ranks
+        return float(tm.item()), ev[0].elapsed_time(ev[1]), (ev[2].elapsed_time(ev[3]) if full else 0.0)
+
+    # The K-step region is timed a.reps times (each repetition with its own barrier / synchronise bracket); `value` is the MEDIAN
+    # repetition, min / max go into the line next to it (boxes and runs differ by a few per cent: VERDICT r3 #5).
+    reps = 1 if a.check else max(1, a.reps)
+    regions = [timed_region() for _ in range(reps)]
+    walls = sorted(r[0] for r in regions)
+    wall = walls[len(walls) // 2] if len(walls) % 2 else 0.5 * (walls[len(walls) // 2 - 1] + walls[len(walls) // 2])
+    mid = min(regions, key=lambda r: abs(r[0] - wall))
+    lay_ms, shp_ms = mid[1], mid[2]
     check = None
     if full and a.check:                        # (before the per-loop replays below advance the state again)
         import zlib
@@ -430,28 +475,29 @@ def main():
             z = torch.cat(parts, 0)
         check = {'latents_crc32': zlib.crc32(z.numpy().tobytes()), 'objects': int(z.shape[0]),
                  'abs_sum': float(z.double().abs().sum())}
+    lay_reps, shp_reps = [r[1] / a.steps for r in regions], [r[2] / a.steps for r in regions]
     if fused is not None:
-        # per-loop figures for the record (outside the timed region): each loop alone on the idle GPU
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        # per-loop figures for the record (outside the timed region): each loop alone on the idle GPU, `reps` times each
         nn = min(a.steps, 50)
-        e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph)
-        e[1].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
-        e[2].record(); torch.cuda.synchronize()
-        solo = (e[0].elapsed_time(e[1]) * a.steps / nn, e[1].elapsed_time(e[2]) * a.steps / nn)
-    lay_ms, shp_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+        lay_reps, shp_reps = [], []
+        for _ in range(reps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph)
+            e[1].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
+            e[2].record(); torch.cuda.synchronize()
+            lay_reps.append(e[0].elapsed_time(e[1]) / nn)
+            shp_reps.append(e[1].elapsed_time(e[2]) / nn)
+        solo = (_stats(lay_reps)['median'] * a.steps, _stats(shp_reps)['median'] * a.steps)
     if fused_sharded:
         # the layout steps ran inside the sharded main graphs; for the record (outside the timed region): the layout loop alone
         e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         nn = min(a.steps, 50)
         e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph); e[1].record(); torch.cuda.synchronize()
         lay_ms = e[0].elapsed_time(e[1]) * a.steps / nn
+        lay_reps = [lay_ms / a.steps]
     fused_ms = None
     if fused is not None:
         fused_ms, (lay_ms, shp_ms) = lay_ms, solo
-    tmax = torch.tensor([wall], device=dev if backend == 'nccl' else 'cpu')
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
     assert torch.isfinite(st['x']).all(), 'non-finite layout state'
     if full:
         assert torch.isfinite(ss['x']).all(), 'non-finite shape latent'
@@ -460,19 +506,32 @@ def main():
         ms_per_step = wall * 1e3 / a.steps
         value = scenes * a.steps / wall           # scene-steps per second (scenes == 1 unless weak scaling)
         T = int(triples.shape[0])
+        rep = {'wall_ms_per_step': _stats([w * 1e3 / a.steps for w in walls]),
+               'value': _stats([scenes * a.steps / w for w in walls]),
+               'layout_ms_per_step': _stats(lay_reps), 'shape_ms_per_step': _stats(shp_reps) if full else None}
         lay = {'steps_per_s': round(a.steps / (lay_ms * 1e-3), 2), 'ms_per_step': round(lay_ms / a.steps, 4),
+               'ms_per_step_min_max': [rep['layout_ms_per_step']['min'], rep['layout_ms_per_step']['max']],
                'kernels_per_step': st['plan'].n_ops, 'weight_bytes_per_step': st['plan'].weight_bytes,
                'hbm_GBps_algorithmic': round(st['plan'].weight_bytes / (lay_ms * 1e-3 / a.steps) / 1e9, 1)}
         if full:
             flops = ss['plan'].flops          # this rank's share of the step
             ach_step = flops / (shp_ms * 1e-3 / a.steps) / 1e12
             dom = time_dominant_kernel(ss, dev)
-            ach, dom_us, dom_n = dom if dom else (ach_step, None, 0)
+            ach, dom_us, dom_n, dom_st = dom if dom else (ach_step, None, 0, None)
+            t_sum = lay_ms / a.steps + shp_ms / a.steps              # full_steps/s = 1 / (t_layout_step + t_shape_step)
+            note = None
+            if fused_ms is not None and ms_per_step < shp_ms / a.steps:
+                note = ('the fused full step (%.3f ms) is shorter than the shape loop timed alone (%.3f ms): the two are separate '
+                        'measurements, %d repetitions each, and run-to-run variation on one box (see `repetitions`) exceeds the ~1 ms '
+                        'the layout branch adds' % (ms_per_step, shp_ms / a.steps, reps))
             out = {
                 'metric': 'denoising steps/sec (layout+SDF) for 32-node scene-graph, 64^3 SDF (3x16^3 latent), '
                           'full step = one DDPM layout step + one DDIM shape step over all objects',
                 'value': round(value, 4), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling,
+                'value_min_max': [rep['value']['min'], rep['value']['max']],
+                'full_steps_per_s_sum': round(1e3 / t_sum, 4),
+                'repetitions': rep, 'note': note,
                 'vs_baseline': None, 'dtype': 'f16 MFMA operands / f32 accumulate (shape UNet); f32 (layout, GCN)',
                 'data': 'synthetic',
                 'config': {'workload': 'EchoScene full (layout+SDF) %d-node synthetic graph (T=%d), 3x16^3 latent -> '
@@ -481,17 +540,19 @@ def main():
                                                  'batch graph): no per-step collective' % (scenes_local, world)) if weak
                                           else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
                                                 '[O,64] codes every DDIM step over RCCL)' % world)),
-                           'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': bool(a.deterministic) if sh_world > 1 else None,
+                           'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': (not a.tuned) if sh_world > 1 else None,
                            'loops': ('one hipGraph per full step, layout step as a parallel branch '
                                                                               '(%.3f ms per step); layout / shape below: each loop alone' % (fused_ms / a.steps))
                            if fused_ms is not None else ('layout step as a parallel branch of the sharded main graph' if fused_sharded else 'two HIP streams'), 'layout': lay,
                            'shape': {'steps_per_s': round(a.steps / (shp_ms * 1e-3), 3),
                                      'ms_per_step': round(shp_ms / a.steps, 3),
+                                     'ms_per_step_min_max': [rep['shape_ms_per_step']['min'], rep['shape_ms_per_step']['max']],
                                      'kernels_per_step': ss['plan'].n_ops,
                                      'algorithmic_TFLOP_per_step': round(flops / 1e12, 3)}},
                 'roofline': {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                              'frac': round(ach / MFMA_F16_PEAK_TFLOPS, 4), 'traffic': pmc_traffic('k_conv_ws'), 'traffic_source': pmc_traffic_source(), 'kernel': 'k_conv_ws',
                              'launches_per_step': dom_n, 'avg_launch_us': None if dom_us is None else round(dom_us, 1),
+                             'avg_launch_us_min_max': None if dom_st is None else [dom_st['min'], dom_st['max']],
                              'whole_shape_step_TFLOPs': round(ach_step, 1),
                              'note': 'achieved = algorithmic FLOPs of the k_conv_ws launches of one shape step / their '
                                      'duration (HIP events on the launch stream, launches replayed back to back); '
@@ -505,6 +566,7 @@ def main():
                 'metric': 'denoising steps/sec (layout box-denoiser loop, 32-node scene graph, 1000-step DDPM)',
                 'value': round(value, 2), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                 'ms_per_step': round(ms_per_step, 5), 'higher_is_better': True, 'scaling': a.scaling,
+                'value_min_max': [rep['value']['min'], rep['value']['max']], 'repetitions': rep,
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'configs[1]: EchoLayout box diffusion, %d-node synthetic graph (T=%d triples), '
                                        '1000-step DDPM, HIP denoiser + graph conv' % (O, T),

@@ -506,9 +506,9 @@ extern "C" int es_linear_rows_slices(const es_linear_args* a, int* kb_per_slice)
 
 extern "C" int es_linear_rows_auto_slices(int K, int N, int kalign_cols) {
     // ~256 workgroups for TWO 16-row tiles (M = 32, one scene), slices of at least 128 columns (one k-block per wave), <= 8 slabs
-    static const char* env = getenv("ES_ROWS_SPLIT");     // A/B switch: 0 = never split, n = target workgroup count
-    int target = 256;
-    if (env) { target = atoi(env); if (target <= 0) return 0; }
+    // (a constant of the build, not an environment switch: the slice count decides where a K sum is cut, i.e. the fp32 bits.
+    //  Round-3 A/B, layout steps/s: target 128 -> 949, 256 -> 1093, 512 -> 958)
+    constexpr int target = 256;
     const int nkb = (K + 15) / 16, nct = (N + 15) / 16;
     int S = target / (2 * nct);
     if (S > 8) S = 8;

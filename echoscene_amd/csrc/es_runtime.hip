@@ -9,6 +9,7 @@
 #include "es_common.h"
 #include <vector>
 #include <cstdlib>
+#include <exception>
 
 static thread_local char g_err[512] = "";
 
@@ -274,18 +275,31 @@ bool encode_ptr(uint64_t p, const es_buffer_desc* bufs, int nb, uint64_t* out) {
 }
 }  // namespace
 
+// Buffer table entry = byte size; bit 63 set = SCRATCH: a buffer every byte of which the plan writes before it reads it
+// (activations, split-K workspace, statistics) -- its contents are not stored, the loader allocates and zero-fills it.
+constexpr uint64_t ES_BUF_SCRATCH = 1ull << 63;
+constexpr uint32_t ES_MAX_BUFFERS = 1u << 20, ES_MAX_OPS = 1u << 20, ES_MAX_REGIONS = 4096;
+
 struct es_model {
     std::vector<void*> bufs;
     std::vector<size_t> sizes;
     std::vector<RegionRec> regions;
     es_plan* plan = nullptr;
+    long schedule_len = -1;      // loop iterations the coefficient table holds ("coef" region / the update op's stride); -1 = no loop
 };
 
 extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buffer_desc* buffers, int n_buffers,
                              const es_region_desc* regions, int n_regions) {
     ES_REQUIRE(path && plan && buffers && n_buffers > 0, "es_model_save: bad args");
-    for (int i = 0; i < n_buffers; ++i)
-        ES_REQUIRE(buffers[i].bytes < (1ull << OFF_BITS), "es_model_save: buffer %d too large", i);
+    // (es_buffer_desc.bytes with bit 63 set marks a scratch buffer: listed, not dumped)
+    std::vector<es_buffer_desc> bd(buffers, buffers + n_buffers);
+    std::vector<bool> scratch(n_buffers);
+    for (int i = 0; i < n_buffers; ++i) {
+        scratch[i] = (bd[i].bytes & ES_BUF_SCRATCH) != 0;
+        bd[i].bytes &= ~ES_BUF_SCRATCH;
+        ES_REQUIRE(bd[i].bytes < (1ull << OFF_BITS), "es_model_save: buffer %d too large", i);
+    }
+    buffers = bd.data();
     std::vector<es_op> ops = plan->ops;
     size_t offs[64];
     for (size_t k = 0; k < ops.size(); ++k) {
@@ -306,7 +320,7 @@ extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buf
     h.abi = ES_ABI_VERSION; h.n_buffers = (uint32_t)n_buffers; h.n_ops = (uint32_t)ops.size(); h.n_regions = (uint32_t)n_regions;
     h.op_size = (uint32_t)sizeof(es_op);
     bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
-    for (int i = 0; i < n_buffers && ok; ++i) { const uint64_t b = buffers[i].bytes; ok = fwrite(&b, 8, 1, fp) == 1; }
+    for (int i = 0; i < n_buffers && ok; ++i) { const uint64_t b = buffers[i].bytes | (scratch[i] ? ES_BUF_SCRATCH : 0); ok = fwrite(&b, 8, 1, fp) == 1; }
     for (int i = 0; i < n_regions && ok; ++i) {
         RegionRec r{};
         memcpy(r.name, regions[i].name, 32);
@@ -319,6 +333,7 @@ extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buf
     ok = ok && fwrite(ops.data(), sizeof(es_op), ops.size(), fp) == ops.size();
     std::vector<char> host;
     for (int i = 0; i < n_buffers && ok; ++i) {
+        if (scratch[i]) continue;
         host.resize(buffers[i].bytes);
         if (hipMemcpy(host.data(), buffers[i].ptr, buffers[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
         ok = fwrite(host.data(), 1, host.size(), fp) == host.size();
@@ -335,16 +350,28 @@ extern "C" void es_model_free(es_model* m) {
     delete m;
 }
 
-extern "C" es_model* es_model_load(const char* path) {
-    FILE* fp = path ? fopen(path, "rb") : nullptr;
-    if (!fp) { es_set_error("es_model_load: cannot open %s", path ? path : "(null)"); return nullptr; }
-    es_model* m = new es_model();
-    auto fail = [&](const char* why) -> es_model* { es_set_error("es_model_load(%s): %s", path, why); fclose(fp); es_model_free(m); return nullptr; };
+static es_model* model_load_impl(const char* path, FILE* fp, es_model* m) {
+    auto fail = [&](const char* why) -> es_model* { es_set_error("es_model_load(%s): %s", path, why); return nullptr; };
     ModelHeader h{};
     if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, ES_MODEL_MAGIC, 8)) return fail("not a model file");
     if (h.abi != ES_ABI_VERSION || h.op_size != sizeof(es_op)) return fail("written by another ABI version");
+    // the header is untrusted input: bound every count before it sizes an allocation
+    if (h.n_buffers == 0 || h.n_buffers > ES_MAX_BUFFERS || h.n_ops == 0 || h.n_ops > ES_MAX_OPS || h.n_regions > ES_MAX_REGIONS)
+        return fail("implausible header counts");
     m->sizes.resize(h.n_buffers);
-    for (uint32_t i = 0; i < h.n_buffers; ++i) { uint64_t b; if (fread(&b, 8, 1, fp) != 1) return fail("truncated buffer table"); m->sizes[i] = (size_t)b; }
+    std::vector<bool> scratch(h.n_buffers);
+    size_t free_b = 0, total_b = 0, need = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail("hipMemGetInfo failed");
+    for (uint32_t i = 0; i < h.n_buffers; ++i) {
+        uint64_t b;
+        if (fread(&b, 8, 1, fp) != 1) return fail("truncated buffer table");
+        scratch[i] = (b & ES_BUF_SCRATCH) != 0;
+        b &= ~ES_BUF_SCRATCH;
+        if (b >= (1ull << OFF_BITS)) return fail("implausible buffer size");
+        m->sizes[i] = (size_t)b;
+        need += (size_t)b;
+    }
+    if (need > total_b) return fail("the buffers exceed the device memory");
     m->regions.resize(h.n_regions);
     if (h.n_regions && fread(m->regions.data(), sizeof(RegionRec), h.n_regions, fp) != h.n_regions) return fail("truncated region table");
     std::vector<es_op> ops(h.n_ops);
@@ -353,6 +380,10 @@ extern "C" es_model* es_model_load(const char* path) {
     std::vector<char> host;
     for (uint32_t i = 0; i < h.n_buffers; ++i) {
         if (hipMalloc(&m->bufs[i], m->sizes[i] ? m->sizes[i] : 1) != hipSuccess) return fail("hipMalloc failed");
+        if (scratch[i]) {
+            if (hipMemset(m->bufs[i], 0, m->sizes[i]) != hipSuccess) return fail("hipMemset failed");
+            continue;
+        }
         host.resize(m->sizes[i]);
         if (fread(host.data(), 1, host.size(), fp) != host.size()) return fail("truncated buffer contents");
         if (hipMemcpy(m->bufs[i], host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("upload failed");
@@ -369,12 +400,35 @@ extern "C" es_model* es_model_load(const char* path) {
             *f = (uint64_t)m->bufs[bi] + off;
         }
     }
+    for (RegionRec& r : m->regions) {
+        r.name[31] = 0;
+        if (r.buffer >= h.n_buffers || r.offset > m->sizes[r.buffer] || r.bytes > m->sizes[r.buffer] - r.offset) return fail("region out of range");
+    }
+    // length of the schedule the loop's coefficient table holds: es_model_run refuses to step past it
     for (const RegionRec& r : m->regions)
-        if (r.buffer >= h.n_buffers || r.offset + r.bytes > m->sizes[r.buffer]) return fail("region out of range");
-    fclose(fp);
+        if (!strncmp(r.name, "coef", 32))
+            for (const es_op& op : ops)
+                if ((op.kind == ES_OP_DDPM || op.kind == ES_OP_DDIM) && op.u.update.coef_stride > 0)
+                    m->schedule_len = (long)(r.bytes / ((size_t)op.u.update.coef_stride * 4));
     m->plan = es_plan_create(ops.data(), (int)ops.size());
-    if (!m->plan) { es_model_free(m); return nullptr; }
-    return m;
+    return m->plan ? m : nullptr;
+}
+
+extern "C" es_model* es_model_load(const char* path) {
+    FILE* fp = path ? fopen(path, "rb") : nullptr;
+    if (!fp) { es_set_error("es_model_load: cannot open %s", path ? path : "(null)"); return nullptr; }
+    es_model* m = nullptr;
+    es_model* r = nullptr;
+    try {                                         // nothing may unwind through the C boundary (std::bad_alloc from a resize, ...)
+        m = new es_model();
+        r = model_load_impl(path, fp, m);
+    } catch (const std::exception& e) {
+        es_set_error("es_model_load(%s): %s", path, e.what());
+        r = nullptr;
+    }
+    fclose(fp);
+    if (!r && m) es_model_free(m);
+    return r;
 }
 
 extern "C" int es_model_region(const es_model* m, const char* name, void** dev_ptr, size_t* bytes) {
@@ -392,6 +446,9 @@ extern "C" int es_model_num_ops(const es_model* m) { return m && m->plan ? (int)
 
 extern "C" int es_model_run(es_model* m, int first_step, int n_steps, es_stream stream) {
     ES_REQUIRE(m && m->plan, "es_model_run: null model");
+    ES_REQUIRE(first_step >= 0 && n_steps >= 0, "es_model_run: first_step %d, n_steps %d", first_step, n_steps);
+    ES_REQUIRE(m->schedule_len < 0 || (long)first_step + n_steps <= m->schedule_len,
+               "es_model_run: iterations %d .. %d exceed the model's schedule (%ld steps)", first_step, first_step + n_steps, m->schedule_len);
     void* step = nullptr;
     if (int rc = es_model_region(m, "step", &step, nullptr)) return rc;
     return es_sampler_run(m->plan, (int32_t*)step, first_step, n_steps, 1, stream);

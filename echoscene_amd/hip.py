@@ -193,7 +193,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 4:
+        if L.es_abi_version() != 5:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

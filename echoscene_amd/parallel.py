@@ -7,8 +7,10 @@ UNet3D forward depends on the other objects only through the 64-d conv-pool code
 latents that feeds the shape GCN ("echo" message passing, openai_model_3d.py:800-814), so the only
 per-step exchange is an all-gather of [O_local, 64] floats (8 KB per step at O=32), after which
 every rank runs the tiny GCN redundantly on the full graph.  At the end the latents (or decoded
-SDFs) are all-gathered.  Results are identical to the single-GPU run because every kernel treats
-objects independently and the GCN is computed on the full graph on every rank.
+SDFs) are all-gathered.  With ``ShapeDenoiser(deterministic=True)`` (the default) the results are identical to the
+single-GPU run BIT FOR BIT: every kernel treats objects independently, the GCN is computed on the full graph on every
+rank, and every K split / partial-sum tiling is chosen from the layer and the GLOBAL object count (never from the rank's
+share).  ``deterministic=False`` lets each rank tune them to its share: same values up to fp32 summation order.
 """
 import torch
 
@@ -53,9 +55,9 @@ def sharded_ddim_loop(backend, num_objects, n_steps, world, group=None):
         step(i, codes_all)    -> advance this rank's latents by DDIM iteration i given all objects' codes
         latents_local()       -> [O_local, C, D, H, W]
         gather_buffers()      -> optional: pre-allocated (send block, receive buffer) of the exchange
-    Per step on the HIP path: ONE captured graph = stem ops, the RCCL all-gather of [block, 64] floats per rank, everything else
-    (backend.step_graph); where the collective cannot be captured (gloo in the CPU / one-GPU tests) the step is graph launch (stem),
-    all-gather, graph launch (rest) -- no allocation, no torch op in between.  Returns the full latents [O, C, D, H, W] on every
+    Per step on the HIP path: graph launch (stem), all-gather of [block, 64] floats per rank, graph launch (rest) -- no allocation,
+    no torch op in between; with ES_STEP_GRAPH=1 and every rank able to capture it (a collective decision, backend.step_graph)
+    ONE captured graph = stem ops, the RCCL all-gather, everything else.  Returns the full latents [O, C, D, H, W] on every
     rank.  A rank without objects (more ranks than objects) still joins every collective."""
     exchange = world > 1 or getattr(backend, 'force_exchange', False)
     bufs = backend.gather_buffers() if (exchange and hasattr(backend, 'gather_buffers')) else None

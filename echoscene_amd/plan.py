@@ -7,11 +7,23 @@ for device allocations, host-side weight preparation (BatchNorm folding, centre-
 concatenation of projection matrices) and host->device copies.
 """
 import ctypes as C
+import os
+
 import numpy as np
 import torch
 
 from . import hip
 from .hip import Seg, LinearArgs, UpdateArgs, CopyArgs, RowSelArgs, Op
+
+
+# K-slice choices of the rows planner.  They change where a K sum is cut -- i.e. the fp32 bits of the results -- so they are
+# CONSTANTS of the build, not environment switches (ADVICE r3: two processes / ranks with different environments would break the
+# bit-for-bit claims: collated batch == single scene, plan reuse, model-file replay).  A/B figures from round 3, one box, layout steps/s:
+ROWS_GCN_SLICES = 2      # K slices of the triple-row GCN products: 8 -> 1048, 4 -> 1066, 2 -> ~1090
+ROWS_CAV_SLICES = 1      # cross-attention-vector product: 1 / 2 / 3 / 4 slices -> 1124 / 1125 / 1118 / 1108
+ROWS_LN_SPLIT = 2        # slices of a product whose consumer is a LayerNorm (whole-row statistics): 1 -> 1067, 2 -> 1093
+ROWS_VO1_SLICES = 2      # attention-with-one-token product: 2 / 1 -> 1124 / 1122
+ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's launch: measured -1.1 %
 
 
 class View:
@@ -79,6 +91,11 @@ def norm_segs(views, gamma, beta, eps, silu, C=None, groups=32):
     normalization(ch), openai_model_3d.py / denoise_net.py ResBlock.in_layers): groups never straddle a source."""
     C = sum(v.width for v in views) if C is None else C
     gs = C // groups
+    if C % groups or gs < 4 or gs > 32 or gs & (gs - 1):
+        # the rows kernel's GroupNorm prologue reduces a group inside one wave with power-of-two strides (es_rows.hip); the shipped
+        # layout denoisers have 512 / 1024 channels (group size 16 / 32).  Said here, at plan build, not at the first launch.
+        raise ValueError('GroupNorm32 over %d channels: group size %d is not a power of two in 4..32 -- the rows path supports '
+                         'model_channels in {128, 256, 512, 1024} (reference: any multiple of 32)' % (C, gs))
     out, off = [], 0
     for v in views:
         assert v.width % gs == 0 and off % gs == 0
@@ -216,15 +233,19 @@ class Builder:
         self.keep = []
         self.weight_bytes = 0      # algorithmic weight bytes streamed per plan execution
         self.tags = {}             # name -> View of an intermediate (parity debugging)
-        import os
         # side-stream graph branches: measured SLOWER on MI355X (2.27 vs 2.06 ms per layout step) -- off by default
         self.use_lanes = os.environ.get('ES_LANES', '0') != '0'
         self.flops = 0
         self.allow_split = True    # K split over workgroups with slab outputs (Builder.linear(out=None))
+        self.scratch = set()       # data_ptr of buffers the plan fully writes before it reads them (save_model does not dump them)
 
-    def buf(self, *shape, dtype=torch.float32, zero=False):
+    def buf(self, *shape, dtype=torch.float32, zero=False, scratch=False):
+        """``scratch=True``: every byte of the buffer is written by an op of the plan before any op reads it (activations, split-K
+        workspace, statistics) and nothing writes it at build time -- model files list it without its contents."""
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
         self.keep.append(t)
+        if scratch and not zero:
+            self.scratch.add(t.data_ptr())
         return t
 
     def dev(self, t, dtype=torch.float32):
@@ -355,6 +376,7 @@ class Plan:
         self.n_ops = len(b.ops)
         self.weight_bytes = b.weight_bytes
         self.flops = b.flops
+        self.scratch = set(getattr(b, 'scratch', ()))
         arr = (Op * len(b.ops))(*b.ops)
         self._arr = arr
         self.handle = hip.lib().es_plan_create(arr, len(b.ops))
@@ -416,14 +438,19 @@ def save_model(plan, path, regions):
         used[i] = blocks[i]
     bl = [used[i] for i in sorted(used)]
     bufs = (hip.BufferDesc * len(bl))()
+    region_ptrs = {t.data_ptr() for t in regions.values()}
+    stored = 0
     for k, (a, n) in enumerate(bl):
-        bufs[k].ptr, bufs[k].bytes = a, n
+        # scratch blocks (Builder.buf(scratch=True): written by the plan before they are read) are listed, not dumped
+        sc = a in plan.scratch and a not in region_ptrs
+        bufs[k].ptr, bufs[k].bytes = a, n | ((1 << 63) if sc else 0)
+        stored += 0 if sc else n
     regs = (hip.RegionDesc * len(regions))()
     for k, (name, t) in enumerate(regions.items()):
         regs[k].name = name.encode()
         regs[k].ptr, regs[k].bytes = t.data_ptr(), t.numel() * t.element_size()
     hip.check(L.es_model_save(str(path).encode(), C.c_void_p(plan.handle), bufs, len(bl), regs, len(regions)), 'es_model_save')
-    return sum(n for _, n in bl)
+    return stored
 
 
 def combine_plans(device, main, side, side_repeat=1):
@@ -514,8 +541,7 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         # layer input: ONE launch (fuse_next); likewise net2's first Linear over the pooled messages and the predicate projection.
         # (the triple products have ~4x the rows of the node products, i.e. 4x the workgroups per slice: 2-4 slices instead of the
         #  8 the (K, N) rule would pick -- the consumer reads S slabs of [T x H]; a planner constant, not a function of M)
-        import os
-        gs_ = int(os.environ.get('ES_ROWS_GCN_SLICES', '2'))         # A/B on one box: 8 -> 1048, 4 -> 1066, 2 -> ~1090 layout steps/s
+        gs_ = ROWS_GCN_SLICES
         nkb1 = (2 * Dobj + Dp + 15) // 16
         t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
                        seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, fuse_next=has_proj,
@@ -710,8 +736,7 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     cavo = {}
     if not w.concat:
         # the cross-attention vectors of all transformer blocks: one product (folded to_out2 . to_v2 matrices)
-        import os
-        cs_ = int(os.environ.get('ES_ROWS_CAV_SLICES', '1'))
+        cs_ = ROWS_CAV_SLICES
         if cs_ > 1:
             cavv = b.linear([seg(ctx)], w.cav_all, O, split=max(8, ((w.cav_all.K + 15) // 16 + cs_ - 1) // cs_))
         else:
@@ -725,8 +750,7 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
 
     # Every trunk product writes a slab tensor (K split over workgroups) unless its consumer needs whole rows cheaply:
     # the two LayerNorm operands of a transformer block (t0, t2) are produced with ``ln_split`` slices.
-    import os
-    ln_split = int(os.environ.get('ES_ROWS_LN_SPLIT', '2'))      # slices of a product whose consumer is a LayerNorm (A/B)
+    ln_split = ROWS_LN_SPLIT
 
     def ln_kbps(K):
         nkb = (K + 15) // 16
@@ -745,7 +769,7 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
-                skip_early = 'skip' in d and os.environ.get('ES_ROWS_SKIP_EARLY', '0') != '0'     # measured -1.1 %: off
+                skip_early = 'skip' in d and ROWS_SKIP_EARLY
                 h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
                               res=View(emb_all, col=eo, ld=emb_ld, width=cout), fuse_next=skip_early)
                 gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
@@ -778,7 +802,7 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
                 # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
-                vs_ = int(os.environ.get('ES_ROWS_VO1_SLICES', str(ln_split)))
+                vs_ = ROWS_VO1_SLICES
                 t2 = b.linear([seg(t0, pro=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5, gs=C)], d['vo1'], O,
                               res=t0, res2=cavo[name],
                               split=(False if vs_ <= 1 else max(8, ((C + 15) // 16 + vs_ - 1) // vs_)))

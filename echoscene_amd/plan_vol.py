@@ -175,7 +175,7 @@ class VolBuilderMixin:
         if not ncdhw and Mh * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
             need = max(16 if Mh * pc.N <= (1 << 22) else 8, splitk or 0) * M * pc.N     # contract of es_conv_args.splitk = -1
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
-                self._ws = self.buf(need)
+                self._ws = self.buf(need, scratch=True)
                 for op in self.ops:
                     if op.kind == hip.OP_CONV and op.u.conv.workspace:
                         op.u.conv.workspace = self._ws.data_ptr()
@@ -220,10 +220,15 @@ class VolBuilderMixin:
         st = getattr(self, '_rg_stats', None)
         if st is None:
             st = self._rg_stats = {}
-        if x.data_ptr() not in st:
-            st[x.data_ptr()] = self.buf(2 * (M // 64) * Cx)
-            op.u.conv.gn_stats_out = st[x.data_ptr()].data_ptr()
-        return st[x.data_ptr()]
+        ent = st.get(x.data_ptr())
+        if ent is None or ent[0] is not op:
+            # keyed by (producer op, tensor): a buffer that a LATER conv rewrites gets fresh sums from that conv, never the stale
+            # ones of the first producer
+            buf = self.buf(2 * (M // 64) * Cx, scratch=True)
+            op.u.conv.gn_stats_out = buf.data_ptr()
+            st[x.data_ptr()] = ent = (op, buf)
+        assert op.u.conv.gn_stats_out == ent[1].data_ptr() and op.u.conv.out_f32 == x.data_ptr()
+        return ent[1]
 
     def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None, groups=32):
         a = GNArgs()
@@ -234,7 +239,7 @@ class VolBuilderMixin:
         need = O * ((V + 7) // 8) * groups * 2 + O * groups * 2     # es_groupnorm_vol: partials at the smallest voxel tile (8) + final stats
         st = getattr(self, '_gn_stats', None)           # one scratch shared by all GroupNorms (same stream, in order)
         if st is None or st.numel() < need:
-            st = self._gn_stats = self.buf(need)
+            st = self._gn_stats = self.buf(need, scratch=True)
         a.stats = st.data_ptr()
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
@@ -433,6 +438,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             side_join['pending'] = False
 
     # ---- volume path ----
+    sbuf = lambda *sh, **kw: b.buf(*sh, scratch=True, **kw)    # activations: written by the step before they are read (not stored in model files)
     state = dict(h=None, C=0, dims=dims, last_op=None, h16=None)
     O = Ol                                     # ---- from here on: local objects only ----
 
@@ -442,7 +448,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     def need_f16():
         """f16 copy of the current fp32 activation (for convs that read it un-normalised)."""
         if state['h16'] is None:
-            t = b.buf(O * V_(state['dims']), state['C'], dtype=f16)
+            t = sbuf(O * V_(state['dims']), state['C'], dtype=f16)
             op = b.ops[state['last_op']]
             op.u.conv.out_f16 = t.data_ptr()
             state['h16'] = t
@@ -455,9 +461,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             dm = state['dims']
             M = O * V_(dm)
             if kind == 'conv_in':
-                xcl = b.buf(O * V0, 32, dtype=f16)
+                xcl = sbuf(O * V0, 32, dtype=f16)
                 b.to_cl(xc if w.concat else x, O, w.in_ch, V0, 32, xcl)
-                o = b.buf(M, mc)
+                o = sbuf(M, mc)
                 state['last_op'] = b.conv(xcl, d['conv'], O, dm, out_f32=o)
                 state.update(h=o, C=mc, h16=None)
             elif kind == 'res':
@@ -466,14 +472,14 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 x2, C2 = (skip if skip is not None else (None, 0))
                 assert C1 + C2 == cin, (name, C1, C2, cin)
                 eo, _ = w.emb_slices[name]
-                y1 = b.buf(M, cin, dtype=f16)
-                raw = b.buf(M, cin, dtype=f16) if 'skip' in d else None
+                y1 = sbuf(M, cin, dtype=f16)
+                raw = sbuf(M, cin, dtype=f16) if 'skip' in d else None
                 b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
-                h1 = b.buf(M, cout)
+                h1 = sbuf(M, cout)
                 b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=row0 if emb_ld else 0), out_f32=h1)
-                y2 = b.buf(M, cout, dtype=f16)
+                y2 = sbuf(M, cout, dtype=f16)
                 b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
-                o = b.buf(M, cout)
+                o = sbuf(M, cout)
                 if 'skip' in d:
                     state['last_op'] = b.conv(y2, d['conv2'], O, dm, bias=d['bias2'], skip=(raw, d['skip']), out_f32=o)
                 else:
@@ -484,44 +490,44 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             elif kind == 'attn' and w.concat:
                 Cc = it[1]
                 xin = state['h']
-                yn = b.buf(M, Cc, dtype=f16)
+                yn = sbuf(M, Cc, dtype=f16)
                 b.groupnorm(xin, Cc, None, 0, O, V_(dm), d['gn'][0], d['gn'][1], 1e-5, False, yn)
-                qkv = b.buf(M, 3 * Cc, dtype=f16)
+                qkv = sbuf(M, 3 * Cc, dtype=f16)
                 b.conv(yn, d['qkv'], O, dm, out_f16=qkv)
-                at = b.buf(M, Cc, dtype=f16)
+                at = sbuf(M, Cc, dtype=f16)
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
-                o = b.buf(M, Cc)
+                o = sbuf(M, Cc)
                 state['last_op'] = b.conv(at, d['proj_out'], O, dm, res=xin, out_f32=o)
                 state.update(h=o, h16=None)
             elif kind == 'attn':
                 join_side()                        # the cross-attention vectors (cavo) are read from here on
                 Cc = it[1]
                 xin = state['h']
-                yn = b.buf(M, Cc, dtype=f16)
+                yn = sbuf(M, Cc, dtype=f16)
                 b.groupnorm(xin, Cc, None, 0, O, V_(dm), d['gn'][0], d['gn'][1], 1e-6, False, yn)
-                t0 = b.buf(M, Cc)
+                t0 = sbuf(M, Cc)
                 b.conv(yn, d['proj_in'], O, dm, out_f32=t0)
-                l1 = b.buf(M, Cc, dtype=f16)
+                l1 = sbuf(M, Cc, dtype=f16)
                 b.layernorm(t0, M, Cc, d['ln1'][0], d['ln1'][1], l1)
-                qkv = b.buf(M, 3 * Cc, dtype=f16)
+                qkv = sbuf(M, 3 * Cc, dtype=f16)
                 b.conv(l1, d['qkv'], O, dm, out_f16=qkv)
-                at = b.buf(M, Cc, dtype=f16)
+                at = sbuf(M, Cc, dtype=f16)
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
-                t2 = b.buf(M, Cc)
+                t2 = sbuf(M, Cc)
                 b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, col=cavo[name].col, ld=cavo[name].ld, width=cavo[name].width, row=row0), res=t0, out_f32=t2)
-                l3 = b.buf(M, Cc, dtype=f16)
+                l3 = sbuf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
-                gg = b.buf(M, 4 * Cc, dtype=f16)
+                gg = sbuf(M, 4 * Cc, dtype=f16)
                 if d['ff1'].geglu:               # GEGLU in the contraction epilogue: the [M, 8C] fp32 tensor never exists
                     b.conv(l3, d['ff1'], O, dm, out_f16=gg, epilogue=hip.EPI_GEGLU, out_ld=4 * Cc)
                 else:
-                    gl = b.buf(M, 8 * Cc)
+                    gl = sbuf(M, 8 * Cc)
                     b.conv(l3, d['ff1'], O, dm, out_f32=gl)
                     b.geglu(gl, M, 4 * Cc, gg)
-                t3 = b.buf(M, Cc, dtype=f16)
+                t3 = sbuf(M, Cc, dtype=f16)
                 b.conv(gg, d['ff2'], O, dm, res=t2, out_f16=t3)
-                o = b.buf(M, Cc)
+                o = sbuf(M, Cc)
                 state['last_op'] = b.conv(t3, d['proj_out'], O, dm, res=xin, out_f32=o)
                 b.tags[name + '.transformer_blocks.0:in'] = View(t0)
                 b.tags[name + '.transformer_blocks.0:attn2'] = View(t2)
@@ -529,13 +535,13 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             elif kind == 'down':
                 a16 = need_f16()
                 nd = (dm[0] // 2, dm[1] // 2, dm[2] // 2) if w.concat else (dm[0], dm[1] // 2, dm[2] // 2)
-                o = b.buf(O * V_(nd), state['C'])
+                o = sbuf(O * V_(nd), state['C'])
                 state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_DOWN_DHW if w.concat else hip.CONV_DOWN_HW, out_f32=o)
                 state.update(h=o, dims=nd, h16=None)
             elif kind == 'up':
                 a16 = need_f16()
                 nd = (dm[0] * 2, dm[1] * 2, dm[2] * 2) if w.concat else (dm[0], dm[1] * 2, dm[2] * 2)
-                o = b.buf(O * V_(nd), state['C'])
+                o = sbuf(O * V_(nd), state['C'])
                 state['last_op'] = b.conv(a16, d['conv'], O, nd, mode=hip.CONV_UP_DHW if w.concat else hip.CONV_UP_HW, out_f32=o)
                 state.update(h=o, dims=nd, h16=None)
             b.tags[name] = View(state['h'])
@@ -550,7 +556,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
         run_block(f'output_blocks.{i}', blk, skip=hs.pop())
     join_side()                                # (a topology without transformer blocks: join before the step ends)
     dm = state['dims']
-    yo = b.buf(O * V_(dm), state['C'], dtype=f16)
+    yo = sbuf(O * V_(dm), state['C'], dtype=f16)
     b.groupnorm(state['h'], state['C'], None, 0, O, V_(dm), w.out_gn[0], w.out_gn[1], 1e-5, True, yo)
     b.conv(yo, w.out_conv, O, dm, out_f32=eps_out, ncdhw=True)
     return objbuf
@@ -623,10 +629,11 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
     """z f32 [Oc,3,16,16,16] -> sdf_out f32 [Oc,1,64,64,64] (one chunk of objects)."""
     from .hip import VQArgs
     f16 = torch.float16
+    sbuf = lambda *sh, **kw: b.buf(*sh, scratch=True, **kw)    # activations: not stored in model files
     st = dict(h=None, C=0, dims=tuple(zdims), last=None, h16=None)
     V_ = lambda dm: dm[0] * dm[1] * dm[2]
     V0 = V_(zdims)
-    zq = b.buf(Oc * V0, 32, dtype=f16)
+    zq = sbuf(Oc * V0, 32, dtype=f16)
     a = VQArgs()
     a.z, a.codebook, a.lut = z.data_ptr(), w.codebook.data_ptr(), w.lut.data_ptr()
     a.O, a.V, a.n_embed, a.Cpad = Oc, V0, w.n_embed, 32
@@ -634,7 +641,7 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
     a.out_f16 = zq.data_ptr()
     b._push(hip.OP_VQ, 'vq', a)
     b.keep.append(w)
-    o = b.buf(Oc * V0, w.conv_in.N)
+    o = sbuf(Oc * V0, w.conv_in.N)
     st['last'] = b.conv(zq, w.conv_in, Oc, zdims, out_f32=o)
     st.update(h=o, C=w.conv_in.N)
 
@@ -644,14 +651,14 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
     def res(r):
         dm, M = st['dims'], Oc * V_(st['dims'])
         x, cin, cout = st['h'], r['cin'], r['cout']
-        y1 = b.buf(M, cin, dtype=f16)
-        raw = b.buf(M, cin, dtype=f16) if 'skip' in r else None
+        y1 = sbuf(M, cin, dtype=f16)
+        raw = sbuf(M, cin, dtype=f16) if 'skip' in r else None
         gn(x, cin, r['gn1'][0], r['gn1'][1], 1, y1, raw)
-        h1 = b.buf(M, cout)
+        h1 = sbuf(M, cout)
         b.conv(y1, r['conv1'], Oc, dm, out_f32=h1)
-        y2 = b.buf(M, cout, dtype=f16)
+        y2 = sbuf(M, cout, dtype=f16)
         gn(h1, cout, r['gn2'][0], r['gn2'][1], 1, y2)
-        o = b.buf(M, cout)
+        o = sbuf(M, cout)
         if 'skip' in r:
             st['last'] = b.conv(y2, r['conv2'], Oc, dm, bias=r['bias2'], skip=(raw, r['skip']), out_f32=o)
         else:
@@ -662,13 +669,13 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
     # AttnBlock: single head of C channels over all voxels
     dm, M, Cc = st['dims'], Oc * V_(st['dims']), w.attn['C']
     x = st['h']
-    yn = b.buf(M, Cc, dtype=f16)
+    yn = sbuf(M, Cc, dtype=f16)
     gn(x, Cc, w.attn['gn'][0], w.attn['gn'][1], 0, yn)
-    qkv = b.buf(M, 3 * Cc, dtype=f16)
+    qkv = sbuf(M, 3 * Cc, dtype=f16)
     b.conv(yn, w.attn['qkv'], Oc, dm, out_f16=qkv)
-    at = b.buf(M, Cc, dtype=f16)
+    at = sbuf(M, Cc, dtype=f16)
     b.attention(qkv, Oc, V_(dm), 1, Cc, at)
-    o = b.buf(M, Cc)
+    o = sbuf(M, Cc)
     st['last'] = b.conv(at, w.attn['proj'], Oc, dm, res=x, out_f32=o)
     st.update(h=o, h16=None)
     res(w.mid2)
@@ -677,14 +684,14 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
             res(r)
         if up is not None:
             dm = st['dims']
-            t = b.buf(Oc * V_(dm), st['C'], dtype=f16)           # f16 copy of the current activation
+            t = sbuf(Oc * V_(dm), st['C'], dtype=f16)           # f16 copy of the current activation
             b.ops[st['last']].u.conv.out_f16 = t.data_ptr()
             nd = (dm[0] * 2, dm[1] * 2, dm[2] * 2)
-            o = b.buf(Oc * V_(nd), st['C'])
+            o = sbuf(Oc * V_(nd), st['C'])
             st['last'] = b.conv(t, up, Oc, nd, mode=hip.CONV_UP_DHW, out_f32=o)
             st.update(h=o, dims=nd, h16=None)
     dm = st['dims']
-    yo = b.buf(Oc * V_(dm), st['C'], dtype=f16)
+    yo = sbuf(Oc * V_(dm), st['C'], dtype=f16)
     gn(st['h'], st['C'], w.out_gn[0], w.out_gn[1], 2, yo)        # norm_out -> GELU
     b.conv(yo, w.conv_out, Oc, dm, out_f32=sdf_out, ncdhw=True)
     return dm

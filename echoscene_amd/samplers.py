@@ -1,6 +1,8 @@
 """Loop owners on the host side: thin objects that own packed weights + per-graph plans and call
 the native sampling loop.  They mirror ``EchoToLayout`` / ``EchoToShape`` of the reference
 (model/networks/diffusion_layout/echo2layout.py, diffusion_shape/echo2shape.py)."""
+import os
+
 import torch
 
 from . import hip
@@ -103,7 +105,7 @@ class LayoutDenoiser:
         """The layout loop of this scene graph as a model file for hosts without Python (es_model_load + es_layout_sample)."""
         from .plan import save_model
         st = self._plan_for(obj_embed, triples)
-        return save_model(st['plan'], path, dict(x=st['x'], noise=st['noise'], step=st['step']))
+        return save_model(st['plan'], path, dict(x=st['x'], noise=st['noise'], step=st['step'], coef=self.coef))
 
     def eps(self, x, obj_embed, triples, iteration):
         """One UNet1DModel.forward at loop iteration ``iteration`` (t = T-1-iteration)."""
@@ -135,7 +137,7 @@ class ShapeDenoiser:
     step as one hipGraph; world > 1 splits each step at the echo all-gather."""
 
     def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
-                 group=None, deterministic=False, force_exchange=False):
+                 group=None, deterministic=True, force_exchange=False):
         """``force_exchange``: build the sharded step structure (stem plan -> code exchange -> main plan) even at world == 1 --
         the one-GPU test of the captured RCCL exchange (tests/test_hip_scene.py)."""
         self.force_exchange = bool(force_exchange)
@@ -153,11 +155,11 @@ class ShapeDenoiser:
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)
         self.rank, self.world, self.group = rank, world, group
-        # deterministic=True: a shard reproduces the unsharded run BIT FOR BIT (split-K factors and GroupNorm partial-sum tiles are
-        # chosen from the GLOBAL object count).  Default False: every rank tunes them to its local share -- the results then differ
-        # from the single-GPU run in fp32 summation order only (5e-4 relative after 4 steps, inside the 2e-2 parity budget) and a
-        # shard of 4 objects runs 1.8x faster (one-GPU emulation: x3.6 vs x2.0 at 8 ranks): bit-exactness across world sizes costs
-        # the K split that small shards need, because a K loop cut in other places sums in another order.
+        # deterministic=True (the default: SURVEY.md section 8(e), "the 8-GPU result must equal the 1-GPU result bit for bit"): a
+        # shard reproduces the unsharded run BIT FOR BIT -- every K-split and partial-sum tiling is a function of the layer and the
+        # GLOBAL object count, never of the local share.  deterministic=False (opt-in): every rank tunes them to its local share --
+        # the results then differ from the single-GPU run in fp32 summation order only (5e-4 relative after 4 steps, inside the
+        # 2e-2 parity budget); faster at few objects per GPU (DESIGN.md section 6 has both curves).
         self.deterministic = deterministic
         self.tables = time_tables(self.w, self.temb, self.w.shape_t, self.device)
         self._plans, self.max_plans = {}, 2
@@ -274,49 +276,57 @@ class ShapeDenoiser:
         from .plan import save_model
         assert self.world == 1 and not self.force_exchange
         st = self._plan_for(uc, triples, c)
-        return save_model(st['plan'], path, dict(x=st['x'], step=st['step']))
+        return save_model(st['plan'], path, dict(x=st['x'], step=st['step'], coef=self.coef))
 
     def step_graph(self, group=None):
         """ONE graph per DDIM step of the sharded loop ("RCCL on a dedicated stream, or direct peer
         writes for the 8 KB"): this rank's stem ops -> the RCCL all-gather of the [block, 64] codes -> everything else, captured
         together (torch.cuda.CUDAGraph: ProcessGroupNCCL collectives are capturable), so a step is a single graph launch with no
         host round trip between its three parts.  The step counter lives on the device and is advanced by the captured DDIM
-        update.  Returns the graph, or None when the exchange cannot be captured (gloo test backend, an empty shard, eager mode,
-        or a capture error) -- the loop then falls back to graph launch / collective / graph launch per step."""
-        import os
+        update.
+
+        OPT-IN (``ES_STEP_GRAPH=1``): the captured exchange has only ever run on a 1-rank NCCL group (one GPU per box here), so
+        the default is the three-call step (graph launch / collective / graph launch), which the 2-rank tests do cover.  When it
+        is enabled the graph-or-eager decision is COLLECTIVE: every rank attempts the capture, then all ranks all-reduce (MIN) a
+        success flag and ALL fall back to the three-call step if any rank failed -- a rank must never replay captured all-gathers
+        while a peer issues eager ones after a failed capture.  A rank without objects captures nothing and issues
+        one eager all-gather per step; that matches its peers' captured ones call for call.
+        Returns the graph, or None (three-call step)."""
         st = self._cur
-        if not self._use_graph or ('stem_plan' not in st and not st.get('empty')) or os.environ.get('ES_STEP_GRAPH', '1') == '0':
+        if not self._use_graph or ('stem_plan' not in st and not st.get('empty')) or os.environ.get('ES_STEP_GRAPH', '0') != '1':
             return None
         if 'step_graph' in st:
             return st['step_graph']
         st['step_graph'] = None
-        try:
-            import torch.distributed as dist
-            if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
-                return None
-            send, recv = st['codes_local'], st['codes_all']
-            if st.get('empty'):
-                # a rank without objects captures nothing, but it must take part in the set-up collective the other ranks
-                # issue below (its loop then runs one eager all-gather per step, matching their captured ones)
-                dist.all_gather_into_tensor(recv, send, group=group)
-                return None
-            s = torch.cuda.Stream(device=self.device)
-            s.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(s):
-                dist.all_gather_into_tensor(recv, send, group=group)      # communicator set-up outside the capture (recv is scratch)
-                torch.cuda.synchronize(self.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
-                    st['stem_plan'].run()
-                    dist.all_gather_into_tensor(recv, send, group=group)
-                    st['main_plan'].run()
-            torch.cuda.current_stream(self.device).wait_stream(s)
-            st['step_graph'] = g
-        except Exception as e:                 # noqa: BLE001 -- any capture problem: keep the three-call step
-            import warnings
-            warnings.warn('sharded DDIM step: the RCCL exchange could not be captured (%s); using graph / collective / graph per step' % e)
-            st['step_graph'] = None
-        return st['step_graph']
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
+            return None                          # (decided from the backend alone: the same on every rank)
+        send, recv = st['codes_local'], st['codes_all']
+        g, ok = None, 1
+        # communicator set-up outside any capture; every rank (an empty shard too) takes part (recv is scratch)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        torch.cuda.synchronize(self.device)
+        if not st.get('empty'):
+            try:
+                s = torch.cuda.Stream(device=self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s):
+                        st['stem_plan'].run()
+                        dist.all_gather_into_tensor(recv, send, group=group)
+                        st['main_plan'].run()
+                torch.cuda.current_stream(self.device).wait_stream(s)
+            except Exception as e:                 # noqa: BLE001 -- any capture problem on this rank
+                import warnings
+                warnings.warn('sharded DDIM step: the RCCL exchange could not be captured on rank %d (%s)' % (self.rank, e))
+                g, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)      # collective decision: all ranks replay, or none does
+        if int(flag.item()) != 1:
+            g = None
+        st['step_graph'] = g
+        return g
 
     def begin(self, first_step):
         """set the device step counter (the captured step graph does not re-set it every replay)"""

@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 4
+#define ES_ABI_VERSION 5
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -385,10 +385,15 @@ int es_sampler_run(es_plan* plan, int32_t* step, int first_step, int n_steps, in
  * call, SGDiff.py:87-95 -> echo2layout.py:96-124, echo2shape.py:484-525, vqvae_networks/network.py:95-103).
  *
  * File = header, buffer table, named regions, the op list with every pointer field rewritten as (buffer, offset), buffer
- * contents.  es_model_save is called by the planner (it knows the allocation ranges); es_model_load allocates the buffers with
+ * contents.  A buffer whose es_buffer_desc.bytes has bit 63 set is SCRATCH (every byte is written by the plan before it is read:
+ * activations, split-K workspace, statistics): it is listed but not stored -- the loader allocates and zero-fills it -- so a model
+ * file is about the size of the packed weights.  Header counts and sizes are validated on load (untrusted input); nothing throws
+ * through the C boundary.  es_model_save is called by the planner (it knows the allocation ranges); es_model_load allocates the buffers with
  * hipMalloc, uploads the contents, rebases the pointers and creates the plan.  Named regions give the caller its I/O:
  *   layout model:  "x" [O,8] state, "noise" [T+1,O,8] (row 0 = x_T, row 1+i = draw of iteration i), "step" int32
  *   shape model :  "x" [O,3,16,16,16] latents, "step" int32
+ *   both loops  :  "coef" = the schedule's coefficient table [n_steps][coef_stride]: es_model_run / es_layout_sample / es_shape_sample
+ *                  refuse to run past its last row
  *   vq model    :  "z" [O,3,16,16,16] input latents, "sdf" [O,1,64,64,64] output
  * ---------------------------------------------------------------------------------------- */
 typedef struct es_model es_model;

@@ -546,7 +546,7 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
         env = dict(os.environ, ES_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
                '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '3', '--warmup', '1',
-               '--no-cpu-baseline', '--no-sub-records', '--nodes', '8', '--deterministic', '--check']
+               '--no-cpu-baseline', '--no-sub-records', '--nodes', '8', '--check']          # default mode: bit-exact shards
         r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])

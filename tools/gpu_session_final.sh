@@ -11,5 +11,5 @@ echo "smoke rc=$?" >> $OUT/summary.txt
 timeout 300 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
 bash tools/gpu_session_profile.sh ${1:-final}
 timeout 600 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
-timeout 600 python tools/emulate_shards.py --steps 20 --deterministic 2>&1 | grep "^world" > $OUT/shards_det.txt
-cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; cat $OUT/shards_default.txt $OUT/shards_det.txt
+timeout 600 python tools/emulate_shards.py --steps 20 --tuned 2>&1 | grep "^world" > $OUT/shards_tuned.txt
+cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; cat $OUT/shards_default.txt $OUT/shards_tuned.txt

@@ -2,6 +2,7 @@
 on this GPU, the sharded step structure forced at world == 1 (ShapeDenoiser(force_exchange=True)).  Prints STEP_GRAPH_OK when
 the exchange was captured and the latents equal the ordinary single-graph run bit for bit.  usage: python tools/probe_step_graph.py [mc]"""
 import os, sys, socket
+os.environ['ES_STEP_GRAPH'] = '1'          # the captured exchange is opt-in (samplers.ShapeDenoiser.step_graph)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
