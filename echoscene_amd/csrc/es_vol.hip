@@ -986,8 +986,12 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define ES_STAMP_AT(k) do { } while (0)
 #endif
 
-template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool STATS_ = false>
-__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
+// One (tile, K range) of k_conv_ws: producer / consumer roles, 3-slot ring, epilogue.  S > 1: the raw partial tile goes to slab bz of
+// a.workspace (split K / stream-K); S == 1: the final epilogue.  Every wave of the workgroup calls it with the same arguments.
+template <int BM_, int NC_, int NP_, bool UP_, int EPI_, bool STATS_>
+__device__ __forceinline__ void conv_ws_tile(const es_conv_args& a, const ConvGeom& g, int ncdhw, char* smem, const int wave, const int lane,
+                                             const long M, const int bx, const int by, const int ks_begin, const int ks_end,
+                                             const int S, const int bz, unsigned long long* stamp) {
     constexpr int NS = 3, UPS_ = 1;                               // ring depth; K units per barrier
     constexpr int WROWS = BM_ / (NC_ / 2);
     constexpr int MI = WROWS / 16;
@@ -998,23 +1002,11 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     static_assert(APIECES % NP_ == 0 && BPIECES % NP_ == 0, "pieces must divide over the producer waves");
     constexpr unsigned OOB = 0x80000000u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef ES_STAMP
-    unsigned long long* stamp = g_stamp_buf ? g_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (NC_ + NP_) + wave) * 8 : nullptr;
-#endif
-    ES_STAMP_AT(0);
-    const long M = (long)g.O * g.D * g.H * g.W;
-    int bx, by, bz;
-    conv_tile_of(a, bx, by, bz);                 // XCD-aware, re-use-aware tile order
+    (void)stamp;
     const long m0 = (long)bx * BM_;
     const int n0 = by * BN;
     const int kch0 = a.Cin >> 5;
     const int nks0 = a.taps * kch0;
-    const int S = gridDim.z;
-    int ks_begin, ks_end;
-    split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
     const int nloc = ks_end - ks_begin;                           // K units of this workgroup
     const int nstage = (nloc + UPS_ - 1) / UPS_;
     if (wave >= NC_) {
@@ -1149,7 +1141,6 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
         ES_STAMP_AT(4);
         return;
     }
-
     // =============================== consumer ===============================
     const int wm = wave >> 1, wn = wave & 1;
     f4 acc[MI][7];
@@ -1209,6 +1200,76 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     ES_STAMP_AT(3);
     conv_epilogue<BM_, NC_, true, true, EPI_, false, STATS_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, ncdhw);
     ES_STAMP_AT(4);
+}
+
+template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool STATS_ = false>
+__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* stamp = nullptr;
+#ifdef ES_STAMP
+    stamp = g_stamp_buf ? g_stamp_buf + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (NC_ + NP_) + wave) * 8 : nullptr;
+#endif
+    ES_STAMP_AT(0);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;
+    conv_tile_of(a, bx, by, bz);                 // XCD-aware, re-use-aware tile order
+    const int S = gridDim.z;
+    int ks_begin, ks_end;
+    split_range(a.taps * (a.Cin >> 5), a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
+    conv_ws_tile<BM_, NC_, NP_, UP_, EPI_, STATS_>(a, g, ncdhw, smem, wave, lane, M, bx, by, ks_begin, ks_end, S, bz, stamp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_ws_sk: STREAM-K launch of the same tile code for problems with fewer than 256 tiles of 256 rows (the 16x4x4 level at one
+// scene: 96 tiles; every level at <= 16 objects per GPU).  Plain split K gives every tile the same integer number S of K ranges, so the
+// launch runs tiles x S workgroups -- 96 x 2 = 192 on 256 CUs (a quarter of the chip idle), and S = 3 would need a second round.  Here
+// the launch is G workgroups (one per CU) and the tiles' K units are ONE sequence of W = tiles x UT split units (tile-major: row tile,
+// then column tile, then K); workgroup w owns units [w W / G, (w + 1) W / G) -- at most two pieces of neighbouring tiles -- and writes
+// each piece's partial tile to its own workspace slab (slot = the piece's ordinal inside its tile); k_conv_sk_reduce sums a tile's
+// slabs in slot order (deterministic).  The cut positions are a function of (layer, object count of the WHOLE problem, G): a shard of
+// a multi-GPU run that passes O_hint / O_base executes exactly the pieces of its own tiles (bit-identical partial sums).
+// ---------------------------------------------------------------------------------------------
+struct SkGeom {
+    int ntn, UT, unit, nks0;        // column tiles; split units per tile; K steps per phase-0 unit (3: one (chunk, kd, kh) group, or 1)
+    int W;                          // tiles of the WHOLE problem x UT   (W * (G + 1) < 2^31: checked by the host)
+    int G;                          // workgroups of the WHOLE problem
+    int g0;                         // first (global) workgroup this launch runs
+    int t_lo, t_hi;                 // (global) tiles this launch owns: [t_lo, t_hi), tile = row tile * ntn + column tile
+};
+// workgroup that owns split unit u: b_w = floor(w W / G) <= u  <=>  w <= ceil((u + 1) G / W) - 1
+__device__ __host__ __forceinline__ int sk_owner(int u, int W, int G) { return (int)(((unsigned)(u + 1) * (unsigned)G - 1u) / (unsigned)W); }
+
+template <bool UP_>
+__global__ __launch_bounds__(768, 3) void k_conv_ws_sk(const es_conv_args a, const ConvGeom g, const SkGeom sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    // XCD-contiguous ranges of workgroups (as conv_tile_of): neighbours in the unit sequence share an L2
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int gid = sk.g0 + L;
+    int lo = (int)((unsigned)gid * (unsigned)sk.W / (unsigned)sk.G), hi = (int)((unsigned)(gid + 1) * (unsigned)sk.W / (unsigned)sk.G);
+    if (lo < sk.t_lo * sk.UT) lo = sk.t_lo * sk.UT;
+    if (hi > sk.t_hi * sk.UT) hi = sk.t_hi * sk.UT;
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    const int U0 = sk.nks0 / sk.unit;
+    for (int u = lo; u < hi;) {
+        const int t = u / sk.UT;
+        const int ub = u - t * sk.UT;
+        const int ue = (hi - t * sk.UT) < sk.UT ? (hi - t * sk.UT) : sk.UT;
+        const int tl = t - sk.t_lo;
+        const int bx = __builtin_amdgcn_readfirstlane(tl / sk.ntn), by = __builtin_amdgcn_readfirstlane(tl - (tl / sk.ntn) * sk.ntn);
+        const int slot = __builtin_amdgcn_readfirstlane(gid - sk_owner(t * sk.UT, sk.W, sk.G));
+        const int ks_begin = __builtin_amdgcn_readfirstlane(ub <= U0 ? ub * sk.unit : sk.nks0 + (ub - U0));
+        const int ks_end = __builtin_amdgcn_readfirstlane(ue <= U0 ? ue * sk.unit : sk.nks0 + (ue - U0));
+        conv_ws_tile<256, 8, 4, UP_, ES_EPI_NONE, false>(a, g, 0, smem, wave, lane, M, bx, by, ks_begin, ks_end, 2, slot, nullptr);
+        u = t * sk.UT + ue;
+        __syncthreads();                         // the next piece's ring overwrites this piece's epilogue slabs
+    }
 }
 
 
@@ -1745,6 +1806,72 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a
     }
 }
 
+// Split-K / stream-K reduction with the epilogue AND the next GroupNorm's row-group sums in one pass: one workgroup per 64-row group,
+// thread = (row parity, column quad) -- the even rows of the group top to bottom in one lane, the odd rows in its neighbour, then the
+// two halves: the summation order of conv_epilogue<STATS_> and k_rowgroup_stats, so every route leaves the same bits.  The slabs of an
+// element are added in slot order (fixed).  S_plain > 0: every tile has S_plain slabs (plain split K, any tile size); S_plain == 0:
+// stream-K, the slab count of a tile follows from the cut positions (SkGeom).  Requires M % 64 == 0 and voxels per object % 64 == 0.
+template <bool STATS_>
+__global__ __launch_bounds__(256) void k_conv_sk_reduce(const es_conv_args a, const long M, const int V, const SkGeom sk, const int S_plain) {
+    const int N4 = a.N >> 2;
+    const long MN = M * a.N;
+    const long m0 = (long)blockIdx.x * 64;
+    const int par = threadIdx.x & 1;
+    const long nrg = M >> 6;
+    const float* rvp = a.rowvec ? a.rowvec + (m0 / V) * a.rowvec_ld : nullptr;
+    for (int qi = threadIdx.x >> 1; qi < N4; qi += 128) {
+        const int n = qi * 4;
+        int ns = S_plain;
+        if (S_plain == 0) {
+            const int t = sk.t_lo + (int)(m0 >> 8) * sk.ntn + n / BN;
+            ns = sk_owner((t + 1) * sk.UT - 1, sk.W, sk.G) - sk_owner(t * sk.UT, sk.W, sk.G) + 1;
+        }
+        f4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b4 = *(const f4*)&a.bias[n];
+        if (rvp) r4 = *(const f4*)&rvp[n];
+        f4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
+        const float* p0 = (const float*)a.workspace + (m0 + par) * a.N + n;
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+            f4 v[4], rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long ro = (long)(2 * (r0 + k)) * a.N;
+                v[k] = *(const f4*)(p0 + ro);
+                rr[k] = a.res ? *(const f4*)&a.res[(m0 + par + 2 * (r0 + k)) * a.out_ld + n] : f4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int z = 1; z < ns; ++z) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += *(const f4*)(p0 + (long)z * MN + (long)(2 * (r0 + k)) * a.N);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long m = m0 + par + 2 * (r0 + k);
+                f4 x = v[k];
+                x += b4; x += r4; x += rr[k];
+                if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = x;
+                if (a.out_f16) {
+                    const h4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+                    *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
+                }
+                if (STATS_) {
+                    gs += x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gq[e] = fmaf(x[e], x[e], gq[e]);
+                }
+            }
+        }
+        if (STATS_) {
+            f4 os, oq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { os[e] = __shfl_xor(gs[e], 1); oq[e] = __shfl_xor(gq[e], 1); }
+            if (par == 0) {
+                *(f4*)&a.gn_stats_out[(long)blockIdx.x * a.N + n] = gs + os;
+                *(f4*)&a.gn_stats_out[(nrg + blockIdx.x) * a.N + n] = gq + oq;
+            }
+        }
+    }
+}
+
 // Row-group sums of es_conv_args.gn_stats_out for the routes whose epilogue does not form them (64- / 128-row tiles, k_linear_ws,
 // split K): one thread per (64-row group, column quad), the summation order of conv_epilogue<STATS_> -- the even rows of the group
 // top to bottom, the odd rows top to bottom, then the two halves -- so that every route leaves the same bits.
@@ -2029,6 +2156,34 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         while (s2 > 1 && nks / s2 < 24) --s2;
         if (s2 >= 2 && hg256 * s2 >= 160) { S = s2; ws_split = true; }
     }
+    // Stream-K instead of an integer split factor (k_conv_ws_sk): G workgroups share the K units of all tiles as one sequence.
+    static const char* sk_env = getenv("ES_CONV_STREAMK");         // A/B switch (timing only; it changes where K sums are cut): 0 = off
+    bool sk_on = false;
+    SkGeom skg{};
+    const long Vobj = (long)a->D * a->H * a->W;
+    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && !(wss_env && atoi(wss_env) == 0) &&
+        !(sk_env && atoi(sk_env) == 0) && Vobj % 256 == 0 && ws_epilogue_ok) {
+        static const int n_cu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+        const int kch2 = a->a2 ? a->Cin2 / 32 : 0;
+        skg.ntn = ntn; skg.unit = a->taps == 27 ? 3 : 1; skg.nks0 = a->taps * (a->Cin / 32);
+        skg.UT = skg.nks0 / skg.unit + kch2;
+        const long Wl = hg256 * skg.UT;                            // tiles of the WHOLE problem x split units per tile
+        skg.W = (int)Wl;
+        long G = n_cu;
+        const long min_units = (24 + skg.unit - 1) / skg.unit;    // >= 24 K steps per workgroup on average
+        if (skg.W / G < min_units) G = skg.W / min_units;
+        const int smax = Mh * (long)a->N <= (1L << 22) ? 16 : 8;  // workspace contract (echoscene_hip.h): slabs per tile
+        const long min_chunk = (skg.UT + smax - 2) / (smax - 1);  // a tile is cut into at most ceil(UT / chunk) + 1 <= smax pieces
+        if (G > 0 && skg.W / G < min_chunk) G = skg.W / min_chunk;
+        if (G > hg256 && G >= 96 && Wl * (G + 2) < (1L << 31)) {  // more workgroups than tiles (else: no split needed / other routes)
+            sk_on = true; ws_split = false; S = 1;
+            skg.G = (int)G;
+            const long o_base = a->O_hint > a->O ? a->O_base : 0;
+            skg.t_lo = (int)((o_base * Vobj / 256) * ntn);
+            skg.t_hi = skg.t_lo + (int)(((M + 255) / 256) * ntn);
+            skg.g0 = (int)sk_owner(skg.t_lo * skg.UT, skg.W, skg.G);
+        }
+    }
     // Tiny K-short problems (the transformer linears at <= 8 objects per GPU: e.g. 1024 rows x 672 columns, 21 K units): even the
     // 64-row tiles give only a few dozen workgroups, each a lone, latency-bound chain of K units (22-30 us for < 1 GFLOP).
     // Split K over 64-row tiles until about one workgroup per CU runs (>= 5 units per split).
@@ -2036,7 +2191,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     bool tiny_split = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
-        if (!ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
+        if (!ws_split && !sk_on && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
             !(tiny_env && atoi(tiny_env) == 0)) {
             int s3 = (int)((256 + hg64 - 1) / hg64);
             const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
@@ -2045,20 +2200,22 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    const bool route256 = (wg256 >= 256 || force256 || ws_split || sk_on) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
-    if (route256 && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
+    if (route256 && !sk_on && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
         static const int cand[5] = {8, 6, 4, 3, 2};
         for (int k = 0; k < 5; ++k)
             if (ntn % cand[k] == 0 && ((M + 255) / 256) * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
     }
     // the producer/consumer 256-row kernel forms the row-group sums of gn_stats_out in its epilogue; every other route runs
     // k_rowgroup_stats over the finished output
-    const bool epi_stats = route256 && ncb == 1 && ws && !geglu && S == 1 && a->out_f32 && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
+    const bool epi_stats = route256 && !sk_on && ncb == 1 && ws && !geglu && S == 1 && a->out_f32 && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
                            (a->D * a->H * a->W) % 64 == 0;
-    if (emits) { *emits = epi_stats ? 1 : 0; return 0; }
+    // split-K / stream-K launches: the reduction pass forms the sums on the way (k_conv_sk_reduce<true>)
+    const bool fused_reduce = (S > 1 || sk_on) && M % 64 == 0 && Vobj % 64 == 0 && a->N % 4 == 0 && a->out_ld % 4 == 0;
+    if (emits) { *emits = (epi_stats || (fused_reduce && a->out_f32)) ? 1 : 0; return 0; }
     {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
@@ -2078,12 +2235,19 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
+            set((const void*)k_conv_ws_sk<false>, LDS256);
+            set((const void*)k_conv_ws_sk<true>, LDS256);
             set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
-    if (route256) {
+    if (sk_on) {
+        const int g1 = (int)sk_owner(skg.t_hi * skg.UT - 1, skg.W, skg.G);
+        const dim3 sgrid((unsigned)(g1 - skg.g0 + 1), 1, 1);
+        if (upm) hipLaunchKernelGGL((k_conv_ws_sk<true>), sgrid, dim3(768), LDS256, st, *a, g, skg);
+        else hipLaunchKernelGGL((k_conv_ws_sk<false>), sgrid, dim3(768), LDS256, st, *a, g, skg);
+    } else if (route256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
@@ -2111,7 +2275,11 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (upm) hipLaunchKernelGGL((k_conv_lean<64, 4, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
     }
-    if (S > 1) {
+    if (fused_reduce) {
+        const int V = (int)Vobj;
+        if (want_stats) { hipLaunchKernelGGL((k_conv_sk_reduce<true>), dim3((unsigned)(M / 64)), dim3(256), 0, st, *a, M, V, skg, sk_on ? 0 : S); stats_done = true; }
+        else hipLaunchKernelGGL((k_conv_sk_reduce<false>), dim3((unsigned)(M / 64)), dim3(256), 0, st, *a, M, V, skg, sk_on ? 0 : S);
+    } else if (S > 1) {
         const long n4 = M * (a->N / 4);
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);

@@ -54,7 +54,7 @@ class ConvArgs(C.Structure):
                 ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
                 ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
                 ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32), ('O_hint', C.c_int32),
-                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p)]
+                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p), ('O_base', C.c_int32)]
 
 
 class GNArgs(C.Structure):

@@ -167,6 +167,7 @@ class VolBuilderMixin:
         a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
         a.epilogue = epilogue
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem
+        a.O_base = int(getattr(self, 'o_base', 0) or 0) if a.O_hint else 0      # ... and where this shard's objects sit in it (stream-K cuts)
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
         # eligibility from the WHOLE problem's row count (O_hint): a shard and the unsharded run must take the same can_split

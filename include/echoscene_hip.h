@@ -220,6 +220,9 @@ typedef struct es_conv_args {
                                  instead.  One summation order for all routes (even rows of the group top to bottom, odd
                                  rows top to bottom, then the two halves): the same bits whichever route ran.
                                  Requires voxels per object % 64 == 0, out_f32 != NULL, channels-last output         */
+    int32_t O_base;           /* with O_hint > O: index of this launch's first object inside the whole problem (objects [O_base,
+                                 O_base + O) of O_hint).  Stream-K cuts the K units of ALL tiles of the whole problem as one
+                                 sequence; a shard runs exactly the pieces of its own tiles                                   */
 } es_conv_args;
 enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
