@@ -88,16 +88,12 @@ def time_dominant_kernel(ss, dev, reps=5):
             continue                             # direct small-N kernel / NCDHW output / (Cin == 32: the zero-padded 3-channel input conv)
         tiles = ((M + 255) // 256) * ((c.N + 223) // 224)
         if tiles < 256:
-            # mirrors es_conv_mfma_f16: stream-K over the 256-row producer/consumer tiles (k_conv_ws_sk) when the K units of all
-            # tiles give more workgroups than tiles; otherwise the launch stays on the 128- / 64-row k_conv_lean tiles
-            unit = 3 if c.taps == 27 else 1
-            UT = c.taps * (c.Cin // 32) // unit + (c.Cin2 // 32 if c.a2 else 0)
-            W, G = tiles * UT, 256
-            G = min(G, W // ((24 + unit - 1) // unit))
-            smax = 16 if M * c.N <= (1 << 22) else 8
-            G = min(G, W // ((UT + smax - 2) // (smax - 1)))
-            if not (G > tiles and G >= 96 and c.epilogue == 0 and c.workspace and (c.D * c.H * c.W) % 256 == 0):
-                continue
+            nks = c.taps * (c.Cin // 32) + (c.Cin2 // 32 if c.a2 else 0)
+            s2 = min(256 // tiles, 16 if M * c.N <= (1 << 22) else 8)
+            while s2 > 1 and nks // s2 < 24:
+                s2 -= 1
+            if not (s2 >= 2 and tiles * s2 >= 160 and c.epilogue == 0 and c.workspace):
+                continue                         # stays on the 128- / 64-row k_conv_lean tiles
         ops.append(op)
         flops += 2.0 * M * c.N * (c.Cin * c.taps + c.Cin2)
     if not ops:

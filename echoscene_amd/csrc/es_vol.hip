@@ -164,8 +164,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
         for (int vl = ty; vl < vox_per_block; vl += TY) {
             const int v = v0 + vl;
             if (v >= a.V) break;
-            const float* p = src + ((long)o * a.V + v) * ld + cc;
-            const f4 x0 = *(const f4*)p, x1 = *(const f4*)(p + 4);
+            f4 x0, x1;
+            if (a.x1_is_f16) {                       // (wave-uniform) the source is the producing conv's f16-only output
+                const h8 hx = *(const h8*)((const _Float16*)(const void*)src + ((long)o * a.V + v) * ld + cc);
+                x0 = f4{(float)hx[0], (float)hx[1], (float)hx[2], (float)hx[3]};
+                x1 = f4{(float)hx[4], (float)hx[5], (float)hx[6], (float)hx[7]};
+            } else {
+                const float* p = src + ((long)o * a.V + v) * ld + cc;
+                x0 = *(const f4*)p; x1 = *(const f4*)(p + 4);
+            }
             f4 y0 = x0 * sc0 + sh0, y1 = x1 * sc1 + sh1;
             h8 y, r;
 #pragma unroll
@@ -1222,58 +1229,6 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_ws_sk: STREAM-K launch of the same tile code for problems with fewer than 256 tiles of 256 rows (the 16x4x4 level at one
-// scene: 96 tiles; every level at <= 16 objects per GPU).  Plain split K gives every tile the same integer number S of K ranges, so the
-// launch runs tiles x S workgroups -- 96 x 2 = 192 on 256 CUs (a quarter of the chip idle), and S = 3 would need a second round.  Here
-// the launch is G workgroups (one per CU) and the tiles' K units are ONE sequence of W = tiles x UT split units (tile-major: row tile,
-// then column tile, then K); workgroup w owns units [w W / G, (w + 1) W / G) -- at most two pieces of neighbouring tiles -- and writes
-// each piece's partial tile to its own workspace slab (slot = the piece's ordinal inside its tile); k_conv_sk_reduce sums a tile's
-// slabs in slot order (deterministic).  The cut positions are a function of (layer, object count of the WHOLE problem, G): a shard of
-// a multi-GPU run that passes O_hint / O_base executes exactly the pieces of its own tiles (bit-identical partial sums).
-// ---------------------------------------------------------------------------------------------
-struct SkGeom {
-    int ntn, UT, unit, nks0;        // column tiles; split units per tile; K steps per phase-0 unit (3: one (chunk, kd, kh) group, or 1)
-    int W;                          // tiles of the WHOLE problem x UT   (W * (G + 1) < 2^31: checked by the host)
-    int G;                          // workgroups of the WHOLE problem
-    int g0;                         // first (global) workgroup this launch runs
-    int t_lo, t_hi;                 // (global) tiles this launch owns: [t_lo, t_hi), tile = row tile * ntn + column tile
-};
-// workgroup that owns split unit u: b_w = floor(w W / G) <= u  <=>  w <= ceil((u + 1) G / W) - 1
-__device__ __host__ __forceinline__ int sk_owner(int u, int W, int G) { return (int)(((unsigned)(u + 1) * (unsigned)G - 1u) / (unsigned)W); }
-
-template <bool UP_>
-__global__ __launch_bounds__(768, 3) void k_conv_ws_sk(const es_conv_args a, const ConvGeom g, const SkGeom sk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long M = (long)g.O * g.D * g.H * g.W;
-    // XCD-contiguous ranges of workgroups (as conv_tile_of): neighbours in the unit sequence share an L2
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int gid = sk.g0 + L;
-    int lo = (int)((unsigned)gid * (unsigned)sk.W / (unsigned)sk.G), hi = (int)((unsigned)(gid + 1) * (unsigned)sk.W / (unsigned)sk.G);
-    if (lo < sk.t_lo * sk.UT) lo = sk.t_lo * sk.UT;
-    if (hi > sk.t_hi * sk.UT) hi = sk.t_hi * sk.UT;
-    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
-    const int U0 = sk.nks0 / sk.unit;
-    for (int u = lo; u < hi;) {
-        const int t = u / sk.UT;
-        const int ub = u - t * sk.UT;
-        const int ue = (hi - t * sk.UT) < sk.UT ? (hi - t * sk.UT) : sk.UT;
-        const int tl = t - sk.t_lo;
-        const int bx = __builtin_amdgcn_readfirstlane(tl / sk.ntn), by = __builtin_amdgcn_readfirstlane(tl - (tl / sk.ntn) * sk.ntn);
-        const int slot = __builtin_amdgcn_readfirstlane(gid - sk_owner(t * sk.UT, sk.W, sk.G));
-        const int ks_begin = __builtin_amdgcn_readfirstlane(ub <= U0 ? ub * sk.unit : sk.nks0 + (ub - U0));
-        const int ks_end = __builtin_amdgcn_readfirstlane(ue <= U0 ? ue * sk.unit : sk.nks0 + (ue - U0));
-        conv_ws_tile<256, 8, 4, UP_, ES_EPI_NONE, false>(a, g, 0, smem, wave, lane, M, bx, by, ks_begin, ks_end, 2, slot, nullptr);
-        u = t * sk.UT + ue;
-        __syncthreads();                         // the next piece's ring overwrites this piece's epilogue slabs
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
 // k_linear_ws: k_conv_ws for the 1x1 / linear launches with several column tiles (qkv: 6, FeedForward: 16-24), where a tile has only
 // 14-84 K units against ~23 us of per-tile cost outside the K loop (tools/microbench_epilogue.py).  A workgroup owns ONE row tile and
 // walks NCB consecutive column tiles: the K units of all of them form one stream through the ring -- the producers' per-row set-up is
@@ -1735,6 +1690,97 @@ __global__ __launch_bounds__(256) void k_conv_small_n_tiled(const es_conv_args a
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_n16: 3x3x3 conv with N <= 16 output channels from a WIDE input (the UNet's output conv 224 -> 3, out.2 of
+// openai_model_3d.py:735-739).  On the 224-column MFMA tile this launch is 98.7 % padding and 265 us (1.4 % of the step): a
+// workgroup there streams one gathered 256 x 32 A tile per (chunk, tap) -- the same voxels 27 times -- for ONE useful MFMA column.
+// Here a workgroup owns a 4 x 4 x 16 block of output voxels and stages its 6 x 6 x 18 halo (out-of-volume voxels = zero fill of the
+// LDS-DMA) ONCE per 32-channel chunk: 2.5x the block instead of 27x; the 27 taps are 27 shifted fragment reads of that LDS image.
+// B = the first sixteen rows (1 KiB, already swizzled) of the K step's block in the ordinary tiled weight image.  Wave w owns depth
+// slice w: four 16-voxel MFMA row tiles (one per h row), K order = (chunk outer, tap inner) as in the tile kernels -- same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int N16_ROWS = 6 * 6 * 18;                       // halo'd voxels of a 4 x 4 x 16 block
+constexpr int N16_A_BYTES = 44 * 1024, N16_B_BYTES = 28 * 1024;
+
+__global__ __launch_bounds__(256, 2) void k_conv_n16(const es_conv_args a, const ConvGeom g) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + N16_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw = g.W >> 4, th = g.H >> 2, td = g.D >> 2;
+    int t = blockIdx.x;
+    const int bw = t % tw; t /= tw;
+    const int bh = t % th; t /= th;
+    const int bd = t % td;
+    const int o = t / td;
+    const int Cin = a.Cin, kch = Cin >> 5;
+    // ---- staging roles: piece p = wave + 4 j (j < 11) covers LDS bytes [p KiB, p KiB + 1 KiB): 16 halo'd voxels x 64 B
+    constexpr int NPA = 11, NPB = 7;
+    unsigned voff[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int piece = wave + 4 * j;
+        const int slot = piece * 64 + lane;                  // 16-B slot of the image: row = slot >> 2, physical chunk = slot & 3
+        const int row = slot >> 2;
+        const int lc = (slot & 3) ^ f_swz(row);
+        const int hw = row % 18, hh = (row / 18) % 6, hd = row / 108;
+        const int d = bd * 4 - 1 + hd, h = bh * 4 - 1 + hh, w = bw * 16 - 1 + hw;
+        const bool ok = row < N16_ROWS && d >= 0 && d < g.D && h >= 0 && h < g.H && w >= 0 && w < g.W;
+        voff[j] = ok ? (unsigned)((((o * g.D + d) * g.H + h) * g.W + w) * Cin * 2 + lc * 16) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.a), (short)0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w), (short)0, (int)OOB, 0x00020000);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int rowbase = (wave * 6) * 18 + i16;              // LDS row of (depth slice wave, h 0, w i16) at tap (0, 0, 0)
+    f4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    const int fragB = i16 * 64 + ((q ^ f_swz(i16)) << 4);
+    for (int c = 0; c < kch; ++c) {
+        if (c) __syncthreads();                              // every wave is done with the previous chunk's image
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int piece = wave + 4 * j;
+            if (piece < 44)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(As + piece * 1024), 16, (int)voff[j], (int)((unsigned)c * 64u), 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const int tap = wave + 4 * j;                    // 27 pieces: the first 16 rows of the K step's weight block
+            if (tap < 27)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(Bs + tap * 1024), 16, (int)((unsigned)lane * 16u),
+                                                         (int)((unsigned)(c * 27 + tap) * (unsigned)(BNP * BK * 2)), 0, 0);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+#pragma unroll 3
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const h8 bf = *(const h8*)(Bs + tap * 1024 + fragB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rowbase + ((kd * 6) + kh + i) * 18 + kw;
+                const h8 af = *(const h8*)(As + row * 64 + ((q ^ f_swz(row)) << 4));
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane holds D[voxel = q*4 + r of the row tile][column = i16]; NCDHW fp32 output (+ bias)
+    if (i16 < a.N) {
+        const float bias = a.bias ? a.bias[i16] : 0.f;
+        const long V = (long)g.D * g.H * g.W;
+        float* outp = a.out_f32 + ((long)o * a.N + i16) * V;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long vox = ((long)(bd * 4 + wave) * g.H + bh * 4 + i) * g.W + bw * 16 + q * 4;
+            *(f4*)(outp + vox) = f4{acc[i][0] + bias, acc[i][1] + bias, acc[i][2] + bias, acc[i][3] + bias};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // VQ nearest-codebook lookup (quantizer.py:68-119): d_j = |z|^2 + |e_j|^2 - 2 z.e_j, argmin_j
 // (first minimum), output = lut[argmin] written as channels-last f16 padded to Cpad.  lut is the
 // codebook already passed through post_quant_conv (a 1x1x1 conv, folded on the host).
@@ -1802,72 +1848,6 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a
         if (a.out_f16) {
             h4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
-        }
-    }
-}
-
-// Split-K / stream-K reduction with the epilogue AND the next GroupNorm's row-group sums in one pass: one workgroup per 64-row group,
-// thread = (row parity, column quad) -- the even rows of the group top to bottom in one lane, the odd rows in its neighbour, then the
-// two halves: the summation order of conv_epilogue<STATS_> and k_rowgroup_stats, so every route leaves the same bits.  The slabs of an
-// element are added in slot order (fixed).  S_plain > 0: every tile has S_plain slabs (plain split K, any tile size); S_plain == 0:
-// stream-K, the slab count of a tile follows from the cut positions (SkGeom).  Requires M % 64 == 0 and voxels per object % 64 == 0.
-template <bool STATS_>
-__global__ __launch_bounds__(256) void k_conv_sk_reduce(const es_conv_args a, const long M, const int V, const SkGeom sk, const int S_plain) {
-    const int N4 = a.N >> 2;
-    const long MN = M * a.N;
-    const long m0 = (long)blockIdx.x * 64;
-    const int par = threadIdx.x & 1;
-    const long nrg = M >> 6;
-    const float* rvp = a.rowvec ? a.rowvec + (m0 / V) * a.rowvec_ld : nullptr;
-    for (int qi = threadIdx.x >> 1; qi < N4; qi += 128) {
-        const int n = qi * 4;
-        int ns = S_plain;
-        if (S_plain == 0) {
-            const int t = sk.t_lo + (int)(m0 >> 8) * sk.ntn + n / BN;
-            ns = sk_owner((t + 1) * sk.UT - 1, sk.W, sk.G) - sk_owner(t * sk.UT, sk.W, sk.G) + 1;
-        }
-        f4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) b4 = *(const f4*)&a.bias[n];
-        if (rvp) r4 = *(const f4*)&rvp[n];
-        f4 gs = {0.f, 0.f, 0.f, 0.f}, gq = {0.f, 0.f, 0.f, 0.f};
-        const float* p0 = (const float*)a.workspace + (m0 + par) * a.N + n;
-        for (int r0 = 0; r0 < 32; r0 += 4) {
-            f4 v[4], rr[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long ro = (long)(2 * (r0 + k)) * a.N;
-                v[k] = *(const f4*)(p0 + ro);
-                rr[k] = a.res ? *(const f4*)&a.res[(m0 + par + 2 * (r0 + k)) * a.out_ld + n] : f4{0.f, 0.f, 0.f, 0.f};
-            }
-            for (int z = 1; z < ns; ++z) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += *(const f4*)(p0 + (long)z * MN + (long)(2 * (r0 + k)) * a.N);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long m = m0 + par + 2 * (r0 + k);
-                f4 x = v[k];
-                x += b4; x += r4; x += rr[k];
-                if (a.out_f32) *(f4*)&a.out_f32[m * a.out_ld + n] = x;
-                if (a.out_f16) {
-                    const h4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
-                    *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + n) = hv;
-                }
-                if (STATS_) {
-                    gs += x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gq[e] = fmaf(x[e], x[e], gq[e]);
-                }
-            }
-        }
-        if (STATS_) {
-            f4 os, oq;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { os[e] = __shfl_xor(gs[e], 1); oq[e] = __shfl_xor(gq[e], 1); }
-            if (par == 0) {
-                *(f4*)&a.gn_stats_out[(long)blockIdx.x * a.N + n] = gs + os;
-                *(f4*)&a.gn_stats_out[(nrg + blockIdx.x) * a.N + n] = gq + oq;
-            }
         }
     }
 }
@@ -2084,6 +2064,21 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         ES_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    // N <= 16 from a wide input, NCDHW fp32 output, no fusions (the UNet's output conv): halo'd LDS image + one MFMA column
+    static const char* n16_env = getenv("ES_CONV_N16");           // A/B switch (timing only: same K order, same bits): 0 = off
+    if (a->N <= 16 && a->taps == 27 && a->Cin > 64 && ncdhw && a->mode == ES_CONV_SAME && !a->a2 && !a->res && !a->rowvec &&
+        !a->out_f16 && a->D % 4 == 0 && a->H % 4 == 0 && a->W % 16 == 0 && !(n16_env && atoi(n16_env) == 0) &&
+        (long)a->O * a->D * a->H * a->W * a->Cin * 2 < (1L << 31)) {
+        if (emits) { *emits = 0; return 0; }
+        static std::once_flag once_n;
+        static hipError_t attr_n = hipSuccess;
+        std::call_once(once_n, [] { attr_n = hipFuncSetAttribute((const void*)k_conv_n16, hipFuncAttributeMaxDynamicSharedMemorySize, N16_A_BYTES + N16_B_BYTES); });
+        ES_REQUIRE(attr_n == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_n));
+        const unsigned nblk = (unsigned)((long)a->O * (a->D / 4) * (a->H / 4) * (a->W / 16));
+        hipLaunchKernelGGL(k_conv_n16, dim3(nblk), dim3(256), N16_A_BYTES + N16_B_BYTES, (hipStream_t)stream, *a, g);
+        ES_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int ntn = (a->N + BN - 1) / BN;
     // small-M layers (16x4x4 level): 64-row tiles double the number of workgroups (>= 1 per CU)
     // Tile / split choice by workgroup count (256 CUs x 2 resident workgroups):
@@ -2098,9 +2093,9 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     hipStream_t st = (hipStream_t)stream;
     const bool want_stats = a->gn_stats_out != nullptr;
     bool stats_done = false;
-    ES_REQUIRE(!want_stats || (a->out_f32 && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (a->D * a->H * a->W) % 64 == 0 &&
+    ES_REQUIRE(!want_stats || ((a->out_f32 || a->out_f16) && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (a->D * a->H * a->W) % 64 == 0 &&
                                a->epilogue == ES_EPI_NONE),
-               "es_conv_mfma_f16: gn_stats_out needs a channels-last fp32 output, N %% 4 == 0 and voxels per object %% 64 == 0");
+               "es_conv_mfma_f16: gn_stats_out needs a channels-last output, N %% 4 == 0 and voxels per object %% 64 == 0");
     int S = a->splitk;
     const bool can_split = a->workspace && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0);
     if (S < 0) {                                           // auto
@@ -2156,34 +2151,6 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         while (s2 > 1 && nks / s2 < 24) --s2;
         if (s2 >= 2 && hg256 * s2 >= 160) { S = s2; ws_split = true; }
     }
-    // Stream-K instead of an integer split factor (k_conv_ws_sk): G workgroups share the K units of all tiles as one sequence.
-    static const char* sk_env = getenv("ES_CONV_STREAMK");         // A/B switch (timing only; it changes where K sums are cut): 0 = off
-    bool sk_on = false;
-    SkGeom skg{};
-    const long Vobj = (long)a->D * a->H * a->W;
-    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && !(wss_env && atoi(wss_env) == 0) &&
-        !(sk_env && atoi(sk_env) == 0) && Vobj % 256 == 0 && ws_epilogue_ok) {
-        static const int n_cu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-        const int kch2 = a->a2 ? a->Cin2 / 32 : 0;
-        skg.ntn = ntn; skg.unit = a->taps == 27 ? 3 : 1; skg.nks0 = a->taps * (a->Cin / 32);
-        skg.UT = skg.nks0 / skg.unit + kch2;
-        const long Wl = hg256 * skg.UT;                            // tiles of the WHOLE problem x split units per tile
-        skg.W = (int)Wl;
-        long G = n_cu;
-        const long min_units = (24 + skg.unit - 1) / skg.unit;    // >= 24 K steps per workgroup on average
-        if (skg.W / G < min_units) G = skg.W / min_units;
-        const int smax = Mh * (long)a->N <= (1L << 22) ? 16 : 8;  // workspace contract (echoscene_hip.h): slabs per tile
-        const long min_chunk = (skg.UT + smax - 2) / (smax - 1);  // a tile is cut into at most ceil(UT / chunk) + 1 <= smax pieces
-        if (G > 0 && skg.W / G < min_chunk) G = skg.W / min_chunk;
-        if (G > hg256 && G >= 96 && Wl * (G + 2) < (1L << 31)) {  // more workgroups than tiles (else: no split needed / other routes)
-            sk_on = true; ws_split = false; S = 1;
-            skg.G = (int)G;
-            const long o_base = a->O_hint > a->O ? a->O_base : 0;
-            skg.t_lo = (int)((o_base * Vobj / 256) * ntn);
-            skg.t_hi = skg.t_lo + (int)(((M + 255) / 256) * ntn);
-            skg.g0 = (int)sk_owner(skg.t_lo * skg.UT, skg.W, skg.G);
-        }
-    }
     // Tiny K-short problems (the transformer linears at <= 8 objects per GPU: e.g. 1024 rows x 672 columns, 21 K units): even the
     // 64-row tiles give only a few dozen workgroups, each a lone, latency-bound chain of K units (22-30 us for < 1 GFLOP).
     // Split K over 64-row tiles until about one workgroup per CU runs (>= 5 units per split).
@@ -2191,7 +2158,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     bool tiny_split = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
-        if (!ws_split && !sk_on && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
+        if (!ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
             !(tiny_env && atoi(tiny_env) == 0)) {
             int s3 = (int)((256 + hg64 - 1) / hg64);
             const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
@@ -2200,22 +2167,20 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    const bool route256 = (wg256 >= 256 || force256 || ws_split || sk_on) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
-    if (route256 && !sk_on && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
+    if (route256 && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
         static const int cand[5] = {8, 6, 4, 3, 2};
         for (int k = 0; k < 5; ++k)
             if (ntn % cand[k] == 0 && ((M + 255) / 256) * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
     }
     // the producer/consumer 256-row kernel forms the row-group sums of gn_stats_out in its epilogue; every other route runs
     // k_rowgroup_stats over the finished output
-    const bool epi_stats = route256 && !sk_on && ncb == 1 && ws && !geglu && S == 1 && a->out_f32 && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
+    const bool epi_stats = route256 && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
                            (a->D * a->H * a->W) % 64 == 0;
-    // split-K / stream-K launches: the reduction pass forms the sums on the way (k_conv_sk_reduce<true>)
-    const bool fused_reduce = (S > 1 || sk_on) && M % 64 == 0 && Vobj % 64 == 0 && a->N % 4 == 0 && a->out_ld % 4 == 0;
-    if (emits) { *emits = (epi_stats || (fused_reduce && a->out_f32)) ? 1 : 0; return 0; }
+    if (emits) { *emits = epi_stats ? 1 : 0; return 0; }
     {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
@@ -2235,19 +2200,12 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
-            set((const void*)k_conv_ws_sk<false>, LDS256);
-            set((const void*)k_conv_ws_sk<true>, LDS256);
             set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
-    if (sk_on) {
-        const int g1 = (int)sk_owner(skg.t_hi * skg.UT - 1, skg.W, skg.G);
-        const dim3 sgrid((unsigned)(g1 - skg.g0 + 1), 1, 1);
-        if (upm) hipLaunchKernelGGL((k_conv_ws_sk<true>), sgrid, dim3(768), LDS256, st, *a, g, skg);
-        else hipLaunchKernelGGL((k_conv_ws_sk<false>), sgrid, dim3(768), LDS256, st, *a, g, skg);
-    } else if (route256) {
+    if (route256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
@@ -2275,16 +2233,14 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (upm) hipLaunchKernelGGL((k_conv_lean<64, 4, true>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<64, 4>), grid, dim3(256), LDS64, st, *a, g, ncdhw);
     }
-    if (fused_reduce) {
-        const int V = (int)Vobj;
-        if (want_stats) { hipLaunchKernelGGL((k_conv_sk_reduce<true>), dim3((unsigned)(M / 64)), dim3(256), 0, st, *a, M, V, skg, sk_on ? 0 : S); stats_done = true; }
-        else hipLaunchKernelGGL((k_conv_sk_reduce<false>), dim3((unsigned)(M / 64)), dim3(256), 0, st, *a, M, V, skg, sk_on ? 0 : S);
-    } else if (S > 1) {
+    if (S > 1) {
         const long n4 = M * (a->N / 4);
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
     }
     if (want_stats && !stats_done) {
+        ES_REQUIRE(a->out_f32, "es_conv_mfma_f16: this launch's route forms gn_stats_out by a pass over the fp32 output: out_f32 must be given "
+                               "(es_conv_emits_gn_stats() == 0)");
         const long n4 = ((M + 63) / 64) * (a->N / 4);
         const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
         hipLaunchKernelGGL(k_rowgroup_stats, dim3(blocks), dim3(256), 0, st, (const float*)a->out_f32, M, a->N, a->out_ld, a->gn_stats_out);
@@ -2315,7 +2271,9 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     const int ntiles = (a->V + vt - 1) / vt;
     float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats
     static const char* rg_env = getenv("ES_GN_RG");            // A/B switch: 0 = always the statistics pass over x
-    const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && !(rg_env && atoi(rg_env) == 0);
+    const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && (a->x1_is_f16 || !(rg_env && atoi(rg_env) == 0));
+    ES_REQUIRE(!a->x1_is_f16 || (from_rg && !a->x2 && !a->raw_f16),
+               "es_groupnorm_vol: an f16 source needs the producer's row-group sums (stats1), one source, no raw copy");
     if (!from_rg) hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
     int vpb = 32;
     while (vpb > 8 && (long)a->O * ((a->V + vpb - 1) / vpb) < 512) vpb >>= 1;

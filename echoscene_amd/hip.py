@@ -54,14 +54,14 @@ class ConvArgs(C.Structure):
                 ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
                 ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
                 ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32), ('O_hint', C.c_int32),
-                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p), ('O_base', C.c_int32)]
+                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p)]
 
 
 class GNArgs(C.Structure):
     _fields_ = [('x1', C.c_void_p), ('C1', C.c_int32), ('x2', C.c_void_p), ('C2', C.c_int32), ('O', C.c_int32),
                 ('V', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('silu', C.c_int32), ('stats', C.c_void_p), ('y_f16', C.c_void_p),
-                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p)]
+                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p), ('x1_is_f16', C.c_int32)]
 
 
 class LNArgs(C.Structure):

@@ -179,6 +179,7 @@ class EchoToShape(object):
         z = den.sample(self.uc_rel, self.triples, noise1=noise,
                        c=self.rel if (self.df.conditioning_key == 'concat' or
                                       not self.df.diffusion_net.messsage_passing) else None)
+        self.gen_z = z                      # the latents handed to the VQ-VAE (echo2shape.py:521-522), kept like gen_df
         self.gen_df = self._decoder().decode_no_quant(z, sync=sync)
         return self.gen_df
 
@@ -400,6 +401,7 @@ class Sg2ScDiffModel(_SceneModel):
         s_, t_ = L.size_dim, L.translation_dim
         boxes = {'sizes': x[:, 0:s_].contiguous(), 'translations': x[:, s_:s_ + t_].contiguous(),
                  'angles': x[:, s_ + t_:L.bbox_dim].contiguous()}
+        S.gen_z = z
         S.gen_df = S._decoder().decode_no_quant(z, sync=True)
         return S.gen_df, boxes
 

@@ -167,7 +167,6 @@ class VolBuilderMixin:
         a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
         a.epilogue = epilogue
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem
-        a.O_base = int(getattr(self, 'o_base', 0) or 0) if a.O_hint else 0      # ... and where this shard's objects sit in it (stream-K cuts)
         # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
         M = O * D * H * W
         # eligibility from the WHOLE problem's row count (O_hint): a shard and the unsharded run must take the same can_split
@@ -231,6 +230,42 @@ class VolBuilderMixin:
         assert op.u.conv.gn_stats_out == ent[1].data_ptr() and op.u.conv.out_f32 == x.data_ptr()
         return ent[1]
 
+    def conv_gn_intermediate(self, a_f16, pc, O, dims, rowvec=None):
+        """A conv whose output is read ONLY by a GroupNorm -- the conv1 -> GroupNorm -> conv2 intermediate of a ResBlock
+        (openai_model_3d.py:294-314, vqvae_modules.py:67-126), never part of the residual stream.  It is written ONCE, as f16 (the
+        operand precision the GroupNorm emits anyway), with the GroupNorm's statistics formed from the conv's fp32 values before the
+        rounding (es_conv_args.gn_stats_out): 6 B per element less HBM traffic than fp32 out + fp32 in.
+        Only where the launch forms those sums itself (es_conv_emits_gn_stats); a deterministic shard follows the decision of
+        the WHOLE problem and, when its own route cannot form them, writes fp32 as well (the sums then come from a pass over it:
+        same order, same bits; the GroupNorm still reads the f16 tensor).  Returns the tensor the GroupNorm is to read."""
+        D, H, W = dims
+        M, V = O * D * H * W, D * H * W
+        h16 = self.buf(M, pc.N, dtype=torch.float16, scratch=True)
+        idx = self.conv(a_f16, pc, O, dims, rowvec=rowvec, out_f16=h16)
+        op = self.ops[idx]
+        L = hip.lib()
+        if V % 64 == 0 and os.environ.get('ES_GN_RG', '1') != '0' and os.environ.get('ES_GN_F16', '1') != '0':
+            whole = ConvArgs.from_buffer_copy(op.u.conv)
+            if whole.O_hint > whole.O:
+                whole.O, whole.O_hint = whole.O_hint, 0
+            if L.es_conv_emits_gn_stats(C.byref(whole)) == 1:
+                st = self.buf(2 * (M // 64) * pc.N, scratch=True)
+                op.u.conv.gn_stats_out = st.data_ptr()
+                if L.es_conv_emits_gn_stats(C.byref(op.u.conv)) != 1:
+                    h32 = self.buf(M, pc.N, scratch=True)
+                    op.u.conv.out_f32 = h32.data_ptr()
+                    self.keep.append(h32)
+                if not hasattr(self, '_f16_stats'):
+                    self._f16_stats = {}
+                self._f16_stats[h16.data_ptr()] = st
+                return h16
+        h32 = self.buf(M, pc.N, scratch=True)
+        op.u.conv.out_f32, op.u.conv.out_f16 = h32.data_ptr(), None
+        if not hasattr(self, '_conv_of'):
+            self._conv_of = {}
+        self._conv_of[h32.data_ptr()] = (idx, M, pc.N)
+        return h32
+
     def groupnorm(self, x1, C1, x2, C2, O, V, gamma, beta, eps, silu, y_f16, raw_f16=None, groups=32):
         a = GNArgs()
         a.x1, a.C1 = x1.data_ptr(), C1
@@ -246,6 +281,12 @@ class VolBuilderMixin:
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)
         # statistics from the producing convs' epilogues instead of a pass over x1 / x2 (both sources must have them)
+        if x1.dtype == torch.float16:               # the f16-only output of conv_gn_intermediate(): statistics from that conv's sums
+            assert x2 is None and raw_f16 is None
+            a.x1_is_f16 = 1
+            a.stats1 = self._f16_stats[x1.data_ptr()].data_ptr()
+            self.keep += [gamma, beta]
+            return self._push(hip.OP_GN, 'gn', a)
         p1 = self._rowgroup_producer(x1, C1, O * V, V)
         p2 = self._rowgroup_producer(x2, C2, O * V, V) if x2 is not None else None
         if p1 is not None and (x2 is None or p2 is not None):
@@ -476,8 +517,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 y1 = sbuf(M, cin, dtype=f16)
                 raw = sbuf(M, cin, dtype=f16) if 'skip' in d else None
                 b.groupnorm(x1, C1, x2, C2, O, V_(dm), d['gn1'][0], d['gn1'][1], 1e-5, True, y1, raw)
-                h1 = sbuf(M, cout)
-                b.conv(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=row0 if emb_ld else 0), out_f32=h1)
+                h1 = b.conv_gn_intermediate(y1, d['conv1'], O, dm, rowvec=View(emb_all, col=eo, ld=emb_ld, width=cout, row=row0 if emb_ld else 0))
                 y2 = sbuf(M, cout, dtype=f16)
                 b.groupnorm(h1, cout, None, 0, O, V_(dm), d['gn2'][0], d['gn2'][1], 1e-5, True, y2)
                 o = sbuf(M, cout)
@@ -563,7 +603,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     return objbuf
 
 
-for _n in ('_push', 'conv', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
+for _n in ('_push', 'conv', 'conv_gn_intermediate', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
     setattr(Builder, _n, getattr(VolBuilderMixin, _n))
 
 
@@ -655,8 +695,7 @@ def emit_vq_decode(b, w, z, sdf_out, Oc, zdims=(16, 16, 16)):
         y1 = sbuf(M, cin, dtype=f16)
         raw = sbuf(M, cin, dtype=f16) if 'skip' in r else None
         gn(x, cin, r['gn1'][0], r['gn1'][1], 1, y1, raw)
-        h1 = sbuf(M, cout)
-        b.conv(y1, r['conv1'], Oc, dm, out_f32=h1)
+        h1 = b.conv_gn_intermediate(y1, r['conv1'], Oc, dm)
         y2 = sbuf(M, cout, dtype=f16)
         gn(h1, cout, r['gn2'][0], r['gn2'][1], 1, y2)
         o = sbuf(M, cout)

@@ -205,7 +205,7 @@ class ShapeDenoiser:
             b.shard_block = block
             b.force_exchange = self.force_exchange
             if self.world > 1 and self.deterministic:
-                b.o_hint, b.o_base = O, lo      # split-K / stream-K / partial-sum tiling as in the unsharded run -> bit-identical latents
+                b.o_hint = O       # split-K / partial-sum tiling as in the unsharded run -> bit-identical latents
             x = b.buf(hi - lo, *self.z_shape)
             eps = b.buf(hi - lo, *self.z_shape)
             step = b.buf(1, dtype=torch.int32, zero=True)

@@ -219,10 +219,8 @@ typedef struct es_conv_args {
                                  128-row tiles, k_linear_ws, split K, object chunks) a small kernel passes over the output
                                  instead.  One summation order for all routes (even rows of the group top to bottom, odd
                                  rows top to bottom, then the two halves): the same bits whichever route ran.
-                                 Requires voxels per object % 64 == 0, out_f32 != NULL, channels-last output         */
-    int32_t O_base;           /* with O_hint > O: index of this launch's first object inside the whole problem (objects [O_base,
-                                 O_base + O) of O_hint).  Stream-K cuts the K units of ALL tiles of the whole problem as one
-                                 sequence; a shard runs exactly the pieces of its own tiles                                   */
+                                 Requires voxels per object % 64 == 0, channels-last output; out_f32 may be NULL (f16-only output)
+                                 when es_conv_emits_gn_stats() == 1: the sums are formed from the fp32 values before rounding     */
 } es_conv_args;
 enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
@@ -252,6 +250,10 @@ typedef struct es_gn_args {
                                         present the statistics pass over x1 / x2 is skipped: (object, group) statistics are
                                         reduced from these sums (double, fixed order)                                */
     const float* stats2;
+    int32_t x1_is_f16;               /* 1: x1 points at an f16 [O, V, C1] tensor -- the f16-ONLY output of the conv that produced it (a
+                                        ResBlock's conv1 -> GroupNorm -> conv2 intermediate is never part of the residual stream: it is
+                                        written once, as the operand precision the next contraction reads anyway, openai_model_3d.py:
+                                        294-314).  Requires stats1 (the statistics are the conv's sums over its fp32 values), no x2   */
 } es_gn_args;
 /* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
  * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats (a pass over x, or a reduction of

@@ -578,12 +578,24 @@ class _SGDiffHarness:
                 return noise1.clone()
             return _randn(*a, **k)
         torch.randn = randn
+        # the latents the DDIM loop hands to the VQ-VAE (rel2shape -> vqvae.decode_no_quant, echo2shape.py:521-522): recorded so that a
+        # consumer can be compared BEFORE the codebook argmin, which turns a 4th-digit difference into an O(1) local change of the SDF
+        self.last_z = None
+        vq = self.m.diff.ShapeDiff.vqvae if self.typ == 'echoscene' else None
+        _dec = vq.decode_no_quant if vq is not None else None
+        if vq is not None:
+            def dec(z, *a, **k):
+                self.last_z = z.detach().clone()
+                return _dec(z, *a, **k)
+            vq.decode_no_quant = dec
         try:
             with torch.no_grad():
                 r = fn()
         finally:
             torch.randn = _randn
             dd.DiffusionPoint.gen_samples_sg = _orig_gen
+            if vq is not None:
+                vq.decode_no_quant = _dec
         assert calls['n'] == 101, calls
         return r
 
@@ -687,6 +699,8 @@ def case_scene_flags():
         for k, v in d.items():
             if v is not None:
                 out['%s_%s' % (typ, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+        if typ == 'echoscene':
+            out['echoscene_z'] = h.last_z
         dec = (h.objs, h.triples, h.tf, h.rf)
         np.random.seed(123)
         keep, d = h.call(lambda: m.sample_boxes_and_shape_with_changes(*dec, *dec, manipulated, **(
@@ -696,6 +710,8 @@ def case_scene_flags():
         for k, v in d.items():
             if v is not None:
                 out['%s_chg_%s' % (typ, k)] = v[:, :, ::4, ::4, ::4] if k == 'shapes' else v
+        if typ == 'echoscene':
+            out['echoscene_chg_z'] = h.last_z
         out.update(objs=h.objs, triples=h.triples)
     out.update(manipulated=np.array(manipulated))
     save('scene_flags_tiny', **out)

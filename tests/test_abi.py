@@ -150,10 +150,9 @@ def test_product_does_not_import_oracle():
 
 def test_conv_route_query_for_groupnorm_sums_is_host_only():
     """es_conv_emits_gn_stats: the planner's question "would this conv launch form the next GroupNorm's row-group sums in its own
-    epilogue -- or, round 4, in the reduction pass of a split-K / stream-K launch?" is answered on the host from the dispatcher's own
-    routing (no launch, no device): yes for the 256-row producer/consumer tiles of a 32-object scene and for the launches whose K is
-    split over workgroups (few objects, the 16x4x4 level), no for the GEGLU projection and for volumes with fewer than 64 voxels per
-    object; a deterministic shard (O_hint) is asked about the WHOLE problem by the planner."""
+    epilogue?" is answered on the host from the dispatcher's own routing (no launch, no device): yes for the 256-row
+    producer/consumer tiles of a 32-object scene, no for few objects (split K / small tiles), for the GEGLU projection, for volumes
+    with fewer than 64 voxels per object; a deterministic shard (O_hint) is asked about the WHOLE problem by the planner."""
     import ctypes as C
     from echoscene_amd import hip
     L = hip.lib()
@@ -172,9 +171,8 @@ def test_conv_route_query_for_groupnorm_sums_is_host_only():
         return a
     assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 16, 16), 224, 224))) == 1
     assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 8, 8), 448, 448))) == 1
-    assert L.es_conv_emits_gn_stats(C.byref(args(4, (16, 16, 16), 224, 224))) == 1        # 64 tiles: stream-K, sums from the reduction pass
-    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 4, 4), 672, 672))) == 1         # 96 tiles at the 16x4x4 level: the same
-    assert L.es_conv_emits_gn_stats(C.byref(args(1, (16, 4, 4), 224, 672, taps=1))) == 0  # 7 K units on 64-row tiles, no split: the sums would need a pass of their own
+    assert L.es_conv_emits_gn_stats(C.byref(args(4, (16, 16, 16), 224, 224))) == 0        # 64 tiles: K split over workgroups
+    assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 4, 4), 672, 672))) == 0         # 96 tiles at the 16x4x4 level
     assert L.es_conv_emits_gn_stats(C.byref(args(32, (16, 8, 8), 448, 3584, taps=1, epilogue=hip.EPI_GEGLU, f32=False))) == 0
     assert L.es_conv_emits_gn_stats(C.byref(args(4096, (2, 4, 4), 64, 224))) == 0         # 32 voxels per object
     bad = args(32, (16, 16, 16), 100, 224)                                                # Cin not a multiple of 32

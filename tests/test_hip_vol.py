@@ -45,6 +45,37 @@ def _ncdhw(y, O, D, H, W):
     return y.reshape(O, D, H, W, -1).permute(0, 4, 1, 2, 3).contiguous()
 
 
+@pytest.mark.parametrize('O,Cin,N,dims,bias', [(3, 224, 3, (16, 16, 16), True), (2, 96, 5, (4, 8, 16), False), (1, 128, 16, (8, 4, 32), True)])
+def test_output_conv_narrow_n_kernel(dev, O, Cin, N, dims, bias):
+    """The UNet's output conv (out.2: 3x3x3, 224 -> 3, NCDHW fp32; openai_model_3d.py:735-739) on k_conv_n16 (a halo'd LDS image per
+    4 x 4 x 16 block + ONE 16-column MFMA fragment per tap) vs F.conv3d on the fp16-rounded operands, and -- same K order, same fp32
+    accumulation chain -- BIT-identical to the 224-column tile kernels' result for the same conv (channels-last output route)."""
+    from echoscene_amd.plan import Builder
+    from echoscene_amd.plan_vol import PackedConv
+    D, H, W = dims
+    x = _rnd((O, Cin) + dims, 11).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3), 12) / np.sqrt(Cin * 27)).half().float()
+    bs = _rnd((N,), 13) if bias else None
+    ref = F.conv3d(x, wt, bs, padding=1)
+    b = Builder(dev)
+    a16 = b.dev(_cl(x), torch.float16)
+    pc = PackedConv(wt, bs, dev)
+    out = b.buf(O, N, D, H, W, zero=True)
+    b.conv(a16, pc, O, dims, out_f32=out, ncdhw=True)                 # -> k_conv_n16
+    Np = (N + 3) // 4 * 4
+    wt4 = torch.zeros(Np, Cin, 3, 3, 3)
+    wt4[:N] = wt
+    bs4 = torch.zeros(Np)
+    if bias:
+        bs4[:N] = bs
+    out_cl = b.buf(O * D * H * W, Np, zero=True)
+    b.conv(a16, PackedConv(wt4, bs4, dev), O, dims, out_f32=out_cl)     # channels-last output: the 224-column tile kernels
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-4
+    assert torch.equal(out.cpu(), _ncdhw(out_cl.cpu(), O, D, H, W)[:, :N]), 'k_conv_n16 and the tile kernels must sum in the same order'
+
+
 @pytest.mark.parametrize('mode,N,Cin,dims', [('same', 40, 32, (4, 8, 8)), ('same', 224, 64, (4, 8, 8)),
                                               ('same', 250, 96, (2, 4, 4)), ('down', 48, 64, (4, 4, 4)),
                                               ('up', 48, 32, (4, 8, 8)), ('lin', 300, 64, (4, 4, 4))])

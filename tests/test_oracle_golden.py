@@ -244,6 +244,7 @@ def test_scene_flag_matrix_oracle_vs_reference_api(typ):
             dsd = seeded_state_dict(m.diff.ShapeDiff.df, 'e2e.shape_df.')
             dsd = {k[len('diffusion_net.'):]: v for k, v in dsd.items()}
             z = orc.shape_sample_loop(dsd, orc.rel_s(sd, oe), triples, synth.shape_noise(seed=7), S=4)
+            _close(z, g['echoscene_' + tag + 'z'], 1e-3)                 # the latents the reference's DDIM loop handed to its VQ-VAE
             sdf = orc.vqvae_decode_no_quant(seeded_state_dict(m.diff.ShapeDiff.vqvae, 'e2e.vqvae.'), z)
             _close(sdf[:, :, ::4, ::4, ::4], g['echoscene_' + tag + 'shapes'], 2e-3)
     if typ == 'echoscene':
