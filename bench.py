@@ -185,6 +185,43 @@ def sub_records(dev, lay, use_graph, a):
     return recs
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: exact fp32 in / fp32 accumulate (MI355X_MICROARCH.md)
+
+
+def fp32_route_record(dev, df, sden, uc, triples, conf_params, use_graph, n=2):
+    """The fp32-OPERAND validation route (ShapeDenoiser(precision='fp32'), csrc/es_vol32.hip: the reference's own arithmetic on the
+    same plan) at the benchmarked shape: its step rate with a roofline against the fp32 matrix peak, and -- the point of the route --
+    the difference between one evaluation of the fp16-operand product path and the fp32-operand path on the SAME weights and inputs,
+    i.e. the cost of operand rounding as a measurement (the product path's parity tolerance is 2e-2)."""
+    from echoscene_amd.samplers import ShapeDenoiser
+    O = uc.shape[0]
+    den32 = ShapeDenoiser(df, conf_params, ddim_steps=100, device=dev, precision='fp32')
+    x = torch.randn(O, 3, 16, 16, 16, generator=torch.Generator().manual_seed(21))
+    e32 = den32.eps(x, uc, triples, iteration=50)
+    e16 = sden.eps(x, uc, triples, iteration=50)
+    d = (e16 - e32).double()
+    rel_max = (d.abs().max() / e32.double().abs().max()).item()
+    rel_rms = (d.pow(2).mean().sqrt() / e32.double().pow(2).mean().sqrt()).item()
+    ss = next(iter(den32._plans.values()))
+    ss['plan'].sample(ss['step'], 0, 1, use_graph=use_graph)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record(); ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph); e[1].record()
+    torch.cuda.synchronize()
+    ms = e[0].elapsed_time(e[1]) / n
+    tf = ss['plan'].flops / (ms * 1e-3) / 1e12
+    rec = {'config': 'fp32-operand validation route of the shape step (precision=fp32: fp32 activations and weights on v_mfma_f32_16x16x4_f32), '
+                     '%d objects, same plan structure as the product path' % O,
+           'metric': 'shape steps/s', 'value': round(1e3 / ms, 4), 'ms_per_step': round(ms, 2), 'steps_timed': n, 'dtype': 'f32',
+           'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'kernel': 'k_conv_f32 (whole step)'},
+           'fp16_product_vs_fp32_route_eps': {'max_abs_diff_over_max_abs': rel_max, 'rel_rms': rel_rms,
+                                              'what': 'one UNet3D + echo-GCN evaluation at DDIM iteration 50, same weights / inputs'}}
+    del den32, ss
+    torch.cuda.empty_cache()
+    return rec
+
+
 def configs4_record(dev, use_graph, scenes=8, O=32, n=5):
     """BASELINE configs[4] as ONE rank of the 8-GPU batch run sees it (64 scenes x 32 nodes over 8 GPUs = 8 scenes = 256 objects per
     GPU, partitioned by scene: no collective inside the steps), measured on this GPU: scene-steps/s and the roofline of the shape
@@ -409,9 +446,20 @@ def main():
         torch.cuda.synchronize()
     s_lay, s_shp = torch.cuda.Stream(), torch.cuda.Stream()
 
+    def reset_state():
+        """fresh noise states before every repetition (outside the timed bracket): a loop restarted at iteration 0 on the previous
+        repetition's RESULT treats a clean sample as noise, and on random weights a few such restarts overflow"""
+        if a.check:
+            return                               # (--check seeds the latents itself, one repetition)
+        st['noise'].normal_()
+        st['x'].copy_(st['noise'][0])
+        if full:
+            ss['x'].normal_()
+
     def timed_region():
         """EXACTLY a.steps steps, bracketed by a barrier + device synchronisation on both sides; returns (wall s, layout-loop ms,
         shape-loop ms) -- in the fused case both event pairs bracket the fused loop."""
+        reset_state()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -481,6 +529,7 @@ def main():
         nn = min(a.steps, 50)
         lay_reps, shp_reps = [], []
         for _ in range(reps):
+            reset_state()
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph)
             e[1].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
@@ -576,6 +625,11 @@ def main():
             }
         if world == 1 and not weak and not a.no_sub_records and full:
             out['sub_records'] = sub_records(dev, lay, use_graph, a)
+            try:
+                from echoscene_amd import config as escfg
+                out['sub_records'].append(fp32_route_record(dev, df, sden, uc, triples_all, escfg.shape_df_conf(224).model.params, use_graph))
+            except Exception as exc:                  # (a validation figure must not take the benchmark line down)
+                out['sub_records'].append({'config': 'fp32-operand validation route', 'error': repr(exc)})
         if world == 1 and not weak and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(net, obj_embed, triples, O, full, df if full else None, uc if full else None)
         if check is not None:

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libechoscene_hip.so')
-SOURCES = ['es_runtime.hip', 'es_rows.hip', 'es_vol.hip', 'es_chamfer.hip', 'es_mc.hip']
+SOURCES = ['es_runtime.hip', 'es_rows.hip', 'es_vol.hip', 'es_vol32.hip', 'es_chamfer.hip', 'es_mc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ES_BUILD_FLAGS', '').split()
 

@@ -63,7 +63,10 @@ static int dispatch(const es_op& op, hipStream_t s) {
         case ES_OP_ATTN: return es_attention_f16(&op.u.attn, s);
         case ES_OP_GEGLU: return es_geglu_f16(&op.u.geglu, s);
         case ES_OP_TO_CL:
-            return es_latent_to_cl_f16(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s);
+            return op.u.tocl.out_is_f32 ? es_latent_to_cl_f32(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s)
+                                        : es_latent_to_cl_f16(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s);
+        case ES_OP_CONV_F32: return es_conv_f32(&op.u.conv, s);
+        case ES_OP_ATTN_F32: return es_attention_f32(&op.u.attn, s);
         case ES_OP_STEM: return es_shape_stem(&op.u.stem, s);
         case ES_OP_VQ: return es_vq_lookup(&op.u.vq, s);
         case ES_OP_ROWSEL: return es_row_select(&op.u.rowsel, s);
@@ -234,7 +237,7 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
             v = {ES_PTR(update.x), ES_PTR(update.eps), ES_PTR(update.noise), ES_PTR(update.coef), ES_PTR(update.step)};
             break;
         case ES_OP_COPY: v = {ES_PTR(copy.dst), ES_PTR(copy.src)}; break;
-        case ES_OP_CONV:
+        case ES_OP_CONV: case ES_OP_CONV_F32:
             v = {ES_PTR(conv.a), ES_PTR(conv.w), ES_PTR(conv.a2), ES_PTR(conv.w2), ES_PTR(conv.bias), ES_PTR(conv.rowvec), ES_PTR(conv.res),
                  ES_PTR(conv.out_f32), ES_PTR(conv.out_f16), ES_PTR(conv.workspace), ES_PTR(conv.gn_stats_out)};
             break;
@@ -242,7 +245,7 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
             v = {ES_PTR(gn.x1), ES_PTR(gn.x2), ES_PTR(gn.gamma), ES_PTR(gn.beta), ES_PTR(gn.stats), ES_PTR(gn.y_f16), ES_PTR(gn.raw_f16), ES_PTR(gn.stats1), ES_PTR(gn.stats2)};
             break;
         case ES_OP_LN: v = {ES_PTR(ln.x), ES_PTR(ln.gamma), ES_PTR(ln.beta), ES_PTR(ln.y_f16)}; break;
-        case ES_OP_ATTN: v = {ES_PTR(attn.qkv), ES_PTR(attn.out_f16)}; break;
+        case ES_OP_ATTN: case ES_OP_ATTN_F32: v = {ES_PTR(attn.qkv), ES_PTR(attn.out_f16)}; break;
         case ES_OP_GEGLU: v = {ES_PTR(geglu.h_f32), ES_PTR(geglu.out_f16)}; break;
         case ES_OP_TO_CL: v = {ES_PTR(tocl.x), ES_PTR(tocl.out)}; break;
         case ES_OP_STEM:

@@ -184,6 +184,19 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
                 r[e] = (_Float16)x0[e]; r[4 + e] = (_Float16)x1[e];
             }
             const long off = ((long)o * a.V + v) * C + c;
+            if (a.y_is_f32) {                        // (wave-uniform) fp32-operand validation route: the operand stays fp32
+                f4 z0, z1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t0 = y0[e], t1 = y1[e];
+                    if (a.silu == 1) { t0 = es_silu(t0); t1 = es_silu(t1); }
+                    else if (a.silu == 2) { t0 = es_gelu(t0); t1 = es_gelu(t1); }
+                    z0[e] = t0; z1[e] = t1;
+                }
+                *(f4*)((float*)a.y_f16 + off) = z0; *(f4*)((float*)a.y_f16 + off + 4) = z1;
+                if (a.raw_f16) { *(f4*)((float*)a.raw_f16 + off) = x0; *(f4*)((float*)a.raw_f16 + off + 4) = x1; }
+                continue;
+            }
             *(h8*)((_Float16*)a.y_f16 + off) = y;
             if (a.raw_f16) *(h8*)((_Float16*)a.raw_f16 + off) = r;
         }
@@ -211,10 +224,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const es_ln_args a) {
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
     _Float16* y = (_Float16*)a.y_f16 + (long)row * a.C;
+    float* y32 = (float*)a.y_f16 + (long)row * a.C;          // y_is_f32: the fp32-operand validation route
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int c = lane + 64 * j;
-        if (c < a.C) y[c] = (_Float16)((v[j] - mean) * rstd * a.gamma[c] + a.beta[c]);
+        if (c < a.C) {
+            const float t = (v[j] - mean) * rstd * a.gamma[c] + a.beta[c];
+            if (a.y_is_f32) y32[c] = t; else y[c] = (_Float16)t;
+        }
     }
 }
 
@@ -227,6 +244,13 @@ __global__ __launch_bounds__(256) void k_geglu(const es_geglu_args a) {
         const int c = (int)(i - m * c4n) * 4;
         const float* p = a.h_f32 + m * 2 * a.C4 + c;
         const f4 x = *(const f4*)p, g = *(const f4*)(p + a.C4);
+        if (a.out_is_f32) {                          // fp32-operand validation route: exact erf GELU, fp32 result
+            f4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = x[e] * es_gelu(g[e]);
+            *(f4*)((float*)a.out_f16 + m * a.C4 + c) = z;
+            continue;
+        }
         h4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * es_gelu_fast(g[e]));
@@ -235,13 +259,14 @@ __global__ __launch_bounds__(256) void k_geglu(const es_geglu_args a) {
 }
 
 // NCDHW fp32 [O,C,V] -> channels-last f16 [O,V,Cpad] (zero padded channels)
-__global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int V, int Cpad, _Float16* out) {
+__global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int V, int Cpad, _Float16* out, int is_f32) {
     const long n = (long)O * V * Cpad;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % Cpad);
         const long ov = i / Cpad;
         const long o = ov / V, v = ov - o * V;
-        out[i] = c < C ? (_Float16)x[(o * C + c) * V + v] : (_Float16)0.f;
+        const float t = c < C ? x[(o * C + c) * V + v] : 0.f;
+        if (is_f32) ((float*)(void*)out)[i] = t; else out[i] = (_Float16)t;
     }
 }
 
@@ -2325,13 +2350,15 @@ extern "C" int es_geglu_f16(const es_geglu_args* a, es_stream stream) {
     return 0;
 }
 
-extern "C" int es_latent_to_cl_f16(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) {
+static int latent_to_cl(const float* x, int O, int C, int V, int Cpad, void* out, int is_f32, es_stream stream) {
     const long n = (long)O * V * Cpad;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_to_cl, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, O, C, V, Cpad, (_Float16*)out);
+    hipLaunchKernelGGL(k_to_cl, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, O, C, V, Cpad, (_Float16*)out, is_f32);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
+extern "C" int es_latent_to_cl_f16(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) { return latent_to_cl(x, O, C, V, Cpad, out, 0, stream); }
+extern "C" int es_latent_to_cl_f32(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) { return latent_to_cl(x, O, C, V, Cpad, out, 1, stream); }
 
 extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
     const long n1 = (long)a->O * 32 * 512, n2 = (long)a->O * 512;

@@ -21,6 +21,7 @@ EPI_NONE, EPI_GEGLU = 0, 1
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
 OP_VQ = 12
 OP_FORK, OP_JOIN, OP_ROWSEL = 13, 14, 15
+OP_CONV_F32, OP_ATTN_F32 = 16, 17          # fp32-operand validation route (csrc/es_vol32.hip)
 
 
 class Seg(C.Structure):
@@ -61,12 +62,12 @@ class GNArgs(C.Structure):
     _fields_ = [('x1', C.c_void_p), ('C1', C.c_int32), ('x2', C.c_void_p), ('C2', C.c_int32), ('O', C.c_int32),
                 ('V', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('silu', C.c_int32), ('stats', C.c_void_p), ('y_f16', C.c_void_p),
-                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p), ('x1_is_f16', C.c_int32)]
+                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p), ('x1_is_f16', C.c_int32), ('y_is_f32', C.c_int32)]
 
 
 class LNArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('M', C.c_int32), ('C', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
-                ('beta', C.c_void_p), ('y_f16', C.c_void_p)]
+                ('beta', C.c_void_p), ('y_f16', C.c_void_p), ('y_is_f32', C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -75,7 +76,7 @@ class AttnArgs(C.Structure):
 
 
 class GegluArgs(C.Structure):
-    _fields_ = [('h_f32', C.c_void_p), ('M', C.c_int32), ('C4', C.c_int32), ('out_f16', C.c_void_p)]
+    _fields_ = [('h_f32', C.c_void_p), ('M', C.c_int32), ('C4', C.c_int32), ('out_f16', C.c_void_p), ('out_is_f32', C.c_int32)]
 
 
 class RowSelArgs(C.Structure):
@@ -90,7 +91,7 @@ class CopyArgs(C.Structure):
 
 class ToClArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('O', C.c_int32), ('C', C.c_int32), ('V', C.c_int32), ('Cpad', C.c_int32),
-                ('out', C.c_void_p)]
+                ('out', C.c_void_p), ('out_is_f32', C.c_int32)]
 
 
 class StemArgs(C.Structure):
@@ -147,6 +148,11 @@ EXPORTS = {
     'es_attention_f16': (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     'es_geglu_f16': (C.c_int, [C.POINTER(GegluArgs), C.c_void_p]),
     'es_latent_to_cl_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_latent_to_cl_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_pack_conv_f32_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'es_pack_conv_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'es_conv_f32': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    'es_attention_f32': (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     'es_shape_stem': (C.c_int, [C.POINTER(StemArgs), C.c_void_p]),
     'es_vq_lookup': (C.c_int, [C.POINTER(VQArgs), C.c_void_p]),
     'es_init': (C.c_int, []),

@@ -14,15 +14,18 @@ the rows are derived at import time from the rule that defines them --
     orientation of the published table's first row, {0, 8, 3} -- and is fanned into triangles from the first vertex whose
     diagonals do not lie inside a cube face.
 
-Vertex positions (and therefore the vertex multiset of a mesh) do not depend on the table at all.  What DOES differ from
-PyMCubes' classic (Lorensen / Bourke) table: (1) the choice of diagonals inside a loop, and (2) the LOOP STRUCTURE -- hence the
-triangle count -- on ambiguous-face cases.  The classic table is complement-symmetric (case c and case 255 - c get the same
-triangulation with flipped orientation); the rule above ("cut off every INSIDE corner") is not: 44 case / complement pairs get
-a different number of triangles here (e.g. cases 5 and 10 -> 2 triangles, their complements 250 and 245 -> 4, where the classic
-table has 2 in all four).  Face counts and topology of a mesh can therefore differ from ``mcubes.marching_cubes`` wherever
-an ambiguous face occurs; surfaces stay watertight because the rule is consistent across the shared face.  The per-case triangle
-counts are pinned by tests/test_mc.py::test_case_table_triangle_counts_are_pinned so the convention cannot change unnoticed
-(parity with PyMCubes is pinned for the vertex set only).
+Vertex positions (and therefore the vertex multiset of a mesh) do not depend on the table at all.  What can differ from PyMCubes'
+table is the choice of DIAGONALS inside a loop (a free choice of any table; area / volume move by O(h^2)).
+
+Rounds 2-3 recorded, on an advisor's word, that the classic table is complement-symmetric (case c and 255 - c carrying the same
+triangles) and that this rule therefore diverges from it on 44 case / complement pairs (cases 5 and 10 -> 2 triangles, 250 and 245
+-> 4).  Round 4 checked that claim against the published table itself (P. Bourke, "Polygonising a scalar field", table by C. Bloyd --
+the one marchingcubes.cpp of PyMCubes carries) and it does not hold: that table's rows hold up to FIVE triangles (16 entries; a
+complement-symmetric table needs at most four), and its row 250 (corners 0 and 2 outside) IS the four-triangle hexagon that cuts
+off the inside corners 1 and 3 of the bottom face.  The head and tail rows of the published table have exactly the loops this rule
+generates (tests/test_mc.py::test_case_table_against_rows_of_the_published_table); the rule is consistent across a shared face, so
+surfaces are watertight -- as the published table's are.  The per-case triangle counts are pinned by
+tests/test_mc.py::test_case_table_triangle_counts_are_pinned.  Still unpinned for lack of the package: the rows not quoted there.
 """
 import numpy as np
 

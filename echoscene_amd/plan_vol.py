@@ -52,9 +52,33 @@ class PackedConv:
         self.cin_true = cin
 
 
+class PackedConv32:
+    """fp32 [N][taps][Cin16] image of a conv / linear weight (the fp32-operand validation route, csrc/es_vol32.hip).  A GEGLU projection
+    keeps its value | gate row order (the fp32 route applies GEGLU with its own kernel)."""
+
+    def __init__(self, W, b, device, geglu=False):
+        W = W.detach().float().contiguous().cpu()
+        self.geglu = False
+        self.N, cin = W.shape[0], W.shape[1]
+        self.taps = 1 if W.dim() == 2 else int(W[0, 0].numel())
+        if self.taps not in (1, 27):
+            raise ValueError('conv kernel must be 1x1x1 or 3x3x3')
+        self.Cin = (cin + 15) // 16 * 16
+        L = hip.lib()
+        out = torch.empty(L.es_pack_conv_f32_size(self.N, cin, self.taps), dtype=torch.float32)
+        hip.check(L.es_pack_conv_f32(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())), 'es_pack_conv_f32')
+        self.w = out.to(device)
+        self.b = None if b is None else b.detach().float().contiguous().to(device)
+        self.weight_bytes = self.N * cin * self.taps * 4
+        self.cin_true = cin
+
+
 class UNet3DWeights:
-    def __init__(self, sd, net, device):
-        """sd: state_dict of the UNet3DModel holder ``net`` (keys without 'diffusion_net.')."""
+    def __init__(self, sd, net, device, precision='fp16'):
+        """sd: state_dict of the UNet3DModel holder ``net`` (keys without 'diffusion_net.').  ``precision='fp32'``: fp32 weight
+        images for the fp32-operand validation route."""
+        self.precision = precision
+        PackedConv = globals()['PackedConv32' if precision == 'fp32' else 'PackedConv']
         self.device, self.mc, self.topo = device, net.model_channels, net.topo
         self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
         self.heads = net.num_heads
@@ -149,6 +173,8 @@ class VolBuilderMixin:
              out_f16=None, skip=None, ncdhw=False, splitk=None, epilogue=0, out_ld=None):
         """dims = (D,H,W) of the OUTPUT grid. skip = (raw_f16 tensor, PackedConv) for the fused 1x1 skip."""
         D, H, W = dims
+        if getattr(self, 'fp32', False):
+            return self._conv32(a_f16, pc, O, dims, mode, bias, rowvec, res, out_f32, out_f16, skip, ncdhw, out_ld)
         a = ConvArgs()
         a.a, a.w = a_f16.data_ptr(), pc.w.data_ptr()
         a.O, a.D, a.H, a.W = O, D, H, W
@@ -190,6 +216,33 @@ class VolBuilderMixin:
                 self._conv_of = {}
             self._conv_of[out_f32.data_ptr()] = (idx, M, pc.N)
         return idx
+
+    def _conv32(self, a32, pc, O, dims, mode, bias, rowvec, res, out_f32, out_f16, skip, ncdhw, out_ld):
+        """fp32-operand validation route: the same launch on es_conv_f32 (fp32 activations / weights, exact-fp32 MFMA).  A request
+        for an f16 operand copy (``out_f16``) is served by the fp32 output itself: in this mode every "f16" buffer of the plan is an
+        fp32 tensor."""
+        D, H, W = dims
+        assert isinstance(pc, PackedConv32) and a32.dtype == torch.float32
+        a = ConvArgs()
+        a.a, a.w = a32.data_ptr(), pc.w.data_ptr()
+        a.O, a.D, a.H, a.W = O, D, H, W
+        a.Cin, a.N, a.taps, a.mode = pc.Cin, pc.N, pc.taps, mode
+        if skip is not None:
+            a.a2, a.w2, a.Cin2 = skip[0].data_ptr(), skip[1].w.data_ptr(), skip[1].Cin
+            self.flops += 2 * O * D * H * W * skip[1].Cin * pc.N
+        bt = pc.b if bias is None else bias
+        a.bias = bt.data_ptr() if bt is not None else None
+        if rowvec is not None:
+            a.rowvec, a.rowvec_ld = rowvec.ptr, rowvec.ld
+        a.res = res.data_ptr() if res is not None else None
+        out = out_f32 if out_f32 is not None else out_f16
+        assert out is not None and out.dtype == torch.float32 and (out_f32 is None or out_f16 is None)
+        a.out_f32 = out.data_ptr()
+        a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
+        self.keep += [pc, bt, skip]
+        self.weight_bytes += pc.weight_bytes
+        self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
+        return self._push(hip.OP_CONV_F32, 'conv', a)
 
     def _rowgroup_producer(self, x, Cx, M, V):
         """The conv op of this plan that writes the fp32 tensor x and would form its row-group sums in its own epilogue
@@ -240,6 +293,10 @@ class VolBuilderMixin:
         same order, same bits; the GroupNorm still reads the f16 tensor).  Returns the tensor the GroupNorm is to read."""
         D, H, W = dims
         M, V = O * D * H * W, D * H * W
+        if getattr(self, 'fp32', False):
+            h32 = self.buf(M, pc.N, scratch=True)
+            self.conv(a_f16, pc, O, dims, rowvec=rowvec, out_f32=h32)
+            return h32
         h16 = self.buf(M, pc.N, dtype=torch.float16, scratch=True)
         idx = self.conv(a_f16, pc, O, dims, rowvec=rowvec, out_f16=h16)
         op = self.ops[idx]
@@ -280,6 +337,11 @@ class VolBuilderMixin:
         a.y_f16 = y_f16.data_ptr()
         a.raw_f16 = raw_f16.data_ptr() if raw_f16 is not None else None
         a.O_hint = int(getattr(self, 'o_hint', 0) or 0)
+        if getattr(self, 'fp32', False):            # fp32-operand validation route: fp32 operand out, statistics by a pass over x
+            assert y_f16.dtype == torch.float32 and (raw_f16 is None or raw_f16.dtype == torch.float32)
+            a.y_is_f32 = 1
+            self.keep += [gamma, beta]
+            return self._push(hip.OP_GN, 'gn', a)
         # statistics from the producing convs' epilogues instead of a pass over x1 / x2 (both sources must have them)
         if x1.dtype == torch.float16:               # the f16-only output of conv_gn_intermediate(): statistics from that conv's sums
             assert x2 is None and raw_f16 is None
@@ -299,6 +361,7 @@ class VolBuilderMixin:
         a = LNArgs()
         a.x, a.M, a.C, a.eps = x.data_ptr(), M, Cc, 1e-5
         a.gamma, a.beta, a.y_f16 = gamma.data_ptr(), beta.data_ptr(), y_f16.data_ptr()
+        a.y_is_f32 = 1 if y_f16.dtype == torch.float32 else 0
         self.keep += [gamma, beta]
         return self._push(hip.OP_LN, 'ln', a)
 
@@ -308,16 +371,18 @@ class VolBuilderMixin:
         a.scale = float(dhead) ** -0.5
         a.out_f16 = out_f16.data_ptr()
         self.flops += 4 * B * heads * Ntok * Ntok * dhead
-        return self._push(hip.OP_ATTN, 'attn', a)
+        return self._push(hip.OP_ATTN_F32 if getattr(self, 'fp32', False) else hip.OP_ATTN, 'attn', a)
 
     def geglu(self, h_f32, M, C4, out_f16):
         a = GegluArgs()
         a.h_f32, a.M, a.C4, a.out_f16 = h_f32.data_ptr(), M, C4, out_f16.data_ptr()
+        a.out_is_f32 = 1 if out_f16.dtype == torch.float32 else 0
         return self._push(hip.OP_GEGLU, 'geglu', a)
 
     def to_cl(self, x, O, Cc, V, Cpad, out):
         a = ToClArgs()
         a.x, a.O, a.C, a.V, a.Cpad, a.out = x.data_ptr(), O, Cc, V, Cpad, out.data_ptr()
+        a.out_is_f32 = 1 if out.dtype == torch.float32 else 0
         return self._push(hip.OP_TO_CL, 'tocl', a)
 
     def stem(self, x, w, scratch, out, O, cin=3, ostride=0):
@@ -349,7 +414,8 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     O = Ofull
     D0, H0, W0 = dims
     V0 = D0 * H0 * W0
-    f16 = torch.float16
+    b.fp32 = getattr(w, 'precision', 'fp16') == 'fp32'     # fp32-operand validation route (csrc/es_vol32.hip)
+    f16 = torch.float32 if b.fp32 else torch.float16       # dtype of every contraction OPERAND buffer of the plan
     # ---- per-object (rows path) ----
     emb = None
     if tables is None:
@@ -489,6 +555,8 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
 
     def need_f16():
         """f16 copy of the current fp32 activation (for convs that read it un-normalised)."""
+        if b.fp32:
+            return state['h']                      # the fp32 activation is the operand
         if state['h16'] is None:
             t = sbuf(O * V_(state['dims']), state['C'], dtype=f16)
             op = b.ops[state['last_op']]
@@ -503,8 +571,8 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             dm = state['dims']
             M = O * V_(dm)
             if kind == 'conv_in':
-                xcl = sbuf(O * V0, 32, dtype=f16)
-                b.to_cl(xc if w.concat else x, O, w.in_ch, V0, 32, xcl)
+                xcl = sbuf(O * V0, d['conv'].Cin, dtype=f16)        # (channels padded to the weight image's Cin: 32, fp32 route 16)
+                b.to_cl(xc if w.concat else x, O, w.in_ch, V0, d['conv'].Cin, xcl)
                 o = sbuf(M, mc)
                 state['last_op'] = b.conv(xcl, d['conv'], O, dm, out_f32=o)
                 state.update(h=o, C=mc, h16=None)

@@ -137,16 +137,22 @@ class ShapeDenoiser:
     step as one hipGraph; world > 1 splits each step at the echo all-gather."""
 
     def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
-                 group=None, deterministic=True, force_exchange=False):
+                 group=None, deterministic=True, force_exchange=False, precision='fp16'):
         """``force_exchange``: build the sharded step structure (stem plan -> code exchange -> main plan) even at world == 1 --
-        the one-GPU test of the captured RCCL exchange (tests/test_hip_scene.py)."""
+        the one-GPU test of the captured RCCL exchange (tests/test_hip_scene.py).
+        ``precision``: 'fp16' (product: fp16 MFMA operands, fp32 accumulate) or 'fp32' -- the VALIDATION route: fp32 activations and
+        weights on the exact-fp32 matrix instruction (csrc/es_vol32.hip, 1/16 of the fp16 matrix rate), i.e. the reference's own
+        arithmetic (openai_model_3d.py:816-863 is fp32 everywhere), so that the cost of operand rounding is a measurement."""
+        if precision not in ('fp16', 'fp32'):
+            raise ValueError("precision must be 'fp16' or 'fp32'")
+        self.precision = precision
         self.force_exchange = bool(force_exchange)
         self.device = device or torch.device('cuda')
         self.df = df
         net = df.diffusion_net
         self.net = net
         sd = {k[len('diffusion_net.'):]: v for k, v in _cpu_sd(df).items()}
-        self.w = UNet3DWeights(sd, net, self.device)
+        self.w = UNet3DWeights(sd, net, self.device, precision)
         mp = dict(model_params or {})
         self.sched = ShapeSchedule(ddim_steps, mp.get('timesteps', 1000), mp.get('linear_start', 0.00085),
                                    mp.get('linear_end', 0.012))

@@ -254,6 +254,7 @@ typedef struct es_gn_args {
                                         ResBlock's conv1 -> GroupNorm -> conv2 intermediate is never part of the residual stream: it is
                                         written once, as the operand precision the next contraction reads anyway, openai_model_3d.py:
                                         294-314).  Requires stats1 (the statistics are the conv's sums over its fp32 values), no x2   */
+    int32_t y_is_f32;                /* 1: y_f16 / raw_f16 point at FP32 tensors (the fp32-operand validation route, es_conv_f32)       */
 } es_gn_args;
 /* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
  * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats (a pass over x, or a reduction of
@@ -262,6 +263,7 @@ int es_groupnorm_vol(const es_gn_args* args, es_stream stream);
 
 typedef struct es_ln_args {
     const float* x; int32_t M, C; float eps; const float* gamma; const float* beta; void* y_f16;
+    int32_t y_is_f32;     /* 1: y_f16 points at an fp32 tensor (fp32-operand validation route) */
 } es_ln_args;
 int es_layernorm_tokens(const es_ln_args* args, es_stream stream);      /* nn.LayerNorm, attention.py:229-231 */
 
@@ -273,8 +275,21 @@ typedef struct es_attn_args {
 } es_attn_args;
 int es_attention_f16(const es_attn_args* args, es_stream stream);       /* CrossAttention.forward self-attn, attention.py:172-219 */
 
-typedef struct es_geglu_args { const float* h_f32; int32_t M, C4; void* out_f16; } es_geglu_args;  /* h: [M, 2*C4] value|gate */
+typedef struct es_geglu_args { const float* h_f32; int32_t M, C4; void* out_f16; int32_t out_is_f32; } es_geglu_args;  /* h: [M, 2*C4] value|gate; out_is_f32: fp32 result (validation route) */
 int es_geglu_f16(const es_geglu_args* args, es_stream stream);          /* GEGLU: x * gelu(gate), attention.py:39-46 */
+
+/* ------------------------------------------------------------------------------------------
+ * fp32-OPERAND validation route of the volume path (csrc/es_vol32.hip).  The reference is fp32 everywhere (openai_model_3d.py:
+ * 816-863, GroupNorm32 forced to fp32 at ldm_diffusion_util.py:237-239); the product multiplies fp16 operands.  These entry points run
+ * the same argument structs with fp32 activations (a / a2 / res / out_f32 fp32 channels-last, Cin a multiple of 16) and fp32 weights
+ * ([N][taps][Cin16], es_pack_conv_f32) on v_mfma_f32_16x16x4_f32 (exact fp32, 1/16 of the fp16 matrix rate), so that the effect of
+ * operand rounding is a measurement.  No split K, no fused GEGLU, no statistics output; qkv / out of es_attention_f32 are fp32,
+ * dhead <= 96.
+ * ---------------------------------------------------------------------------------------- */
+size_t es_pack_conv_f32_size(int N, int Cin, int taps);
+int es_pack_conv_f32(const float* h_w, int N, int Cin, int taps, float* h_out);
+int es_conv_f32(const es_conv_args* args, es_stream stream);
+int es_attention_f32(const es_attn_args* args, es_stream stream);
 
 /* VQVAE.decode_no_quant front end (vqvae_networks/network.py:95-103, quantizer.py:68-119): nearest
  * codebook entry per latent voxel; `lut` = codebook already mapped through post_quant_conv. */
@@ -291,6 +306,7 @@ int es_vq_lookup(const es_vq_args* args, es_stream stream);
 /* NCDHW fp32 latent <-> channels-last helpers, the 3->32->64 conv-pool stem of
  * shape_messsage_passing (openai_model_3d.py:757-764). */
 int es_latent_to_cl_f16(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f16, es_stream s);
+int es_latent_to_cl_f32(const float* x_ncdhw, int O, int C, int V, int Cpad, void* out_f32, es_stream s);
 typedef struct es_stem_args {
     const float* x;        /* [O,Cin,16,16,16] fp32 NCDHW, object stride x_ostride floats            */
     const float* w0; const float* b0;   /* Conv3d(3,32,3)  weights [32,3,3,3,3]                   */
@@ -311,7 +327,8 @@ int es_shape_stem(const es_stem_args* args, es_stream stream);
 enum {
     ES_OP_LINEAR = 1, ES_OP_DDPM = 2, ES_OP_DDIM = 3, ES_OP_COPY = 4, ES_OP_CONV = 5, ES_OP_GN = 6,
     ES_OP_LN = 7, ES_OP_ATTN = 8, ES_OP_GEGLU = 9, ES_OP_TO_CL = 10, ES_OP_STEM = 11, ES_OP_VQ = 12,
-    ES_OP_FORK = 13, ES_OP_JOIN = 14, ES_OP_ROWSEL = 15
+    ES_OP_FORK = 13, ES_OP_JOIN = 14, ES_OP_ROWSEL = 15,
+    ES_OP_CONV_F32 = 16, ES_OP_ATTN_F32 = 17      /* the fp32-operand validation route: es_conv_f32 / es_attention_f32 on the same argument structs */
 };
 /* Row select: out[r, 0..n) = table[*step, 0..n) for r < rows.  The timestep-dependent but node-independent products of a
  * denoiser (time MLP, all ResBlock emb projections, box/shape time embedding) are tabulated once per schedule
@@ -327,7 +344,7 @@ typedef struct es_copy_args {      /* device-to-device copy: flat (rows <= 1) or
     void* dst; const void* src; size_t bytes;
     int32_t rows; size_t dst_pitch, src_pitch;
 } es_copy_args;
-typedef struct es_tocl_args { const float* x; int32_t O, C, V, Cpad; void* out; } es_tocl_args;
+typedef struct es_tocl_args { const float* x; int32_t O, C, V, Cpad; void* out; int32_t out_is_f32; } es_tocl_args;
 typedef struct es_op {
     int32_t kind;
     int32_t lane;    /* execution lane (0 = main stream; >0 = side stream forked/joined with ES_OP_FORK/JOIN) */

@@ -69,7 +69,7 @@ def test_output_conv_narrow_n_kernel(dev, O, Cin, N, dims, bias):
     if bias:
         bs4[:N] = bs
     out_cl = b.buf(O * D * H * W, Np, zero=True)
-    b.conv(a16, PackedConv(wt4, bs4, dev), O, dims, out_f32=out_cl)     # channels-last output: the 224-column tile kernels
+    b.conv(a16, PackedConv(wt4, bs4, dev), O, dims, out_f32=out_cl, splitk=1)     # channels-last output: the 224-column tile kernels, K not split
     b.finish().run()
     torch.cuda.synchronize()
     assert _rel(out, ref) < 1e-4
@@ -228,14 +228,14 @@ def test_shape_stem(dev):
     assert _rel(out, ref) < 1e-5
 
 
-def _shape(dev, mc, ctx, prefix, S):
+def _shape(dev, mc, ctx, prefix, S, precision='fp16'):
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     p = escfg.shape_unet_params(mc)
     p['context_dim'] = ctx
     df = DiffusionUNet(p)
     synth.seeded_fill_(df, prefix=prefix)
-    return ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=S, device=dev)
+    return ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=S, device=dev, precision=precision)
 
 
 def _unet3d_sd(den):
@@ -302,6 +302,68 @@ def test_unet3d_full_eps_vs_reference_golden(dev):
     e = _rel(eps, g['eps'])
     print('unet3d full: fp16-MFMA eps vs fp32 reference golden: rel err %.3e' % e)
     assert e < 2e-2
+
+
+@pytest.mark.parametrize('mode,N,Cin,dims,skipC', [('same', 40, 48, (4, 8, 8), 0), ('same', 224, 64, (4, 8, 8), 32), ('down', 48, 64, (4, 4, 4), 0),
+                                                    ('up', 72, 32, (4, 8, 8), 0), ('lin', 300, 80, (4, 4, 4), 0), ('same', 3, 64, (4, 4, 4), 0)])
+def test_conv_fp32_operand_route(dev, mode, N, Cin, dims, skipC):
+    """es_conv_f32 (fp32 activations / weights on v_mfma_f32_16x16x4_f32, csrc/es_vol32.hip): every conv mode of the volume path, the
+    fused 1x1 skip, bias + per-object vector + residual, NCDHW output -- against F.conv3d in fp32 on UNROUNDED operands, 1e-5."""
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv32
+    O = 3
+    D, H, W = dims
+    taps = 1 if mode == 'lin' else 27
+    idims = dict(same=dims, lin=dims, down=(D, 2 * H, 2 * W), up=(D, H // 2, W // 2))[mode]
+    x = _rnd((O, Cin) + idims, 1)
+    wt = _rnd((N, Cin, 3, 3, 3) if taps == 27 else (N, Cin), 2) / np.sqrt(Cin * taps)
+    bias, rowv, res = _rnd((N,), 3), _rnd((O, N), 4), _rnd((O * D * H * W, N), 5)
+    if mode == 'same':
+        ref = F.conv3d(x, wt, bias, padding=1)
+    elif mode == 'down':
+        ref = F.conv3d(x, wt, bias, stride=(1, 2, 2), padding=1)
+    elif mode == 'up':
+        ref = F.conv3d(F.interpolate(x, (D, H, W), mode='nearest'), wt, bias, padding=1)
+    else:
+        ref = F.conv3d(x, wt[:, :, None, None, None], bias)
+    b = Builder(dev)
+    b.fp32 = True
+    a32 = b.dev(_cl(x))
+    skip = None
+    if skipC:
+        xs, ws = _rnd((O, skipC) + dims, 6), _rnd((N, skipC), 7) / np.sqrt(skipC)
+        ref = ref + F.conv3d(xs, ws[:, :, None, None, None])
+        skip = (b.dev(_cl(xs)), PackedConv32(ws, None, dev))
+    if N == 3:                                   # the output conv's form: NCDHW, no fusions
+        out = b.buf(O, N, D, H, W, zero=True)
+        b.conv(a32, PackedConv32(wt, bias, dev), O, dims, out_f32=out, ncdhw=True)
+        b.finish().run()
+        torch.cuda.synchronize()
+        assert _rel(out, ref) < 1e-5
+        return
+    ref = _cl(ref) + rowv.repeat_interleave(D * H * W, 0) + res
+    out = b.buf(O * D * H * W, N, zero=True)
+    b.conv(a32, PackedConv32(wt, bias, dev), O, dims, mode=dict(same=0, lin=0, down=1, up=2)[mode], rowvec=View(b.dev(rowv)),
+           res=b.dev(res), out_f32=out, skip=skip)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('tag,mc,ctx', [('tiny', 32, 64), ('full', 224, 1280)])
+def test_unet3d_eps_fp32_operand_route_vs_reference_golden(dev, tag, mc, ctx):
+    """the reference is fp32 everywhere (openai_model_3d.py:816-863); ShapeDenoiser(precision='fp32') runs the SAME plan
+    with fp32 operands on the exact-fp32 matrix instruction.  One UNet3D + echo-GCN evaluation against the reference golden at the
+    fp32 bar: <= 1e-4 relative (the fp16-operand product route measures 8e-4 ... 1.4e-3 on the same goldens)."""
+    g = load_golden('unet3d_' + tag)
+    den = _shape(dev, mc, ctx, 'unet3d_%s.' % tag, 100, precision='fp32')
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it)
+    e = _rel(eps, g['eps'])
+    den16 = _shape(dev, mc, ctx, 'unet3d_%s.' % tag, 100)
+    e16 = _rel(den16.eps(g['x'], g['uc_s'], g['triples'], iteration=it), g['eps'])
+    print('unet3d %s eps vs fp32 reference golden: fp32-operand route rel err %.3e, fp16-operand route %.3e' % (tag, e, e16))
+    assert e < 1e-4
 
 
 def test_unet3d_full_eps_O32_vs_reference_golden(dev):
