@@ -51,6 +51,28 @@ __device__ __forceinline__ float es_gelu_fast(float x) {
     return x < 0.f ? h : x - h;
 }
 
+// Two evaluations of es_gelu_fast at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: one issue slot for two lanes' worth of
+// the polynomial; the reciprocal and the exponential stay scalar-width).  The same operations in the same order as es_gelu_fast (equal up
+// to where the compiler contracts a multiply-add); every route of the fused GEGLU epilogue goes through THIS function, so results do
+// not depend on the route.  Accuracy bound as es_gelu_fast (tests/test_hip_vol.py::test_gelu_of_the_volume_path_over_its_whole_range).
+typedef float es_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ es_f2 es_gelu_fast2(es_f2 x) {
+    const es_f2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const es_f2 z = ax * 0.70710678118654752440f;
+    const es_f2 one = {1.0f, 1.0f};
+    const es_f2 d = __builtin_elementwise_fma(es_f2{0.3275911f, 0.3275911f}, z, one);
+    const es_f2 t = {__frcp_rn(d[0]), __frcp_rn(d[1])};
+    es_f2 pl = __builtin_elementwise_fma(t, es_f2{1.061405429f, 1.061405429f}, es_f2{-1.453152027f, -1.453152027f});
+    pl = __builtin_elementwise_fma(t, pl, es_f2{1.421413741f, 1.421413741f});
+    pl = __builtin_elementwise_fma(t, pl, es_f2{-0.284496736f, -0.284496736f});
+    pl = __builtin_elementwise_fma(t, pl, es_f2{0.254829592f, 0.254829592f});
+    const es_f2 mz2 = -z * z;
+    const es_f2 ex = {__expf(mz2[0]), __expf(mz2[1])};
+    const es_f2 E = pl * t * ex;
+    const es_f2 h = (x * 0.5f) * E;
+    return es_f2{x[0] < 0.f ? h[0] : x[0] - h[0], x[1] < 0.f ? h[1] : x[1] - h[1]};
+}
+
 // Kernel arguments are read with scalar loads as the code reaches each field: several s_load -> s_waitcnt -> branch steps in a row
 // at kernel entry (a dozen for the 1.4 KB block of the rows kernels), each a scalar-cache miss on a fresh launch.  Touch every 64-byte line of the kernarg segment at once
 // (one round trip), so that the loads the compiler emits later hit the scalar cache.

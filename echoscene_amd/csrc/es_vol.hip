@@ -251,9 +251,8 @@ __global__ __launch_bounds__(256) void k_geglu(const es_geglu_args a) {
             *(f4*)((float*)a.out_f16 + m * a.C4 + c) = z;
             continue;
         }
-        h4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (_Float16)(x[e] * es_gelu_fast(g[e]));
+        const es_f2 g01 = es_gelu_fast2(es_f2{g[0], g[1]}), g23 = es_gelu_fast2(es_f2{g[2], g[3]});     // (the fused epilogue's GELU)
+        const h4 y = {(_Float16)(x[0] * g01[0]), (_Float16)(x[1] * g01[1]), (_Float16)(x[2] * g23[0]), (_Float16)(x[3] * g23[1])};
         *(h4*)((_Float16*)a.out_f16 + m * a.C4 + c) = y;
     }
 }
@@ -500,8 +499,9 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
                 const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x128, 0xf, 0xf, false));
                 const float v0 = lo ? acc[i][j][0] : r0, g0 = lo ? r0 : acc[i][j][2];
                 const float v1 = lo ? acc[i][j][1] : r1, g1 = lo ? r1 : acc[i][j][3];
-                hslab[rr * HLD + j * 8 + cw] = (_Float16)(v0 * es_gelu_fast(g0));
-                hslab[(rr + 1) * HLD + j * 8 + cw] = (_Float16)(v1 * es_gelu_fast(g1));
+                const es_f2 ge = es_gelu_fast2(es_f2{g0, g1});      // (packed fp32 polynomial: two evaluations per issue slot)
+                hslab[rr * HLD + j * 8 + cw] = (_Float16)(v0 * ge[0]);
+                hslab[(rr + 1) * HLD + j * 8 + cw] = (_Float16)(v1 * ge[1]);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): own slab writes visible to own wave
             __builtin_amdgcn_wave_barrier();
@@ -1261,9 +1261,11 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 // epilogue of tile c overlaps the loads of tile c+1 (the epilogue slabs live BEHIND the ring: no workgroup barrier in it).
 // Same tile, LDS image, K order and arithmetic as k_conv_ws (results are bit-identical).
 // ---------------------------------------------------------------------------------------------
-template <int EPI_>
+template <int EPI_, int NS_ = 3>
 __global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, const ConvGeom g, int ncb) {
-    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NS = 3;
+    // ring depth: the GEGLU variant's epilogue slabs are small (fp16 results: 18 KB for the 8 waves against 58 KB of fp32 slabs), which
+    // leaves room for a FOURTH slot -- the producers then run three units ahead while the consumers are in their 6 us epilogue
+    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NS = NS_;
     constexpr int WROWS = BM_ / (NC_ / 2), MI = WROWS / 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES, RING_BYTES = NS * STAGE_BYTES;
     constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_, NLOAD = NA + NB;
@@ -1335,10 +1337,13 @@ __global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, cons
         };
         issue();
         if (total > 1) issue();
+        if (NS == 4 && total > 2) issue();
         for (int u = 0; u < total; ++u) {
-            if (u + 1 < total) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of unit u have landed
-            __builtin_amdgcn_s_barrier();        // unit u visible to the consumers; the slot two behind released by them
-            if (u + 2 < total) issue();
+            // own pieces of unit u have landed (units u + 1 .. u + NS - 2 may still be in flight)
+            const int ahead = total - 1 - u < NS - 2 ? total - 1 - u : NS - 2;
+            if (ahead >= 2) wait_vmcnt<2 * NLOAD>(); else if (ahead == 1) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();        // unit u visible to the consumers; the slot NS - 1 behind released by them
+            if (u + NS - 1 < total) issue();
         }
         return;
     }
@@ -2113,6 +2118,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     const long wg256 = ((M + 255) / 256) * ntn, wg128 = ((M + 127) / 128) * ntn;
     const long hg256 = ((Mh + 255) / 256) * ntn, hg128 = ((Mh + 127) / 128) * ntn;      // the same counts for the whole problem
     const int nks = a->taps * (a->Cin / 32) + (a->a2 ? a->Cin2 / 32 : 0);
+    constexpr int LDSLIN_GEGLU = 4 * (256 * BK * 2 + BNP * BK * 2) + 8 * 16 * 72 * 2;      // k_linear_ws<GEGLU>: 4-slot ring + fp16 slabs
     constexpr int LDS256 = 3 * (256 * BK * 2 + BNP * BK * 2), LDS128 = 3 * (128 * BK * 2 + BNP * BK * 2),
                   LDS64 = 3 * (64 * BK * 2 + BNP * BK * 2);
     hipStream_t st = (hipStream_t)stream;
@@ -2192,7 +2198,12 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    // A deterministic shard (O_hint > O) keeps the K cuts of the whole problem; where that means an unsplit K loop (S == 1) on a launch
+    // that is too small for >= 256 tiles, the 256-row producer/consumer tiles are still the fastest way through a long K chain (0.64 us
+    // per K unit against 0.9 us on the 128- / 64-row kernels, whose per-unit time does not shrink with the tile): the row tile does not
+    // change the summation order, so the shard stays bit-identical to the unsharded run.
+    const bool det_ws = ws && a->O_hint > a->O && S == 1 && !geglu && nks >= 32 && wg256 < 256 && !tiny_split && !no256;
+    const bool route256 = (wg256 >= 256 || force256 || ws_split || det_ws) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
@@ -2227,6 +2238,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
             set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
+            set((const void*)k_linear_ws<ES_EPI_GEGLU, 4>, LDSLIN_GEGLU);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
@@ -2235,7 +2247,9 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
             constexpr int LDSLIN = LDS256 + 8 * 16 * 116 * 4;
-            if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
+            static const char* ring_env = getenv("ES_LIN_RING");      // A/B switch (timing only): 3 = the three-slot ring for the GEGLU variant too
+            if (geglu && ring_env && atoi(ring_env) == 3) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
+            else if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU, 4>), lgrid, dim3(768), LDSLIN_GEGLU, st, *a, g, ncb);
             else hipLaunchKernelGGL((k_linear_ws<ES_EPI_NONE>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
         } else if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);

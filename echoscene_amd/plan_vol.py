@@ -143,6 +143,15 @@ class UNet3DWeights:
                 d['ff1'] = PackedConv(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
                 d['ff2'] = PC(tb + '.ff.net.2.weight', tb + '.ff.net.2.bias')
                 d['proj_out'] = PackedConv(sd[name + '.proj_out.weight'].flatten(1), sd[name + '.proj_out.bias'], device)
+                # FeedForward output + proj_out as ONE K-concatenated product (round 4): with t3 = ff2(gg) + t2 (attention.py:243-245)
+                # and out = proj_out(t3) + x_in (:385-396),  out = (Wp W2) gg + Wp t2 + (Wp b2 + bp) + x_in -- the kernel's second
+                # contraction phase (a2 / w2) carries the t2 term; the [M, C] tensor t3 and one HBM-bound launch per block disappear
+                if os.environ.get('ES_VOL_FOLD_FFO', '1') != '0':
+                    W2, b2 = sd[tb + '.ff.net.2.weight'].double(), sd[tb + '.ff.net.2.bias'].double()
+                    Wp, bp = sd[name + '.proj_out.weight'].flatten(1).double(), sd[name + '.proj_out.bias'].double()
+                    d['ffo'] = PackedConv((Wp @ W2).float(), None, device)
+                    d['po'] = PackedConv(Wp.float(), None, device)
+                    d['ffo_bias'] = (Wp @ b2 + bp).float().contiguous().to(device)
                 # cross-attention with one key: to_out2(to_v2(ctx)) folded into one matrix per block (fp64)
                 self.ca[name] = (len(ca_v), it[1])
                 ca_v.append((sd[tb + '.attn2.to_out.0.weight'].double() @ sd[tb + '.attn2.to_v.weight'].double()).float())
@@ -624,7 +633,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                 b.attention(qkv, O, V_(dm), w.heads, Cc // w.heads, at)
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x  (one key: + per-object vector)
                 t2 = sbuf(M, Cc)
-                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, col=cavo[name].col, ld=cavo[name].ld, width=cavo[name].width, row=row0), res=t0, out_f32=t2)
+                t2h = sbuf(M, Cc, dtype=f16) if ('ffo' in d and not b.fp32) else None      # operand copy of t2 for the folded ff2 + proj_out product
+                b.conv(at, d['o1'], O, dm, rowvec=View(cavo[name].t, col=cavo[name].col, ld=cavo[name].ld, width=cavo[name].width, row=row0), res=t0, out_f32=t2,
+                       out_f16=t2h)
                 l3 = sbuf(M, Cc, dtype=f16)
                 b.layernorm(t2, M, Cc, d['ln3'][0], d['ln3'][1], l3)
                 gg = sbuf(M, 4 * Cc, dtype=f16)
@@ -634,10 +645,13 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
                     gl = sbuf(M, 8 * Cc)
                     b.conv(l3, d['ff1'], O, dm, out_f32=gl)
                     b.geglu(gl, M, 4 * Cc, gg)
-                t3 = sbuf(M, Cc, dtype=f16)
-                b.conv(gg, d['ff2'], O, dm, res=t2, out_f16=t3)
                 o = sbuf(M, Cc)
-                state['last_op'] = b.conv(t3, d['proj_out'], O, dm, res=xin, out_f32=o)
+                if 'ffo' in d:
+                    state['last_op'] = b.conv(gg, d['ffo'], O, dm, bias=d['ffo_bias'], skip=(t2 if b.fp32 else t2h, d['po']), res=xin, out_f32=o)
+                else:
+                    t3 = sbuf(M, Cc, dtype=f16)
+                    b.conv(gg, d['ff2'], O, dm, res=t2, out_f16=t3)
+                    state['last_op'] = b.conv(t3, d['proj_out'], O, dm, res=xin, out_f32=o)
                 b.tags[name + '.transformer_blocks.0:in'] = View(t0)
                 b.tags[name + '.transformer_blocks.0:attn2'] = View(t2)
                 state.update(h=o, h16=None)
@@ -671,7 +685,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     return objbuf
 
 
-for _n in ('_push', 'conv', 'conv_gn_intermediate', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
+for _n in ('_push', 'conv', '_conv32', 'conv_gn_intermediate', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
     setattr(Builder, _n, getattr(VolBuilderMixin, _n))
 
 

@@ -561,7 +561,7 @@ def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
         y = b.buf(O * V, 2 * N, dtype=torch.float16, zero=True)
         ig = b.groupnorm(oa, N, ob, N, O, V, b.dev(ga), b.dev(be), 1e-5, True, y)
         assert b.ops[ia].u.conv.gn_stats_out and b.ops[ib].u.conv.gn_stats_out and b.ops[ig].u.gn.stats1 and b.ops[ig].u.gn.stats2
-        sa, sb = b._rg_stats[oa.data_ptr()], b._rg_stats[ob.data_ptr()]
+        sa, sb = b._rg_stats[oa.data_ptr()][1], b._rg_stats[ob.data_ptr()][1]       # (producer op, sums)
         b.finish().run()
         torch.cuda.synchronize()
         for o_, s_ in ((oa, sa), (ob, sb)):
