@@ -355,6 +355,7 @@ def main():
                          '-1: the default of this build')
     ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed K-step region (value = the median repetition)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt-mode', action='store_true', help='N > 1: skip the record of the other sharding mode (other_sharding_mode)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--check', action='store_true',
                     help='seeded initial latents (the same for every world size) and a CRC32 of the final latents of the whole scene in the '
@@ -548,6 +549,37 @@ def main():
     if fused is not None:
         fused_ms, (lay_ms, shp_ms) = lay_ms, solo
     assert torch.isfinite(st['x']).all(), 'non-finite layout state'
+    alt = None
+    if full and sh_world > 1 and not a.check and not a.no_alt_mode:
+        # The OTHER sharding mode on the same ranks, shape loop only, same K steps inside the same barrier bracket: the line's `value`
+        # is the bit-exact default (or --tuned); this record puts the other curve next to it, so that one multi-GPU run of the driver
+        # shows both (bit-exact shards cannot be as fast as shards tuned to their own object count).
+        from echoscene_amd.parallel import sharded_ddim_loop
+        _, sden2, _ = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=a.tuned)
+        sden2.sample(uc, triples_all, noise1=noise1, n_steps=2, use_graph=use_graph)
+        ss2 = next(iter(sden2._plans.values()))
+        ws2 = []
+        for _ in range(max(1, min(reps, 3))):
+            ss2['x'].normal_()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = 0
+            while done < a.steps:
+                n = min(a.steps - done, sden2.S)
+                sden2._cur, sden2._use_graph = ss2, use_graph
+                sharded_ddim_loop(sden2, O_all, n, sh_world)
+                done += n
+            torch.cuda.synchronize()
+            dist.barrier()
+            tm = torch.tensor([time.perf_counter() - t0], device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ws2.append(float(tm.item()))
+        alt = {'mode': 'bit-exact shards' if a.tuned else 'tuned shards (--tuned: K splits chosen from the local object count)',
+               'what': 'shape loop only, %d steps, max over ranks, median of %d' % (a.steps, len(ws2)),
+               'shape_ms_per_step': _stats([w * 1e3 / a.steps for w in ws2])}
+        del sden2, ss2
     if full:
         assert torch.isfinite(ss['x']).all(), 'non-finite shape latent'
 
@@ -634,6 +666,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(net, obj_embed, triples, O, full, df if full else None, uc if full else None)
         if check is not None:
             out['check'] = check
+        if alt is not None:
+            out['other_sharding_mode'] = alt
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -1263,8 +1263,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 // ---------------------------------------------------------------------------------------------
 template <int EPI_, int NS_ = 3>
 __global__ __launch_bounds__(768, 3) void k_linear_ws(const es_conv_args a, const ConvGeom g, int ncb) {
-    // ring depth: the GEGLU variant's epilogue slabs are small (fp16 results: 18 KB for the 8 waves against 58 KB of fp32 slabs), which
-    // leaves room for a FOURTH slot -- the producers then run three units ahead while the consumers are in their 6 us epilogue
+    // ring depth NS_: 3; 4 (ES_LIN_RING=4, GEGLU variant only: its fp16 epilogue slabs leave the room) measured neutral
     constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NS = NS_;
     constexpr int WROWS = BM_ / (NC_ / 2), MI = WROWS / 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES, RING_BYTES = NS * STAGE_BYTES;
@@ -2176,7 +2175,9 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && !(wss_env && atoi(wss_env) == 0)) {
         // (hg256: the tile count of the WHOLE problem -- a shard with O_hint makes the choice the unsharded run makes, so its
         //  partial sums are cut in the same places and the results stay bit-identical; it then simply runs fewer workgroups)
-        int s2 = (int)(256 / hg256);
+        static const char* wst_env = getenv("ES_CONV_WSS_TARGET");   // experiment: workgroup target of the split (default 256 = one round)
+        const long wst = wst_env ? atol(wst_env) : 256;
+        int s2 = (int)(wst / hg256);
         const int s2max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;      // workspace contract (echoscene_hip.h): 16 slabs for small outputs
         if (s2 > s2max) s2 = s2max;
         while (s2 > 1 && nks / s2 < 24) --s2;
@@ -2198,12 +2199,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    // A deterministic shard (O_hint > O) keeps the K cuts of the whole problem; where that means an unsplit K loop (S == 1) on a launch
-    // that is too small for >= 256 tiles, the 256-row producer/consumer tiles are still the fastest way through a long K chain (0.64 us
-    // per K unit against 0.9 us on the 128- / 64-row kernels, whose per-unit time does not shrink with the tile): the row tile does not
-    // change the summation order, so the shard stays bit-identical to the unsharded run.
-    const bool det_ws = ws && a->O_hint > a->O && S == 1 && !geglu && nks >= 32 && wg256 < 256 && !tiny_split && !no256;
-    const bool route256 = (wg256 >= 256 || force256 || ws_split || det_ws) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
@@ -2247,9 +2243,11 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);
             constexpr int LDSLIN = LDS256 + 8 * 16 * 116 * 4;
-            static const char* ring_env = getenv("ES_LIN_RING");      // A/B switch (timing only): 3 = the three-slot ring for the GEGLU variant too
-            if (geglu && ring_env && atoi(ring_env) == 3) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
-            else if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU, 4>), lgrid, dim3(768), LDSLIN_GEGLU, st, *a, g, ncb);
+            // (a FOURTH ring slot fits behind the GEGLU variant's small fp16 slabs -- the step DESIGN.md had listed as cheap since round 2;
+            //  measured in round 4 on one box: shape step 18.41 ms with three slots, 18.44-18.47 with four: no gain, kept as a switch)
+            static const char* ring_env = getenv("ES_LIN_RING");      // A/B switch (timing only): 4 = four-slot ring for the GEGLU variant
+            if (geglu && ring_env && atoi(ring_env) == 4) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU, 4>), lgrid, dim3(768), LDSLIN_GEGLU, st, *a, g, ncb);
+            else if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
             else hipLaunchKernelGGL((k_linear_ws<ES_EPI_NONE>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
         } else if (ws && (!geglu || !upm)) {
             if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
