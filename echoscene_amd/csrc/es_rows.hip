@@ -19,7 +19,7 @@
 //   * weights are pre-packed in MFMA-fragment order: a wave-level load is one contiguous 1 KiB global_load_dwordx4
 //     that lands in B-operand registers (streamed once per workgroup, no LDS round trip), issued before the staging;
 //   * exact fp32 on the matrix pipe: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain); the k-blocks of a slice are
-//     dealt to the 4 waves and reduced through LDS in a fixed order (deterministic, no float atomics).
+//     dealt to the 8 waves (NWAVE) and reduced through LDS in a fixed order (deterministic, no float atomics).
 #include "es_common.h"
 #include <cstdlib>
 #include <mutex>
@@ -86,8 +86,8 @@ __device__ __forceinline__ f4 sum_slabs(const f4 (&t)[NS], int nslab) {
 }
 
 // Staging of the columns [c0, c0 + kc) of the (virtually concatenated) A operand into LDS tile x[MT][ldx], with each
-// segment's slab sum, input activation and prologue applied.  Thread mapping: row r = tid >> 3, lane cl = tid & 7; a
-// thread walks its row in steps of 8 float4 (8 lanes read one 128-byte line); 16 float4 loads (columns x slabs) are in flight
+// segment's slab sum, input activation and prologue applied.  Thread mapping (512 threads, 16-row tile): row r = tid >> 5, lane
+// cl = tid & 31 (LPR = 32 lanes per row); a thread walks its row in steps of 32 float4 (8 lanes read one 128-byte line); 16 float4 loads (columns x slabs) are in flight
 // per thread before the first is used.  Segment loop / mode switches are wave-uniform.  GroupNorm: a group (gs = 4 .. 32
 // channels) is gs/4 adjacent lanes of one pass -> statistics by lane shuffles, two-pass (mean, then squared deviations).
 // NS: compile-time bound of the slab counts of this launch's segments (1, 2, 4, 8).
@@ -97,7 +97,7 @@ __device__ __forceinline__ f4 sum_slabs(const f4 (&t)[NS], int nslab) {
 template <int NS, int PROC, bool CSR>
 __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, int ldx, int m0, int c0, int kc, int tid) {
     // passes (32 lanes x float4 = 128 columns of a row) per batch: up to 16 float4 loads in flight per thread.  A pass that lies
-    // wholly past the region is skipped (wave-uniform): with 4 waves and 32-load batches the clamped duplicates of a 64-column
+    // wholly past the region is skipped (wave-uniform): in the 4-wave version with 32-load batches the clamped duplicates of a 64-column
     // slice cost +1.9 us per launch -- at one wave per SIMD nothing hides the dependent VALU chain of the prologue.
     constexpr int UB = NS >= 8 ? 2 : 4;
     const int r = tid >> 5, cl = tid & (LPR - 1);
