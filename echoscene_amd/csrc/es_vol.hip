@@ -972,6 +972,84 @@ __global__ __launch_bounds__(64 * NW_, 2) void k_conv_lean(const es_conv_args a,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_linear_deep: 1x1 / linear launches that are SMALL and K-SHORT (the transformer linears at few objects per GPU: 1024-4096 rows,
+// 14-21 K units).  On the 3-slot ring of k_conv_lean<64> such a workgroup is a lone latency chain -- two units in flight, every further
+// unit waits a full L2 -> LDS round trip: 22-30 us for < 1 GFLOP -- and round 2's answer (split K over 2-4 workgroups + a reduction
+// kernel, "tiny split") is two launches of 7 + 8 us.  Here the ring is SEVEN slots deep (7 x 20 KB) and the whole ring is issued at
+// kernel entry, so the K loop pays ONE round trip and then runs at LDS speed; no split, no reduction kernel, the full epilogue
+// (bias / per-object vector / residual / f16 copy / GEGLU) in the launch.  Same tile (64 x 224), LDS image, K order and MFMA
+// accumulation chain as k_conv_lean<64> with S = 1: bit-identical to the unsplit launch of any other conv kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linear_deep(const es_conv_args a, const ConvGeom g) {
+    constexpr int BM_ = 64, NW_ = 4, NS = 7, NT = 256;
+    constexpr int WROWS = BM_ / (NW_ / 2), MI = WROWS / 16;        // 32 rows per wave, 2 MFMA row tiles
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NA = BM_ * 4 / NT, NB = BNP * 4 / NT, NLOAD = NA + NB;           // 1 + 4 pieces per thread and unit
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;
+    conv_tile_of(a, bx, by, bz);
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
+    const int nloc = a.Cin >> 5;
+    // staging: thread's A piece = row tid >> 2, 16-B chunk (tid & 3) ^ swizzle; B pieces = the block's 16 KiB, 4 per thread
+    unsigned voffA;
+    {
+        const int row = tid >> 2;
+        const long m = m0 + row;
+        voffA = m < M ? (unsigned)(m * a.Cin * 2 + (((tid & 3) ^ f_swz(row)) * 16)) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.a), (short)0, (int)OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const _Float16*)a.w + ((long)by * nloc) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+    auto stage = [&](int ks, int slot) __attribute__((always_inline)) {
+        char* dst = smem + slot * STAGE_BYTES + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)dst, 16, (int)voffA, (int)((unsigned)ks * 64u), 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned vB = (unsigned)tid * 16u + (unsigned)j * (NT * 16) >= (unsigned)(BN * BK * 2) ? OOB : (unsigned)tid * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + A_BYTES + j * (NT * 16)), 16, (int)vB,
+                                                     (int)((unsigned)ks * (unsigned)B_BYTES + (unsigned)j * (NT * 16)), 0, 0);
+        }
+    };
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fragA = (wm * WROWS + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = A_BYTES + (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    int issued = 0;
+    for (; issued < NS - 1 && issued < nloc; ++issued) stage(issued, issued);
+    int slot = 0;
+    for (int ks = 0; ks < nloc; ++ks) {
+        // unit ks has landed when at most (units issued after it) x NLOAD of this thread's loads are outstanding
+        const int after = issued - 1 - ks;
+        if (after >= 5) wait_vmcnt<5 * NLOAD>(); else if (after == 4) wait_vmcnt<4 * NLOAD>(); else if (after == 3) wait_vmcnt<3 * NLOAD>();
+        else if (after == 2) wait_vmcnt<2 * NLOAD>(); else if (after == 1) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();            // unit ks visible to all waves; the slot of unit ks - 1 is free
+        if (issued < nloc) { const int ws_ = slot == 0 ? NS - 1 : slot - 1; stage(issued, ws_); ++issued; }
+        const char* As = smem + slot * STAGE_BYTES;
+        h8 af[MI], bfr[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bfr[j] = *(const h8*)(As + fragB + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(As + fragA + i * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        slot = slot == NS - 1 ? 0 : slot + 1;
+    }
+    conv_epilogue<BM_, NW_>(a, g, acc, smem, M, m0, n0, wave, lane, 1, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv_ws: warp-specialised version of k_conv_lean (same tile, LDS image, K order and epilogue).
 // Why: in k_conv_lean every wave alternates MFMA rows with LDS-DMA issue, and a wave is blocked for ~100-190 cycles
 // per DMA piece while the TA path accepts it -- the K step costs MFMA time PLUS DMA issue time (ablation: 0.46 us + 0.5
@@ -2186,11 +2264,22 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     // Tiny K-short problems (the transformer linears at <= 8 objects per GPU: e.g. 1024 rows x 672 columns, 21 K units): even the
     // 64-row tiles give only a few dozen workgroups, each a lone, latency-bound chain of K units (22-30 us for < 1 GFLOP).
     // Split K over 64-row tiles until about one workgroup per CU runs (>= 5 units per split).
+    // ... round 4: such launches go to k_linear_deep (7-slot ring issued at entry, no split, no reduction kernel) when they are plain
+    // linears of at most ONE round of 64-row tiles (140 KB of LDS = one workgroup per CU: with more tiles than CUs the 3-slot kernel's two
+    // workgroups per CU win; stand-alone at 4 objects: 448 -> 448 19.7 -> 12.5 us, 672 -> 2016 21.4 -> 13.8, but 448 -> 1344 with 384
+    // tiles 16.7 -> 21.3); the split below remains for the shapes it does not take (fused skip phase, 27 taps, more tiles)
+    static const char* deep_env = getenv("ES_CONV_DEEP");          // A/B switch: 0 = off
+    bool deep = false;
+    {
+        const long hg64 = ((Mh + 63) / 64) * ntn;
+        deep = !ws_split && a->splitk <= 0 && !force256 && !no256 && hg256 < 256 && hg64 <= 256 && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME &&
+               nks >= 4 && nks <= 28 && !ncdhw && M * (long)a->Cin * 2 < (1L << 31) && !(deep_env && atoi(deep_env) == 0);
+    }
     static const char* tiny_env = getenv("ES_CONV_TINYSPLIT");     // A/B switch: 0 = off
     bool tiny_split = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
-        if (!ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
+        if (!deep && !ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
             !(tiny_env && atoi(tiny_env) == 0)) {
             int s3 = (int)((256 + hg64 - 1) / hg64);
             const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
@@ -2199,7 +2288,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split;
+    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split && !deep;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
@@ -2232,13 +2321,17 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, LDS256);
             set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
+            set((const void*)k_linear_deep, 7 * (64 * BK * 2 + BNP * BK * 2));
             set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU, 4>, LDSLIN_GEGLU);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
-    if (route256) {
+    if (deep) {
+        S = 1;
+        hipLaunchKernelGGL(k_linear_deep, dim3((unsigned)((M + 63) / 64), ntn, 1), dim3(256), 7 * (64 * BK * 2 + BNP * BK * 2), st, *a, g);
+    } else if (route256) {
         dim3 grid((unsigned)((M + 255) / 256), ntn, S);
         if (ncb > 1) {
             const dim3 lgrid(grid.x, (unsigned)(ntn / ncb), 1);

@@ -76,6 +76,50 @@ def test_output_conv_narrow_n_kernel(dev, O, Cin, N, dims, bias):
     assert torch.equal(out.cpu(), _ncdhw(out_cl.cpu(), O, D, H, W)[:, :N]), 'k_conv_n16 and the tile kernels must sum in the same order'
 
 
+@pytest.mark.parametrize('O,dims,Cin,N,geglu', [(4, (16, 8, 8), 448, 448, False), (4, (16, 4, 4), 672, 2016, False), (2, (16, 8, 8), 448, 3584, True),
+                                                (3, (4, 4, 4), 160, 250, False)])
+def test_small_linear_launches_on_the_deep_ring_kernel(dev, O, dims, Cin, N, geglu):
+    """k_linear_deep: small, K-short 1x1 / linear launches (the transformer linears at few objects per GPU) with a 7-slot ring issued at
+    kernel entry, no split K, no reduction kernel.  Against torch on the fp16-rounded operands, and BIT-identical to the unsplit launch
+    of the ordinary 64-row tile kernel (`splitk=1` keeps the launch off the deep-ring route: same K order, same accumulation chain)."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    D, H, W = dims
+    M = O * D * H * W
+    x = _rnd((M, Cin), 1).half().float()
+    wt = (_rnd((N, Cin), 2) / np.sqrt(Cin)).half().float()
+    bias = _rnd((N,), 3)
+    b = Builder(dev)
+    a16 = b.dev(x, torch.float16)
+    if geglu:
+        pc = PackedConv(wt, bias, dev, geglu=True)
+        assert pc.geglu
+        h = x @ wt.t() + bias
+        ref = h[:, :N // 2] * F.gelu(h[:, N // 2:])
+        outs = [b.buf(M, N // 2, dtype=torch.float16, zero=True) for _ in range(2)]
+        b.conv(a16, pc, O, dims, out_f16=outs[0], epilogue=hip.EPI_GEGLU, out_ld=N // 2)
+        i1 = b.conv(a16, pc, O, dims, out_f16=outs[1], epilogue=hip.EPI_GEGLU, out_ld=N // 2)
+        b.ops[i1].u.conv.splitk = 1                  # (es_conv_args.splitk = 1: "no split, ordinary route")
+        b.finish().run()
+        torch.cuda.synchronize()
+        assert _rel(outs[0], ref) < 2e-3
+        assert torch.equal(outs[0], outs[1])
+        return
+    pc = PackedConv(wt, bias, dev)
+    rowv, res = _rnd((O, N), 4), _rnd((M, N), 5)
+    ref = x @ wt.t() + bias + rowv.repeat_interleave(D * H * W, 0) + res
+    o32 = [b.buf(M, N, zero=True) for _ in range(2)]
+    o16 = [b.buf(M, N, dtype=torch.float16, zero=True) for _ in range(2)]
+    rv, rs = View(b.dev(rowv)), b.dev(res)
+    b.conv(a16, pc, O, dims, rowvec=rv, res=rs, out_f32=o32[0], out_f16=o16[0])
+    b.conv(a16, pc, O, dims, rowvec=rv, res=rs, out_f32=o32[1], out_f16=o16[1], splitk=1)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert _rel(o32[0], ref) < 1e-4
+    assert torch.equal(o32[0], o32[1]) and torch.equal(o16[0], o16[1])
+
+
 @pytest.mark.parametrize('mode,N,Cin,dims', [('same', 40, 32, (4, 8, 8)), ('same', 224, 64, (4, 8, 8)),
                                               ('same', 250, 96, (2, 4, 4)), ('down', 48, 64, (4, 4, 4)),
                                               ('up', 48, 32, (4, 8, 8)), ('lin', 300, 64, (4, 4, 4))])
