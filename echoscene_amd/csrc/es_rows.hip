@@ -399,7 +399,8 @@ __global__ void k_ddpm_update(const es_update_args a) {
         const float* c = a.coef + (long)st * a.coef_stride;
         const float x = a.x[i], e = load_slabs1(a.eps + i, a.eps_nslab > 1 ? a.eps_nslab : 1, a.eps_slab_stride);
         const float nz = a.noise[(long)st * a.noise_stride + i];
-        const float x0 = c[0] * x - c[1] * e;
+        float x0 = c[0] * x - c[1] * e;
+        if (a.clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);          // clip_denoised=True: torch.clamp(x_recon, -1, 1), diffusion_ddpm.py:243-244
         const float mean = c[2] * x0 + c[3] * x;
         a.x[i] = mean + c[4] * nz;
     }
@@ -413,7 +414,10 @@ __global__ void k_ddim_update(const es_update_args a) {
         const float* c = a.coef + (long)st * a.coef_stride;
         const float x = a.x[i], e = load_slabs1(a.eps + i, a.eps_nslab > 1 ? a.eps_nslab : 1, a.eps_slab_stride);
         const float px0 = (x - c[0] * e) / c[1];
-        a.x[i] = c[2] * px0 + c[3] * e;
+        float xn = c[2] * px0 + c[3] * e;
+        // eta != 0 (samplers/ddim.py:256-260): + sigma_t * randn; c[3] then already is sqrt(1 - a_prev - sigma_t^2), c[4] = sigma_t
+        if (a.noise) xn = xn + c[4] * a.noise[(long)st * a.noise_stride + i];
+        a.x[i] = xn;
     }
 }
 

@@ -46,7 +46,7 @@ class UpdateArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('eps', C.c_void_p), ('eps_nslab', C.c_int32), ('eps_slab_stride', C.c_int32),
                 ('noise', C.c_void_p), ('noise_stride', C.c_int32),
                 ('coef', C.c_void_p), ('coef_stride', C.c_int32), ('step', C.c_void_p), ('n', C.c_int32),
-                ('inc_step', C.c_int32)]
+                ('inc_step', C.c_int32), ('clip_x0', C.c_int32)]
 
 
 class ConvArgs(C.Structure):

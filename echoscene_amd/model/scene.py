@@ -85,10 +85,11 @@ class EchoToLayout(nn.Module):
     @torch.no_grad()
     def generate_layout_sg(self, box_dim, text=None, ret_traj=False, ddim=False, clip_denoised=False,
                            batch_seeds=None, noise=None):
-        """echo2layout.py:112-126.  ``noise`` (optional, f32[T+1,O,box_dim]) makes the run reproducible."""
-        if clip_denoised or ret_traj or ddim:
-            raise NotImplementedError('only the reference default (no clipping, no trajectory, DDPM) is built')
-        samples = self._denoiser().sample(self.uc_rel, self.preds, noise=noise)
+        """echo2layout.py:112-126.  ``noise`` (optional, f32[T+1,O,box_dim]) makes the run reproducible.
+        ``clip_denoised`` reaches the loop (gen_samples_sg, echo2layout.py:108; diffusion_ddpm.py:243-244).  ``ret_traj``, ``ddim``,
+        ``text`` and ``batch_seeds`` are accepted and -- exactly as in the reference, whose ``sample`` (echo2layout.py:102-110)
+        passes none of them on -- have no effect."""
+        samples = self._denoiser().sample(self.uc_rel, self.preds, noise=noise, clip_denoised=bool(clip_denoised))
         s, t = self.size_dim, self.translation_dim
         return {'sizes': samples[:, 0:s].contiguous(),
                 'translations': samples[:, s:s + t].contiguous(),
@@ -144,11 +145,11 @@ class EchoToShape(object):
     def forward(self, *a, **k):
         raise NotImplementedError('training (EchoToShape.forward / p_losses) is out of scope of this build')
 
-    def _denoiser(self):
-        if self._den is None or self._den.S != self._expected_steps():
+    def _denoiser(self, ddim_eta=0.0):
+        if self._den is None or self._den.S != self._expected_steps() or self._den.ddim_eta != float(ddim_eta):
             from ..samplers import ShapeDenoiser
             self._den = ShapeDenoiser(self.df, self.df_conf.model.params, ddim_steps=self.ddim_steps,
-                                      device=_hip_device(_dev(self.df)), z_shape=self.z_shape)
+                                      device=_hip_device(_dev(self.df)), z_shape=self.z_shape, ddim_eta=ddim_eta)
         return self._den
 
     def _expected_steps(self):
@@ -162,21 +163,19 @@ class EchoToShape(object):
         return self._dec
 
     @torch.no_grad()
-    def rel2shape(self, data, ddim_eta=0.0, noise=None, sync=True):
+    def rel2shape(self, data, ddim_eta=0.0, noise=None, sync=True, step_noise=None):
         """echo2shape.py:484-525: one latent noise shared by all objects, 100-step DDIM (eta 0, no CFG),
         then VQ-VAE decode_no_quant -> SDF [O,1,64,64,64].  ``noise`` f32[1,C,D,H,W] replaces the
         reference's wall-clock seeded draw (``torch.manual_seed(int(time.time()))``, :502)."""
-        if ddim_eta != 0.0:
-            raise NotImplementedError('ddim_eta != 0')
         self.switch_eval()
         self.set_input(data)
-        den = self._denoiser()
+        den = self._denoiser(ddim_eta)             # ddim_eta != 0: sigma_t * randn per step and object (``step_noise`` f32[S,O,C,D,H,W] or drawn)
         if noise is None:
             g = torch.Generator(device=den.device).manual_seed(int(time.time()))
             noise = torch.randn((1,) + tuple(self.z_shape), device=den.device, generator=g)
         # 'concat': c_s is a constant fourth input channel (echo2shape.py:234-235, network.py:26-28); 'crossattn' + mp
         # ignores it (the GCN output overwrites the context, openai_model_3d.py:843-844)
-        z = den.sample(self.uc_rel, self.triples, noise1=noise,
+        z = den.sample(self.uc_rel, self.triples, noise1=noise, step_noise=step_noise,
                        c=self.rel if (self.df.conditioning_key == 'concat' or
                                       not self.df.diffusion_net.messsage_passing) else None)
         self.gen_z = z                      # the latents handed to the VQ-VAE (echo2shape.py:521-522), kept like gen_df

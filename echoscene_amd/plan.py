@@ -324,7 +324,7 @@ class Builder:
         self.flops += 2 * M * pl.K * pl.N * pl.nbatch
         return out
 
-    def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True):
+    def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True, clip_x0=False):
         """eps: tensor or (slab) View"""
         a = UpdateArgs()
         if isinstance(eps, View):
@@ -339,6 +339,7 @@ class Builder:
         a.step = step.data_ptr()
         a.n = x.numel()
         a.inc_step = 1 if inc_step else 0
+        a.clip_x0 = 1 if clip_x0 else 0
         op = Op()
         op.kind, op.lane = kind, 0
         op.u.update = a

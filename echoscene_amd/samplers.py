@@ -56,13 +56,15 @@ class LayoutDenoiser:
         self.tables = time_tables(self.w, self.temb, self.w.box_t, self.device)
         self._plans, self._last, self.max_plans = {}, None, 4
 
-    def _plan_for(self, obj_embed, triples):
-        """Plans are cached by (node count, triple-row capacity): a NEW scene graph of the same size class only rewrites the
+    def _plan_for(self, obj_embed, triples, clip=False):
+        """``clip``: clip_denoised=True of p_sample_loop_sg (the predicted x0 clamped to [-1, 1], diffusion_ddpm.py:243-244) -- a
+        property of the plan's update op, so it is part of the cache key.
+        Plans are cached by (node count, triple-row capacity): a NEW scene graph of the same size class only rewrites the
         index arrays and the predicate-embedding rows in place (GraphIndex.update) -- no plan rebuild, no graph re-capture
         (0.3 s per scene in round 1).  Capacity = triple count rounded up to a multiple of 32."""
         O = obj_embed.shape[0]
         cap = _cap(triples.shape[0])
-        key = (O, cap)
+        key = (O, cap) if not clip else (O, cap, 'clip')
         sig = hash(triples.detach().cpu().numpy().tobytes())
         st = self._plans.get(key)
         if st is None:
@@ -77,7 +79,7 @@ class LayoutDenoiser:
             objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, eps, tables=self.tables)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDPM, x, eps, self.coef, step, noise=View(noise[1:].reshape(self.T, O * D), ld=O * D),
-                     noise_stride=O * D, inc_step=True)
+                     noise_stride=O * D, inc_step=True, clip_x0=clip)
             plan = b.finish()
             # eps-only plan (same ops minus the update) for step-level parity tests
             b2 = Builder(self.device)
@@ -114,10 +116,11 @@ class LayoutDenoiser:
         st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
         return st['eps'].clone()
 
-    def sample(self, obj_embed, triples, noise=None, n_steps=None, use_graph=True):
+    def sample(self, obj_embed, triples, noise=None, n_steps=None, use_graph=True, clip_denoised=False):
         """p_sample_loop_sg: returns x_0 [O, 8].  ``noise`` f32[T+1, O, 8] (row 0 = x_T, row 1+i = draw of
-        iteration i) makes the run reproducible against the CPU oracle; None draws it on the device."""
-        st = self._plan_for(obj_embed, triples)
+        iteration i) makes the run reproducible against the CPU oracle; None draws it on the device.
+        ``clip_denoised``: clamp the predicted x0 to [-1, 1] in every step (diffusion_ddpm.py:243-244; the shipped call passes False)."""
+        st = self._plan_for(obj_embed, triples, clip=bool(clip_denoised))
         O, D = st['x'].shape
         n_steps = self.T if n_steps is None else n_steps
         if noise is None:
@@ -137,12 +140,14 @@ class ShapeDenoiser:
     step as one hipGraph; world > 1 splits each step at the echo all-gather."""
 
     def __init__(self, df, model_params=None, ddim_steps=100, device=None, z_shape=(3, 16, 16, 16), rank=0, world=1,
-                 group=None, deterministic=True, force_exchange=False, precision='fp16'):
+                 group=None, deterministic=True, force_exchange=False, precision='fp16', ddim_eta=0.0):
         """``force_exchange``: build the sharded step structure (stem plan -> code exchange -> main plan) even at world == 1 --
         the one-GPU test of the captured RCCL exchange (tests/test_hip_scene.py).
         ``precision``: 'fp16' (product: fp16 MFMA operands, fp32 accumulate) or 'fp32' -- the VALIDATION route: fp32 activations and
         weights on the exact-fp32 matrix instruction (csrc/es_vol32.hip, 1/16 of the fp16 matrix rate), i.e. the reference's own
         arithmetic (openai_model_3d.py:816-863 is fp32 everywhere), so that the cost of operand rounding is a measurement."""
+        # ``ddim_eta`` != 0: stochastic DDIM -- every step adds sigma_t * randn (samplers/ddim.py:256-260); the draws of a run are a
+        # device table [S, objects x latent] filled per sample() (or handed in: ``step_noise``)
         if precision not in ('fp16', 'fp32'):
             raise ValueError("precision must be 'fp16' or 'fp32'")
         self.precision = precision
@@ -154,8 +159,9 @@ class ShapeDenoiser:
         sd = {k[len('diffusion_net.'):]: v for k, v in _cpu_sd(df).items()}
         self.w = UNet3DWeights(sd, net, self.device, precision)
         mp = dict(model_params or {})
+        self.ddim_eta = float(ddim_eta)
         self.sched = ShapeSchedule(ddim_steps, mp.get('timesteps', 1000), mp.get('linear_start', 0.00085),
-                                   mp.get('linear_end', 0.012))
+                                   mp.get('linear_end', 0.012), eta=self.ddim_eta)
         self.S = len(self.sched.timesteps)
         self.z_shape = tuple(z_shape)
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
@@ -220,8 +226,14 @@ class ShapeDenoiser:
                                       c_dev=c[lo:hi] if need_c else None, tables=self.tables,
                                       gather_rows=block * self.world)
             n_eps_ops = len(b.ops)
-            b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
-            st = dict(x=x, eps=eps, step=step, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
+            snoise = None
+            if self.ddim_eta != 0.0:
+                nz = x.numel()
+                snoise = b.buf(self.S, nz)
+                b.update(hip.OP_DDIM, x, eps, self.coef, step, noise=View(snoise, ld=nz), noise_stride=nz, inc_step=True)
+            else:
+                b.update(hip.OP_DDIM, x, eps, self.coef, step, inc_step=True)
+            st = dict(x=x, eps=eps, step=step, snoise=snoise, objbuf=objbuf, ucw=ucd.shape[1], lo=lo, hi=hi, O=O,
                       codes_local=b.codes_local, codes_all=getattr(b, 'codes_all', None), code_cols=b.code_cols,
                       xc=getattr(b, 'xc', None), g=g, pred=getattr(b, 'pred_rows', None), sig=sig,
                       cdev=getattr(b, 'cdev', None))
@@ -345,9 +357,11 @@ class ShapeDenoiser:
         st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
         return st['eps'].clone()
 
-    def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True, c=None):
+    def sample(self, uc, triples, noise1=None, n_steps=None, use_graph=True, c=None, step_noise=None):
         """DDIM loop; ``noise1`` f32[1,C,D,H,W] is shared by all objects as in the reference
         (echo2shape.py:507-510); None draws it on the device (world > 1: pass it, or every rank draws its own).
+        ``step_noise`` (ddim_eta != 0 only) f32[S, O, C,D,H,W]: the per-step draws of p_sample_ddim, one per OBJECT (noise_like without
+        repeat, ldm_diffusion_util.py:289-292); None draws them on the device.
         Returns the latents of ALL objects [O,C,D,H,W] (all-gathered when sharded)."""
         from .parallel import sharded_ddim_loop
         st = self._plan_for(uc, triples, c)
@@ -355,6 +369,12 @@ class ShapeDenoiser:
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
         st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
+        if st.get('snoise') is not None:
+            if step_noise is None:
+                st['snoise'].normal_()
+            else:
+                sn = step_noise.to(self.device).float()[:, st['lo']:st['hi']]
+                st['snoise'][:sn.shape[0]].copy_(sn.reshape(sn.shape[0], -1))
         if st.get('empty'):
             from .parallel import all_gather_rows, sharded_ddim_loop as loop
             if not self.w.mp:

@@ -56,9 +56,12 @@ class LayoutSchedule:
 
 
 class ShapeSchedule:
-    """DDIM (eta=0) coefficients, iteration i <-> index = S-1-i, timestep ts[index]."""
+    """DDIM coefficients, iteration i <-> index = S-1-i, timestep ts[index].  ``eta`` = 0 (the shipped call, echo2shape.py:484-521):
+    four coefficients per step; ``eta`` != 0: sigma_t as make_ddim_sampling_parameters derives it (ldm_diffusion_util.py:85-96: float64
+    arithmetic on the fp32 alphas, ``1 - alphas`` and its reciprocal formed in fp32 first, the result cast to fp32 when it is used) and
+    sqrt(1 - a_prev - sigma_t^2) in fp32 as p_sample_ddim forms it (samplers/ddim.py:256): five coefficients per step."""
 
-    def __init__(self, ddim_steps=100, timesteps=1000, linear_start=0.00085, linear_end=0.012):
+    def __init__(self, ddim_steps=100, timesteps=1000, linear_start=0.00085, linear_end=0.012, eta=0.0):
         betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps,
                                 dtype=torch.float64) ** 2).numpy()
         ac = torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)
@@ -68,11 +71,21 @@ class ShapeSchedule:
             # same failure the reference hits (IndexError in make_ddim_sampling_parameters)
             raise IndexError('ddim_steps=%d yields timestep %d >= %d' % (ddim_steps, ts.max(), timesteps))
         a = ac[ts]
-        a_prev = torch.tensor([ac[0].item()] + ac[ts[:-1]].tolist(), dtype=torch.float32)
+        prev_list = [ac[0].item()] + ac[ts[:-1]].tolist()
+        a_prev = torch.tensor(prev_list, dtype=torch.float32)
         s1m = torch.sqrt(1.0 - a)
-        tab = torch.stack([s1m, a.sqrt(), a_prev.sqrt(), (1.0 - a_prev - 0.0 ** 2).sqrt()], dim=1)
+        self.eta = float(eta)
+        ap64 = np.asarray(prev_list, dtype=np.float64)
+        # (the reference evaluates ``ndarray / Tensor``, i.e. Tensor.__rtruediv__ = reciprocal(1 - alphas) in fp32, times the array)
+        sig64 = self.eta * np.sqrt((1.0 - a).reciprocal().double().numpy() * (1 - ap64) * (1 - a.double().numpy() / ap64))
+        sig = torch.from_numpy(sig64).to(torch.float32)
+        self.ddim_sigmas = sig
+        cols = [s1m, a.sqrt(), a_prev.sqrt(), (1.0 - a_prev - sig ** 2).sqrt()]
+        if self.eta != 0.0:
+            cols.append(sig)
+        tab = torch.stack(cols, dim=1)
         order = np.arange(len(ts) - 1, -1, -1)
         self.ddim_timesteps = ts
         self.timesteps = ts[order]
-        self.coef = tab[torch.from_numpy(order.copy())].contiguous()        # [S, 4] by iteration
+        self.coef = tab[torch.from_numpy(order.copy())].contiguous()        # [S, 4 | 5] by iteration
         self.alphas_cumprod = ac

@@ -138,22 +138,25 @@ int es_linear_rows_auto_slices(int K, int N, int kalign_cols);
  *     x0   = c[0]*x - c[1]*eps;  mean = c[2]*x0 + c[3]*x;  x <- mean + c[4]*noise
  *   with c = coef[5*step ..] = {sqrt_recip_ac, sqrt_recipm1_ac, post_coef1, post_coef2,
  *   (t!=0)*exp(0.5*post_logvar)} prepared on the host in fp32 exactly as the reference's tables.
- * es_ddim_update: DDIMSampler.p_sample_ddim, eta = 0  (samplers/ddim.py:236-262):
- *     pred_x0 = (x - c[0]*e)/c[1];  x <- c[2]*pred_x0 + c[3]*e
- *   with c = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)}.
+ * es_ddim_update: DDIMSampler.p_sample_ddim  (samplers/ddim.py:236-262):
+ *     pred_x0 = (x - c[0]*e)/c[1];  x <- c[2]*pred_x0 + c[3]*e  (+ c[4]*noise[step] when `noise` is given: eta != 0)
+ *   with c = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma_t^2), sigma_t}; eta = 0 (the shipped call): sigma_t = 0,
+ *   noise = NULL, coef_stride 4.
  * `step` is a device scalar; when inc_step != 0 the kernel increments it after use.
  * ---------------------------------------------------------------------------------------- */
 typedef struct es_update_args {
     float* x;               /* [n] state, updated in place                                      */
     const float* eps;       /* [n] network output                                               */
     int32_t eps_nslab, eps_slab_stride;   /* eps as a slab tensor (the denoiser's last product may split K) */
-    const float* noise;     /* DDPM: noise + (*step)*noise_stride is this step's draw; DDIM: NULL */
+    const float* noise;     /* noise + (*step)*noise_stride is this step's draw (DDPM: always; DDIM: eta != 0, else NULL) */
     int32_t noise_stride;
     const float* coef;      /* [n_steps][coef_stride]                                           */
     int32_t coef_stride;
     int32_t* step;
     int32_t n;
     int32_t inc_step;
+    int32_t clip_x0;        /* DDPM: clip_denoised=True -- the predicted x0 is clamped to [-1, 1] before the posterior mean
+                               (p_mean_variance, diffusion_ddpm.py:243-244; the shipped sampling call passes False, echo2layout.py:113) */
 } es_update_args;
 int es_ddpm_update(const es_update_args* args, es_stream stream);
 /* Post-path box de-normalisation: descale_box_params (helpers/util.py:542-557;

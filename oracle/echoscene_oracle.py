@@ -394,10 +394,12 @@ def ddpm_tables(beta_start=1e-4, beta_end=0.02, time_num=1000):
     }
 
 
-def ddpm_step(tab, x, eps, t, noise):
-    """p_mean_variance + p_sample_sg, eps-prediction, 'fixedsmall', clip_denoised=False
-    (diffusion_ddpm.py:220-264, 266-271, 204-217, 296-309)."""
+def ddpm_step(tab, x, eps, t, noise, clip_denoised=False):
+    """p_mean_variance + p_sample_sg, eps-prediction, 'fixedsmall'; ``clip_denoised``: the predicted x0 clamped to [-1, 1]
+    (diffusion_ddpm.py:220-264 with :243-244, 266-271, 204-217, 296-309; the shipped sampling call passes False)."""
     x0 = tab['sqrt_recip_alphas_cumprod'][t] * x - tab['sqrt_recipm1_alphas_cumprod'][t] * eps
+    if clip_denoised:
+        x0 = torch.clamp(x0, -1.0, 1.0)
     mean = tab['posterior_mean_coef1'][t] * x0 + tab['posterior_mean_coef2'][t] * x
     logvar = tab['posterior_log_variance_clipped'][t] * torch.ones_like(x)
     nonzero = 1.0 - float(t == 0)
@@ -405,7 +407,7 @@ def ddpm_step(tab, x, eps, t, noise):
 
 
 def layout_sample_loop(sd, obj_embed, triples, noise, time_num=1000, n_steps=None,
-                       beta_start=1e-4, beta_end=0.02, heads=8, enable_t_emb=True, trace=None):
+                       beta_start=1e-4, beta_end=0.02, heads=8, enable_t_emb=True, trace=None, clip_denoised=False):
     """p_sample_loop_sg (diffusion_ddpm.py:330-345) with injected noise:
     noise[0] = x_T, noise[1+i] = draw of iteration i.  ``n_steps`` < time_num runs only the
     first n_steps iterations (t = time_num-1 ... time_num-n_steps) -- used for short goldens."""
@@ -417,7 +419,7 @@ def layout_sample_loop(sd, obj_embed, triples, noise, time_num=1000, n_steps=Non
         t = time_num - 1 - i
         t_ = torch.full((O,), t, dtype=torch.int64)
         eps = unet1d_forward(sd, x, obj_embed, triples, t_, heads, enable_t_emb)
-        x = ddpm_step(tab, x, eps, t, noise[1 + i])
+        x = ddpm_step(tab, x, eps, t, noise[1 + i], clip_denoised)
         if trace is not None:
             trace.append(x.clone())
     return x
@@ -440,21 +442,40 @@ def ddim_schedule(alphas_cumprod, S=100, ddpm_steps=1000):
     return ts, a, torch.tensor(a_prev, dtype=torch.float32), torch.sqrt(1. - a)
 
 
-def ddim_step(x, e_t, a_t, a_prev, sqrt_1m_at):
-    """p_sample_ddim with sigma=0 (ddim.py:236-262)."""
+def ddim_sigmas(alphas_cumprod, eta, S=100, ddpm_steps=1000):
+    """sigma_t of make_ddim_sampling_parameters (ldm_diffusion_util.py:85-96): the published DDIM formula evaluated the way that
+    function mixes its operands -- alphas a torch fp32 tensor, alphas_prev a float64 array -- and cast to fp32 by make_schedule."""
+    ts, a, _, _ = ddim_schedule(alphas_cumprod, S, ddpm_steps)
+    a_prev64 = np.asarray([alphas_cumprod[0].item()] + alphas_cumprod[ts[:-1]].tolist())
+    # ``ndarray / Tensor`` is Tensor.__rtruediv__ = reciprocal(self) * other: 1 - alphas AND its reciprocal are formed in fp32,
+    # everything after that in float64 (verified against the reference's tables bit for bit, tests/test_oracle_golden.py)
+    recip = (1 - a).reciprocal().double().numpy()
+    sig = eta * np.sqrt(recip * (1 - a_prev64) * (1 - a.double().numpy() / a_prev64))
+    return torch.from_numpy(sig).to(torch.float32)
+
+
+def ddim_step(x, e_t, a_t, a_prev, sqrt_1m_at, sigma_t=0.0, noise=None):
+    """p_sample_ddim (ddim.py:236-262); sigma_t = 0 for eta = 0 (the shipped call), else + sigma_t * randn."""
     a_t = torch.as_tensor(a_t, dtype=torch.float32)
     a_prev = torch.as_tensor(a_prev, dtype=torch.float32)
+    sigma_t = torch.as_tensor(sigma_t, dtype=torch.float32)
     pred_x0 = (x - sqrt_1m_at * e_t) / a_t.sqrt()
-    dir_xt = (1. - a_prev - 0.0 ** 2).sqrt() * e_t
-    return a_prev.sqrt() * pred_x0 + dir_xt
+    dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+    x_prev = a_prev.sqrt() * pred_x0 + dir_xt
+    if noise is not None:
+        x_prev = x_prev + sigma_t * noise
+    return x_prev
 
 
 def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, enable_t_emb=True,
-                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None, c_concat=None, context=None):
+                      nm=EXACT, linear_start=0.00085, linear_end=0.012, trace=None, c_concat=None, context=None, eta=0.0,
+                      step_noise=None):
     """rel2shape's DDIM loop (echo2shape.py:484-521, ddim.py:127-181): one noise tensor shared by
-    all objects, 'elif True' branch (single UNet call, no CFG), eta 0."""
+    all objects, 'elif True' branch (single UNet call, no CFG); eta 0 unless given -- then ``step_noise`` [S, O, C,D,H,W] holds the
+    per-step, per-object draws of p_sample_ddim (iteration order)."""
     ac = shape_alphas_cumprod(linear_start, linear_end)
     ts, a, a_prev, s1m = ddim_schedule(ac, S)
+    sig = ddim_sigmas(ac, eta, S)
     O = uc_s.shape[0]
     x = noise1.repeat(O, 1, 1, 1, 1).clone()
     total = len(ts)
@@ -465,7 +486,7 @@ def shape_sample_loop(sd, uc_s, triples, noise1, S=100, n_steps=None, heads=8, e
         t_ = torch.full((O,), step, dtype=torch.long)
         # ``context`` (c_s) only matters without message passing: the GCN output overwrites it otherwise
         e = unet3d_forward(sd, x, uc_s, triples, t_, context, heads, enable_t_emb, nm, c_concat=c_concat)
-        x = ddim_step(x, e, a[index], a_prev[index], s1m[index])
+        x = ddim_step(x, e, a[index], a_prev[index], s1m[index], sig[index], None if eta == 0.0 else step_noise[i])
         if trace is not None:
             trace.append(x.clone())
     return x

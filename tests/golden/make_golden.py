@@ -141,7 +141,7 @@ def case_unet1d_tiny():
     save('unet1d_tiny', box=box, obj_embed=oe, triples=triples, t=t, eps=eps.squeeze(-1))
 
 
-def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=False):
+def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=False, clip_denoised=False):
     """Runs the reference's own DiffusionPoint / GaussianDiffusion.p_sample_loop_sg with an
     injected noise_fn; optionally truncated to the first n_steps iterations."""
     from model.networks.diffusion_layout.diffusion_ddpm import DiffusionPoint
@@ -162,14 +162,14 @@ def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=Fa
     with torch.no_grad():
         if n_steps == time_num and not force_traj:
             x = df.gen_samples_sg((O, 8), 'cpu', oe, triples, condition=None, noise_fn=noise_fn,
-                                  clip_denoised=False)
+                                  clip_denoised=clip_denoised)
         else:
             # same body as p_sample_loop_sg, stopped early: call the reference's p_sample_sg
             x = noise_fn(size=(O, 8), dtype=torch.float, device='cpu')
             for t in list(reversed(range(time_num)))[:n_steps]:
                 t_ = torch.empty(O, dtype=torch.int64).fill_(t)
                 x = gd.p_sample_sg(denoise_fn=df._denoise, data=x, t=t_, obj_embed=oe, triples=triples,
-                                   condition=None, noise_fn=noise_fn, clip_denoised=False)
+                                   condition=None, noise_fn=noise_fn, clip_denoised=clip_denoised)
                 traj.append(x.clone())
     tabs = {k: getattr(gd, k) for k in ('sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
                                         'posterior_mean_coef1', 'posterior_mean_coef2',
@@ -717,6 +717,57 @@ def case_scene_flags():
     save('scene_flags_tiny', **out)
 
 
+def case_sampler_options():
+    """The two sampler options the reference's loops take beyond the shipped call (VERDICT r3 "missing #7"):
+    ``clip_denoised=True`` of the layout loop (gen_samples_sg -> p_sample_loop_sg -> p_mean_variance clamps the predicted x0 to
+    [-1, 1], diffusion_ddpm.py:243-244): all 100 steps at tiny width, injected noise;
+    ``eta != 0`` of the DDIM sampler (sigma_t * randn per step and object, samplers/ddim.py:256-260, sigmas from
+    make_ddim_sampling_parameters): 4 steps at tiny width with eta = 0.7, the per-step draws injected through noise_like, plus the
+    sigma tables of S = 4 and S = 100."""
+    net, kw = _unet1d(128, 128)
+    fill(net, 'unet1d_tiny.')
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    oe, triples, x, _, _ = _layout_loop(net, kw, 8, 3, 100, 100, noise, clip_denoised=True)
+    out = dict(layout_obj_embed=oe, layout_triples=triples, layout_x_final_clip=x)
+    from model.networks.diffusion_shape.echo2shape import EchoToShape
+    from model.networks.diffusion_shape.samplers import ddim as ddim_mod
+    from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
+    net3 = _unet3d(32, 64)
+    fill(net3, 'unet3d_tiny.')
+    shim = _ShapeShim()
+    shim.df = shim.df_module = net3
+    EchoToShape.register_schedule(shim, timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    shim.apply_model = lambda *a, **k: EchoToShape.apply_model(shim, *a, **k)
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    O = 4
+    objs, tri3 = synth.synthetic_graph(O, seed=6)
+    uc, c = rnd((O, 1, 64), 52), rnd((O, 1, 64), 53)
+    noise1 = synth.shape_noise(seed=7)
+    step_noise = torch.stack([rnd((O, 3, 16, 16, 16), 900 + k) for k in range(4)])
+    calls = {'n': 0}
+    _orig = ddim_mod.noise_like
+
+    def nl(shape, device, repeat=False):
+        k = calls['n']
+        calls['n'] += 1
+        assert tuple(shape) == (O, 3, 16, 16, 16) and not repeat
+        return step_noise[k].clone()
+    ddim_mod.noise_like = nl
+    try:
+        sampler = DDIMSampler(shim)
+        with torch.no_grad():
+            z, _ = sampler.sample(S=4, batch_size=O, shape=(3, 16, 16, 16), conditioning=c, x_T=noise1.repeat(O, 1, 1, 1, 1),
+                                  verbose=False, unconditional_guidance_scale=3., unconditional_conditioning=uc, triplet=tri3, eta=0.7)
+    finally:
+        ddim_mod.noise_like = _orig
+    assert calls['n'] == 4
+    s100 = DDIMSampler(shim)
+    s100.make_schedule(ddim_num_steps=100, ddim_eta=0.7, verbose=False)
+    out.update(ddim_uc_s=uc, ddim_triples=tri3, ddim_z_final_eta07=z, ddim_sigmas_4=torch.as_tensor(np.asarray(sampler.ddim_sigmas)),
+               ddim_sigmas_100=torch.as_tensor(np.asarray(s100.ddim_sigmas)))
+    save('sampler_options_tiny', **out)
+
+
 def case_temb():
     """a8: the reference's timestep_embedding (ldm_diffusion_util.py:174-194) for both schedules: t = 999..0 at dim 512
     (layout) and the 100 DDIM timesteps at dim 224 (shape) -- pins the product's host tables bit for bit."""
@@ -880,7 +931,7 @@ def case_gcn_ragged():
              cfg=np.array([96, 32, 3, 64, 1, 1, 80]))
 
 
-CASES = dict(unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

@@ -217,6 +217,19 @@ def test_layout_denoiser_without_time_embedding_vs_reference_golden(dev):
     _close(x, g['loop_x10'], 2e-4)
 
 
+def test_layout_loop_with_clip_denoised_vs_reference_golden(dev):
+    """clip_denoised=True (gen_samples_sg -> p_mean_variance clamps the predicted x0 to [-1, 1], diffusion_ddpm.py:243-244): all 100
+    steps at tiny width against the reference's own loop (make_golden.py case_sampler_options); through LayoutDenoiser and through the
+    drop-in EchoToLayout.generate_layout_sg, which also accepts ret_traj / ddim and -- like the reference -- ignores them."""
+    g = load_golden('sampler_options_tiny')
+    den = _layout(dev, 128, 128, 'unet1d_tiny.', 100)
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    x = den.sample(g['layout_obj_embed'], g['layout_triples'], noise, clip_denoised=True)
+    _close(x, g['layout_x_final_clip'], 2e-4)
+    x_plain = den.sample(g['layout_obj_embed'], g['layout_triples'], noise)
+    _close(x_plain, load_golden('layout_loop_tiny')['x_final'], 2e-4)      # the unclipped plan is a separate cache entry
+
+
 def test_unet1d_tiny_blockwise_vs_oracle(dev):
     """Every intermediate of the tiny layout denoiser (time MLP, GCN context, each ResBlock /
     transformer / resample output) against the CPU oracle -- localises any mismatch."""

@@ -115,6 +115,32 @@ def test_unet1d_full_without_time_embedding():
     _close(x, g['loop_x10'], 1e-4)
 
 
+def test_sampler_options_clip_denoised_and_ddim_eta():
+    """The sampler options beyond the shipped call: clip_denoised=True of the layout loop (diffusion_ddpm.py:243-244) and eta != 0 of the
+    DDIM sampler (samplers/ddim.py:256-260) -- goldens from the reference's own loops (make_golden.py case_sampler_options); the sigma
+    tables of the oracle AND of the product's ShapeSchedule must be bit-identical to the reference's."""
+    from echoscene_amd.schedules import ShapeSchedule
+    g = load_golden('sampler_options_tiny')
+    sd = _unet1d_sd(128, 128, 'unet1d_tiny.')
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    x = orc.layout_sample_loop(sd, g['layout_obj_embed'], g['layout_triples'], noise, time_num=100, clip_denoised=True)
+    _close(x, g['layout_x_final_clip'], 1e-4)
+    plain = load_golden('layout_loop_tiny')['x_final']
+    assert (x - plain).abs().max() > 1e-3, 'the clamp must be active on this trajectory (else the golden pins nothing)'
+    ac = orc.shape_alphas_cumprod()
+    for S in (4, 100):
+        assert torch.equal(orc.ddim_sigmas(ac, 0.7, S), g['ddim_sigmas_%d' % S].float())
+        sch = ShapeSchedule(S, eta=0.7)
+        assert torch.equal(sch.ddim_sigmas, g['ddim_sigmas_%d' % S].float())
+        assert sch.coef.shape == (S, 5) and torch.equal(sch.coef[:, 4], sch.ddim_sigmas.flip(0))
+        assert torch.equal(ShapeSchedule(S).coef, sch.coef[:, :4]) is False        # sqrt(1 - a_prev - sigma^2) differs from eta = 0
+    dsd = _unet3d_sd(32, 64, 'unet3d_tiny.')
+    step_noise = torch.stack([torch.from_numpy((__import__('numpy').random.RandomState(900 + k).standard_normal((4, 3, 16, 16, 16))).astype('float32'))
+                              for k in range(4)])
+    z = orc.shape_sample_loop(dsd, g['ddim_uc_s'], g['ddim_triples'], synth.shape_noise(seed=7), S=4, eta=0.7, step_noise=step_noise)
+    _close(z, g['ddim_z_final_eta07'], 2e-4)
+
+
 def _unet3d_sd(mc, ctx, prefix):
     p = escfg.shape_unet_params(mc)
     p['context_dim'] = ctx
