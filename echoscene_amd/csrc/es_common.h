@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include "../../include/echoscene_hip.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -12,6 +14,24 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 void es_set_error(const char* fmt, ...);
+
+// Host-side parallel loop for the one-off weight re-layouts (es_pack_*): 430 M shape-UNet weights through a scalar loop were 9 of the
+// 9.2 s of a process's first scene call.  f(i) for i in [0, n), strided over up to 32 threads; serial when threads cannot be had.
+template <class F>
+inline void es_parallel_for(long n, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 32) nt = 32;
+    if ((long)nt > n) nt = (unsigned)n;
+    if (nt <= 1) { for (long i = 0; i < n; ++i) f(i); return; }
+    std::vector<std::thread> th;
+    unsigned started = 0;
+    try {
+        for (; started < nt; ++started) th.emplace_back([=] { for (long i = started; i < n; i += nt) f(i); });
+    } catch (...) {                              // (could not start every thread: the missing residues run here)
+        for (unsigned t = started; t < nt; ++t) for (long i = t; i < n; i += nt) f(i);
+    }
+    for (auto& t : th) t.join();
+}
 
 #define ES_CHECK_HIP(expr)                                                                   \
     do {                                                                                     \

@@ -457,16 +457,17 @@ extern "C" size_t es_pack_linear_f32_size(int N, int K) {
 
 extern "C" int es_pack_linear_f32(const float* w, int N, int K, float* out) {
     const int NT = (N + 15) / 16, KB = (K + 15) / 16;
-    for (int nt = 0; nt < NT; ++nt)
+    es_parallel_for(NT, [=](long nt) {
         for (int kb = 0; kb < KB; ++kb)
             for (int lane = 0; lane < 64; ++lane) {
                 const int j = lane & 15, q = lane >> 4;
-                const int n = nt * 16 + j;
+                const int n = (int)nt * 16 + j;
                 for (int e = 0; e < 4; ++e) {
                     const int k = kb * 16 + 4 * q + e;
                     out[(((size_t)nt * KB + kb) * 64 + lane) * 4 + e] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
                 }
             }
+    });
     return 0;
 }
 

@@ -2058,20 +2058,20 @@ static inline uint16_t f32_to_f16_bits(float f) {
 extern "C" int es_pack_conv_f16(const float* h_w, int N, int CinW, int taps, uint16_t* h_out) {
     const int Cin = (CinW + 31) / 32 * 32;
     const int nt = (N + BN - 1) / BN, kch = Cin / 32;
-    for (int t = 0; t < nt; ++t)
-        for (int kc = 0; kc < kch; ++kc)
-            for (int tap = 0; tap < taps; ++tap) {
-                uint16_t* blk = h_out + ((size_t)(t * kch + kc) * taps + tap) * (BNP * BK);
-                for (int p = 0; p < BNP * 4; ++p) {
-                    const int row = p >> 2, lc = (p & 3) ^ h_swz(row);
-                    const int n = t * BN + row;
-                    for (int e = 0; e < 8; ++e) {
-                        const int c = kc * 32 + lc * 8 + e;
-                        blk[p * 8 + e] = (row < BN && n < N && c < CinW)
-                                             ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + tap]) : 0;
-                    }
-                }
+    // one 16 KiB block per (n-tile, channel chunk, tap); the blocks are independent: spread over the host's threads
+    es_parallel_for((long)nt * kch * taps, [=](long bi) {
+        const int tap = (int)(bi % taps), kc = (int)((bi / taps) % kch), t = (int)(bi / ((long)taps * kch));
+        uint16_t* blk = h_out + (size_t)bi * (BNP * BK);
+        for (int p = 0; p < BNP * 4; ++p) {
+            const int row = p >> 2, lc = (p & 3) ^ h_swz(row);
+            const int n = t * BN + row;
+            for (int e = 0; e < 8; ++e) {
+                const int c = kc * 32 + lc * 8 + e;
+                blk[p * 8 + e] = (row < BN && n < N && c < CinW)
+                                     ? f32_to_f16_bits(h_w[((size_t)n * CinW + c) * taps + tap]) : 0;
             }
+        }
+    });
     return 0;
 }
 
