@@ -117,8 +117,18 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
             const long sstr = sg.slab_stride;
             const int pro = sg.pro;
             const bool relu_in = sg.pre_act == ES_ACT_RELU;
-            if (CSR && (sg.mode == ES_SEG_CSRMEAN || sg.mode == ES_SEG_CSRSUM)) {
+            if (CSR && (sg.mode == ES_SEG_CSRMEAN || sg.mode == ES_SEG_CSRSUM || sg.mode == ES_SEG_CSRWAVG)) {
                 const int e0 = sg.idx[mc], e1 = sg.idx[mc + 1];
+                const bool wavg = sg.mode == ES_SEG_CSRWAVG;
+                float wden = 1.0f;
+                if (wavg) {
+                    // pooling='wAvg' (graph.py:178-184): the weights of the node's entries summed in the reference's scatter_add
+                    // order -- the object slots first, then the subject slots, each in triple order -- plus 1e-4
+                    float ws = 0.f;
+                    for (int e = e0; e < e1; ++e) if (sg.ent_off[e] != 0) ws += sg.ent_wt[2 * sg.ent_row[e] + 1];
+                    for (int e = e0; e < e1; ++e) if (sg.ent_off[e] == 0) ws += sg.ent_wt[2 * sg.ent_row[e]];
+                    wden = ws + 0.0001f;
+                }
                 for (int c4 = cl; c4 < w4; c4 += LPR) {
                     f4 v = {0.f, 0.f, 0.f, 0.f};
                     // stored order == scatter_add order of the reference.  Entries are fetched 8 at a time (index pairs,
@@ -126,10 +136,12 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
                     for (int e = e0; e < e1; e += 8) {
                         long off[8];
                         f4 t[8];
+                        float wt[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int ee = min(e + u, e1 - 1);
                             off[u] = (long)sg.ent_row[ee] * sg.ld + sg.ent_off[ee];
+                            wt[u] = wavg ? sg.ent_wt[2 * sg.ent_row[ee] + (sg.ent_off[ee] != 0 ? 1 : 0)] : 1.0f;
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) t[u] = *(const f4*)(base + off[u] + 4 * c4);
@@ -143,10 +155,14 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) t[u][q] = fmaxf(t[u][q], 0.f);
                             }
+                            if (wavg) {                                  // s_weights * new_s_vecs is a rounded product, THEN scatter_add (graph.py:169-177)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) t[u][q] = __fmul_rn(wt[u], t[u][q]);
+                            }
                             if (e + u < e1) v += t[u];
                         }
                     }
-                    const float den = sg.mode == ES_SEG_CSRMEAN ? (float)max(e1 - e0, 1) : 1.0f;     // 'avg' pooling divides by the clamped count
+                    const float den = sg.mode == ES_SEG_CSRMEAN ? (float)max(e1 - e0, 1) : wavg ? wden : 1.0f;   // 'avg' pooling divides by the clamped count
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = row_ok ? v[q] / den : 0.f;
                     *(f4*)(dst + 4 * c4) = v;
@@ -384,6 +400,7 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
             if (bias) sres += e_bias;
             if (a.act == ES_ACT_RELU) sres = fmaxf(sres, 0.f);
             else if (a.act == ES_ACT_SILU) sres = es_silu(sres);
+            else if (a.act == ES_ACT_SIGMOID) sres = 1.0f / (1.0f + expf(-sres));
             if (a.res) sres += e_res;
             if (a.res2) sres += e_res2;
         }
@@ -471,6 +488,34 @@ extern "C" int es_pack_linear_f32(const float* w, int N, int K, float* out) {
     return 0;
 }
 
+// the same image formed on the device from the fp32 weight already in HBM (one float4 per thread)
+__global__ __launch_bounds__(256) void k_pack_linear_f32(const float* __restrict__ w, int N, int K, int KB, f4* __restrict__ out, long nvec) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int lane = (int)(i & 63);
+    const long tb = i >> 6;
+    const int kb = (int)(tb % KB);
+    const long nt = tb / KB;
+    const int j = lane & 15, q = lane >> 4;
+    const long n = nt * 16 + j;
+    f4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = kb * 16 + 4 * q + e;
+        v[e] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+    }
+    out[i] = v;
+}
+
+extern "C" int es_pack_linear_f32_dev(const float* d_w, int N, int K, float* d_out, es_stream stream) {
+    ES_REQUIRE(d_w && d_out && N > 0 && K > 0, "es_pack_linear_f32_dev: N=%d K=%d", N, K);
+    const int NT = (N + 15) / 16, KB = (K + 15) / 16;
+    const long nvec = (long)NT * KB * 64;
+    hipLaunchKernelGGL(k_pack_linear_f32, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, N, K, KB, (f4*)d_out, nvec);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // GEGLU variant: W[2*Nh, K] = [value rows | gate rows]  ->  rows interleaved per 16-row tile as 8 value + 8 gate,
 // then packed as usual.  h_bias (2*Nh, may be NULL) is permuted into h_bias_out the same way.
 extern "C" int es_pack_linear_geglu_f32(const float* w, const float* h_bias, int Nh, int K, float* out, float* h_bias_out) {
@@ -538,8 +583,12 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
                    "es_linear_rows_f32: segment %d width/ld must be multiples of 4 (width=%d ld=%d)", s,
                    a.seg[s].width, a.seg[s].ld);
         ES_REQUIRE(a.seg[s].nslab <= 1 || a.seg[s].slab_stride % 4 == 0, "es_linear_rows_f32: segment %d slab stride %d", s, a.seg[s].slab_stride);
+        ES_REQUIRE(a.seg[s].mode >= ES_SEG_DIRECT && a.seg[s].mode <= ES_SEG_CSRWAVG, "es_linear_rows_f32: segment %d mode %d", s, a.seg[s].mode);
+        ES_REQUIRE(a.seg[s].mode != ES_SEG_CSRWAVG || (a.seg[s].ent_wt && a.seg[s].idx && a.seg[s].ent_row && a.seg[s].ent_off),
+                   "es_linear_rows_f32: segment %d: weighted pooling needs row pointers, entries and the weight matrix", s);
         ksum += a.seg[s].width;
     }
+    ES_REQUIRE(a.act >= ES_ACT_NONE && a.act <= ES_ACT_SIGMOID, "es_linear_rows_f32: epilogue activation %d", a.act);
     ES_REQUIRE(ksum == a.K, "es_linear_rows_f32: segment widths sum to %d, K=%d", ksum, a.K);
     ES_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "es_linear_rows_f32: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     // the op-level prologue is shorthand for "every segment": GroupNorm32 / LayerNorm over the concatenation
@@ -600,7 +649,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
         const int pro = a.seg[s].pro;
         if (pro == ES_PRO_GN || pro == ES_PRO_GN_SILU) proc = proc < 1 ? 1 : proc;
         if (pro == ES_PRO_SILU || pro == ES_PRO_GEGLU) proc = 2;
-        csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN || a.seg[s].mode == ES_SEG_CSRSUM;
+        csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN || a.seg[s].mode == ES_SEG_CSRSUM || a.seg[s].mode == ES_SEG_CSRWAVG;
     }
     out->a = a; out->S = S; out->kbps = kbps; out->nsmax = nsmax; out->proc = proc; out->nb = nb;
     out->has_ln = has_ln; out->csr = csr; out->gepi = a.act == ES_ACT_GEGLU;

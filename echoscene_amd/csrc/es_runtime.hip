@@ -226,7 +226,7 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
             for (int s = 0; s < 3; ++s) {
                 const size_t b = offsetof(es_op, u.linear.seg) + s * sizeof(es_seg);
                 for (size_t f : {offsetof(es_seg, ptr), offsetof(es_seg, idx), offsetof(es_seg, ent_row), offsetof(es_seg, ent_off),
-                                 offsetof(es_seg, step), offsetof(es_seg, gamma), offsetof(es_seg, beta)})
+                                 offsetof(es_seg, step), offsetof(es_seg, gamma), offsetof(es_seg, beta), offsetof(es_seg, ent_wt)})
                     v.push_back(b + f);
             }
             for (size_t f : {ES_PTR(linear.wpack), ES_PTR(linear.bias), ES_PTR(linear.gamma), ES_PTR(linear.beta), ES_PTR(linear.res),

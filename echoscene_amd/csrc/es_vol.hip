@@ -2075,6 +2075,37 @@ extern "C" int es_pack_conv_f16(const float* h_w, int N, int CinW, int taps, uin
     return 0;
 }
 
+// The same image formed on the device from the fp32 weight already in HBM (one 16-byte slot per thread): a process's first scene
+// call spent 6 of its 9 s in the host loop above (a strided gather with a software fp32 -> fp16 conversion, ~70 M elements/s on 8
+// threads against 410 M weights); reading the uploaded tensor with the stride of the taps costs the GPU milliseconds.
+__global__ __launch_bounds__(256) void k_pack_conv_f16(const float* __restrict__ w, int N, int CinW, int taps, int kch, h8* __restrict__ out,
+                                                        long nslots) {
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nslots) return;
+    const int p = (int)(s & (BNP * 4 - 1));
+    const long bi = s / (BNP * 4);
+    const int tap = (int)(bi % taps), kc = (int)((bi / taps) % kch), t = (int)(bi / ((long)taps * kch));
+    const int row = p >> 2, lc = (p & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
+    const int n = t * BN + row;
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = kc * 32 + lc * 8 + e;
+        v[e] = (row < BN && n < N && c < CinW) ? (_Float16)w[((size_t)n * CinW + c) * taps + tap] : (_Float16)0.f;   // round to nearest even
+    }
+    out[s] = v;
+}
+
+extern "C" int es_pack_conv_f16_dev(const float* d_w, int N, int CinW, int taps, uint16_t* d_out, es_stream stream) {
+    ES_REQUIRE(d_w && d_out && N > 0 && CinW > 0 && (taps == 1 || taps == 27), "es_pack_conv_f16_dev: N=%d Cin=%d taps=%d", N, CinW, taps);
+    const int Cin = (CinW + 31) / 32 * 32;
+    const long nslots = (long)es_pack_conv_f16_size(N, Cin, taps) / 8;
+    hipLaunchKernelGGL(k_pack_conv_f16, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, N, CinW, taps, Cin / 32,
+                       (h8*)d_out, nslots);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // Row-major image [N][taps][Cin] for k_conv_small_n (N <= 4)
 extern "C" int es_pack_conv_rows_f16(const float* h_w, int N, int CinW, int taps, uint16_t* h_out) {
     const int Cin = (CinW + 31) / 32 * 32;

@@ -13,9 +13,9 @@ c_f32p = C.c_void_p
 c_i32p = C.c_void_p
 
 # enums (include/echoscene_hip.h)
-SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN, SEG_CSRSUM = 0, 1, 2, 3
+SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN, SEG_CSRSUM, SEG_CSRWAVG = 0, 1, 2, 3, 4
 PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW, CONV_DOWN_DHW = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
 (OP_LINEAR, OP_DDPM, OP_DDIM, OP_COPY, OP_CONV, OP_GN, OP_LN, OP_ATTN, OP_GEGLU, OP_TO_CL, OP_STEM) = range(1, 12)
@@ -28,7 +28,8 @@ class Seg(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('idx', C.c_void_p), ('ent_row', C.c_void_p), ('ent_off', C.c_void_p),
                 ('step', C.c_void_p), ('step_stride', C.c_int32), ('ld', C.c_int32), ('width', C.c_int32),
                 ('mode', C.c_int32), ('nslab', C.c_int32), ('slab_stride', C.c_int32), ('pre_act', C.c_int32),
-                ('pro', C.c_int32), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('gs', C.c_int32)]
+                ('pro', C.c_int32), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('eps', C.c_float), ('gs', C.c_int32),
+                ('ent_wt', C.c_void_p)]
 
 
 class LinearArgs(C.Structure):
@@ -128,6 +129,7 @@ EXPORTS = {
     'es_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     'es_pack_linear_f32_size': (C.c_size_t, [C.c_int, C.c_int]),
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'es_pack_linear_f32_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_linear_rows_multi_f32': (C.c_int, [C.POINTER(C.POINTER(LinearArgs)), C.c_int, C.c_void_p]),
@@ -142,6 +144,7 @@ EXPORTS = {
     'es_conv_emits_gn_stats': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'es_pack_conv_f16_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_pack_conv_rows_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_groupnorm_vol': (C.c_int, [C.POINTER(GNArgs), C.c_void_p]),
     'es_layernorm_tokens': (C.c_int, [C.POINTER(LNArgs), C.c_void_p]),
@@ -199,7 +202,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 5:
+        if L.es_abi_version() != 6:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

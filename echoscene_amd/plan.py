@@ -61,7 +61,7 @@ class View:
 
 
 def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=None, step_stride=0, width=None,
-        pro=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, gs=0, pre_act=hip.ACT_NONE, goff=0):
+        pro=hip.PRO_NONE, gamma=None, beta=None, eps=0.0, gs=0, pre_act=hip.ACT_NONE, goff=0, ent_wt=None):
     """One K segment of a rows launch.  pro/gamma/beta/eps/gs: the segment's own prologue (GroupNorm in groups of ``gs``
     channels, LayerNorm, SiLU); ``goff``: offset of the segment's first channel inside gamma/beta; ``pre_act``: activation
     applied to the (slab-summed) source first."""
@@ -82,7 +82,8 @@ def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=No
     s.beta = beta.data_ptr() + 4 * goff if beta is not None else None
     s.eps = eps
     s.gs = gs
-    s._keep = (view.t, idx, ent_row, ent_off, step, gamma, beta)
+    s.ent_wt = ent_wt.ptr if ent_wt is not None else None            # SEG_CSRWAVG: View of the [T, 2] weights
+    s._keep = (view.t, idx, ent_row, ent_off, step, gamma, beta, ent_wt.t if ent_wt is not None else None)
     return s
 
 
@@ -110,11 +111,29 @@ class PackedLinear:
     that the kernel's epilogue (ES_ACT_GEGLU) can emit value*gelu(gate) directly (N_out = N/2)."""
 
     def __init__(self, W, b, device, geglu=False):
-        W = W.detach().to(torch.float32).contiguous().cpu()
         self.N, self.K = W.shape
         self.geglu = geglu
         L = hip.lib()
         n = L.es_pack_linear_f32_size(self.N, self.K)
+        if torch.device(device).type == 'cuda':
+            # the re-layout runs on the GPU from the uploaded fp32 weight (es_pack_linear_f32_dev; bit-identical to the host loop)
+            with torch.cuda.device(device):
+                Wd = W.detach().to(device=device, dtype=torch.float32).contiguous()
+                if geglu:                    # [value rows | gate rows] -> per 16-row tile 8 value rows + their 8 gate rows
+                    Nh = self.N // 2
+                    if Nh % 8:
+                        raise ValueError('GEGLU projection with %d outputs (a multiple of 8 is needed)' % Nh)
+                    idx = (torch.arange(Nh, device=device).view(-1, 1, 8) + torch.tensor([0, Nh], device=device).view(1, 2, 1)).reshape(-1)
+                    Wd = Wd.index_select(0, idx)
+                    b = None if b is None else b.detach().to(device=device, dtype=torch.float32).index_select(0, idx)
+                out = torch.empty(n, dtype=torch.float32, device=device)
+                hip.check(L.es_pack_linear_f32_dev(hip.ptr(Wd), self.N, self.K, hip.ptr(out), hip.current_stream()), 'es_pack_linear_f32_dev')
+            self.w = out
+            self.b = None if b is None else b.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.weight_bytes = self.N * self.K * 4
+            self.nbatch = 1
+            return
+        W = W.detach().to(torch.float32).contiguous().cpu()
         out = torch.empty(n, dtype=torch.float32)
         if geglu:
             bh = None if b is None else b.detach().to(torch.float32).contiguous().cpu()
@@ -136,11 +155,11 @@ class PackedLinearBatch(PackedLinear):
     """Several linears of identical shape stored back to back (one batched launch, grid.z = len)."""
 
     def __init__(self, Ws, bs, device):
-        parts = [PackedLinear(W, b, 'cpu') for W, b in zip(Ws, bs)]
+        parts = [PackedLinear(W, b, device) for W, b in zip(Ws, bs)]
         self.N, self.K, self.geglu = parts[0].N, parts[0].K, False
         assert all(p.N == self.N and p.K == self.K for p in parts)
-        self.w = torch.cat([p.w for p in parts]).to(device)
-        self.b = torch.cat([p.b for p in parts]).to(device) if parts[0].b is not None else None
+        self.w = torch.cat([p.w for p in parts])
+        self.b = torch.cat([p.b for p in parts]) if parts[0].b is not None else None
         self.weight_bytes = sum(p.weight_bytes for p in parts)
         self.nbatch = len(parts)
 
@@ -487,12 +506,17 @@ def combine_plans(device, main, side, side_repeat=1):
 # ------------------------------------------------------------------------------------------------
 # GraphTripleConvNet  (reference model/graph.py:89-250)
 # ------------------------------------------------------------------------------------------------
+def Dp_of(L):
+    """predicate width of a packed GraphTripleConv layer: net1's output is [H | Dp | H] wide (graph.py:108)"""
+    return L['n1b'].N - 2 * L['H']
+
+
 class GCNWeights:
     """Packed weights of one GraphTripleConvNet: BatchNorm folded into the Linears."""
 
     def __init__(self, sd, prefix, device, pooling='avg'):
-        if pooling not in ('avg', 'sum'):
-            raise NotImplementedError("GraphTripleConv pooling=%r: 'avg' and 'sum' are implemented ('wAvg' needs its weighting net)" % pooling)
+        if pooling not in ('avg', 'sum', 'wAvg'):
+            raise ValueError('Invalid pooling "%s"' % pooling)              # graph.py:105
         self.pooling = pooling
         self.layers = []
         i = 0
@@ -518,6 +542,31 @@ class GCNWeights:
                 L['projp'] = PackedLinear(sd[p + '.linear_projection_pred.weight'],
                                           sd[p + '.linear_projection_pred.bias'], device)
                 L['Dobj'] = L['proj'].K
+            if pooling == 'wAvg':
+                # WeightNetGCN (graph.py:37-86): two down-sampling Linears to 128 features, then one head per triple slot
+                # (Linear(384, 64) + ReLU + Linear(64, 1) + Sigmoid).  The two heads read the same features: their first Linears
+                # are stacked into one [128, 384] product and their second ones into a block-diagonal [2, 128] product (the zero
+                # blocks add exact zeros, every head's 64 terms keep their order).
+                q = p + '.weightNet'
+                L['wn_obj'] = PackedLinear(sd[q + '.down_sample_obj.weight'], sd[q + '.down_sample_obj.bias'], device)
+                L['wn_pred'] = PackedLinear(sd[q + '.down_sample_pred.weight'], sd[q + '.down_sample_pred.bias'], device)
+                if (q + '.Net_s.0.weight') in sd:
+                    heads = ('Net_s', 'Net_o')
+                else:                                                       # separate_s_o=False: one head for both slots
+                    heads = ('Net', 'Net')
+                W1 = torch.cat([sd[f'{q}.{h}.0.weight'].float() for h in heads], 0)
+                b1 = torch.cat([sd[f'{q}.{h}.0.bias'].float() for h in heads], 0)
+                nh = sd[f'{q}.{heads[0]}.0.weight'].shape[0]
+                W2 = torch.zeros(2, 2 * nh)
+                W2[0, :nh] = sd[f'{q}.{heads[0]}.2.weight'].float()[0]
+                W2[1, nh:] = sd[f'{q}.{heads[1]}.2.weight'].float()[0]
+                b2 = torch.cat([sd[f'{q}.{h}.2.bias'].float() for h in heads], 0)
+                L['wn_h'] = PackedLinear(W1, b1, device)
+                L['wn_w'] = PackedLinear(W2, b2, device)
+                if L['wn_pred'].K != Dp_of(L):
+                    raise ValueError("pooling='wAvg': the weighting net down-samples predicates of width %d, the layer's are %d wide "
+                                     "(the reference's WeightNetGCN(hidden_dim, output_dim, 128) needs output_dim == input_dim_pred)"
+                                     % (L['wn_pred'].K, Dp_of(L)))
             self.layers.append(L)
             i += 1
         if not self.layers:
@@ -555,8 +604,21 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         t2 = View(b.buf(T, W2))
         b.linear([seg(t1, pre_act=hip.ACT_RELU)], L['n1b'], T, t2, act=hip.ACT_RELU)
         ptr, rows, offs = g.csr(0, H + Dp)
-        n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), hip.SEG_CSRSUM if getattr(gw, 'pooling', 'avg') == 'sum' else hip.SEG_CSRMEAN,
-                           idx=ptr, ent_row=rows, ent_off=offs)],
+        pooling = getattr(gw, 'pooling', 'avg')
+        wts = None
+        if pooling == 'wAvg':
+            # s_weights, o_weights = weightNet(new_s, new_p, new_o) (graph.py:165-167): feat = [down(s) | down(o) | down(p)]
+            feat = b.buf(T, 3 * L['wn_obj'].N)
+            nf = L['wn_obj'].N
+            b.linear([seg(View(t2.t, col=0, ld=W2, width=H))], L['wn_obj'], T, View(feat, col=0, width=nf))
+            b.linear([seg(View(t2.t, col=H + Dp, ld=W2, width=H))], L['wn_obj'], T, View(feat, col=nf, width=nf))
+            b.linear([seg(View(t2.t, col=H, ld=W2, width=Dp))], L['wn_pred'], T, View(feat, col=2 * nf, width=nf))
+            hid = View(b.buf(T, L['wn_h'].N))
+            b.linear([seg(View(feat))], L['wn_h'], T, hid, act=hip.ACT_RELU)
+            wts = View(b.buf(T, 2))
+            b.linear([seg(hid)], L['wn_w'], T, wts, act=hip.ACT_SIGMOID)
+        mode = {'avg': hip.SEG_CSRMEAN, 'sum': hip.SEG_CSRSUM, 'wAvg': hip.SEG_CSRWAVG}[pooling]
+        n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), mode, idx=ptr, ent_row=rows, ent_off=offs, ent_wt=wts)],
                       L['n2a'], O, fuse_next=need_newp)                                      # relu deferred
         if need_newp:
             newp = View(b.buf(T, Dp))

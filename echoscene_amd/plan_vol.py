@@ -20,16 +20,18 @@ class PackedConv:
     """f16 [Npad][taps][Cin32] image of a conv / linear weight + fp32 bias on the device."""
 
     def __init__(self, W, b, device, geglu=False):
-        W = W.detach().float().contiguous().cpu()
+        on_gpu = torch.device(device).type == 'cuda'
+        W = W.detach().float().contiguous()
+        W = W.to(device) if on_gpu else W.cpu()
         self.geglu = False
         if geglu and W.dim() == 2 and (W.shape[0] // 2) % 112 == 0 and b is not None:
             # GEGLU fused into the contraction epilogue (ES_EPI_GEGLU): every 16-row group of the packed weight = the value rows
             # of 8 outputs, then their 8 gate rows (value = first half of the projection, attention.py:39-46), so the value and
             # the gate of an output land in lanes i16 and i16 ^ 8 of one MFMA tile (echoscene_hip.h: es_conv_args.epilogue)
             C4 = W.shape[0] // 2
-            idx = torch.cat([torch.cat([torch.arange(t, t + 8), C4 + torch.arange(t, t + 8)]) for t in range(0, C4, 8)])
-            W = W[idx].contiguous()
-            b = b.detach().float()[idx].contiguous()
+            idx = (torch.arange(C4).view(-1, 1, 8) + torch.tensor([0, C4]).view(1, 2, 1)).reshape(-1)
+            W = W.index_select(0, idx.to(W.device)).contiguous()
+            b = b.detach().float().cpu()[idx].contiguous()
             self.geglu = True
         self.N, cin = W.shape[0], W.shape[1]
         self.taps = 1 if W.dim() == 2 else int(W[0, 0].numel())
@@ -38,9 +40,16 @@ class PackedConv:
         self.Cin = (cin + 31) // 32 * 32
         L = hip.lib()
         if self.N <= 4 and self.taps == 27 and self.Cin <= 64:   # consumed by the small-N kernels (VQ-VAE conv_out)
+            W = W.cpu()
             out = torch.empty(self.N * self.taps * self.Cin, dtype=torch.int16)
             hip.check(L.es_pack_conv_rows_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps,
                                               C.c_void_p(out.data_ptr())), 'es_pack_conv_rows_f16')
+        elif on_gpu:
+            # the tiled image is formed on the GPU from the uploaded fp32 weight (es_pack_conv_f16_dev: bit-identical to the host loop,
+            # which was 6 of the 9 s of a process's first scene call)
+            with torch.cuda.device(device):
+                out = torch.empty(L.es_pack_conv_f16_size(self.N, self.Cin, self.taps), dtype=torch.int16, device=device)
+                hip.check(L.es_pack_conv_f16_dev(hip.ptr(W), self.N, cin, self.taps, hip.ptr(out), hip.current_stream()), 'es_pack_conv_f16_dev')
         else:
             n = L.es_pack_conv_f16_size(self.N, self.Cin, self.taps)
             out = torch.empty(n, dtype=torch.int16)

@@ -20,11 +20,11 @@ def _cpu_sd(module):
     return {k: v.detach().cpu() for k, v in module.state_dict().items()}
 
 
-def gcn_forward(sd, prefix, obj, pred, triples, device=None, weights=None):
+def gcn_forward(sd, prefix, obj, pred, triples, device=None, weights=None, pooling='avg'):
     """GraphTripleConvNet.forward on the HIP path (setup GCNs and unit tests).
     obj f32[O,Dobj], pred f32[T,Dp] (any device), triples int64[T,3] -> (obj_out, pred_out) on device."""
     device = device or torch.device('cuda')
-    gw = weights or GCNWeights(sd, prefix, device)
+    gw = weights or GCNWeights(sd, prefix, device, pooling)
     g = GraphIndex(triples, obj.shape[0], device)
     b = Builder(device)
     o = b.dev(obj)

@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 5
+#define ES_ABI_VERSION 6
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -48,9 +48,11 @@ int es_device_info(char* name_out, int name_cap, int* cu_count);
  *   Chip-wide parallelism for M = 32: grid = (16-column tiles x K slices, 16-row tiles); split-K partial sums are
  *   never reduced by a kernel of their own -- they are "slab tensors" summed by whoever reads them next.
  * ---------------------------------------------------------------------------------------- */
-enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2, ES_SEG_CSRSUM = 3 };   /* CSRSUM: pooling='sum' (graph.py:186-199 without the division) */
+enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2, ES_SEG_CSRSUM = 3, ES_SEG_CSRWAVG = 4 };
+/* CSRSUM: pooling='sum' (graph.py:186-199 without the division); CSRWAVG: pooling='wAvg' (graph.py:163-184): every entry is scaled by
+ * its learned weight (es_seg.ent_wt) before the sum and the sum is divided by (sum of the weights + 1e-4) */
 enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
-enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2, ES_ACT_GEGLU = 3 };
+enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2, ES_ACT_GEGLU = 3, ES_ACT_SIGMOID = 4 };   /* SIGMOID: WeightNetGCN's heads (graph.py:44-57) */
 /* ES_ACT_GEGLU: W/bias rows are interleaved per 16-row tile as [8 value rows | 8 gate rows] (es_pack_linear_geglu_f32);
  * the kernel writes N/2 columns: value * gelu(gate)  (GEGLU.forward, attention.py:39-46). */
 
@@ -77,6 +79,9 @@ typedef struct es_seg {
     const float* gamma; const float* beta;
     float eps;
     int32_t gs;
+    /* CSRWAVG: weights [rows of the source, 2]; an entry of source row t is scaled by ent_wt[2 t] when its column offset is 0 (the
+     * subject slot of the triple) and by ent_wt[2 t + 1] otherwise (the object slot): s_weights / o_weights of graph.py:165-170 */
+    const float* ent_wt;
 } es_seg;
 
 typedef struct es_linear_args {
@@ -119,6 +124,8 @@ typedef struct es_linear_args {
  * holds W[nt*16+j][kb*16+4q .. +3], zero padded. */
 size_t es_pack_linear_f32_size(int N, int K);
 int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
+/* the same image from a weight already on the device (what the Python host uses: the host loop is a strided gather) */
+int es_pack_linear_f32_dev(const float* d_w, int N, int K, float* d_out, es_stream stream);
 /* GEGLU projection W[2*Nh,K] (value rows | gate rows): interleave per 16-row tile, then pack (ES_ACT_GEGLU) */
 int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int K, float* h_out, float* h_bias_out);
 
@@ -235,6 +242,8 @@ int es_conv_emits_gn_stats(const es_conv_args* args);
  * block per K step.  h_out holds uint16 bit patterns. */
 size_t es_pack_conv_f16_size(int N, int Cin, int taps);
 int es_pack_conv_f16(const float* h_w, int N, int Cin, int taps, uint16_t* h_out);
+/* the same image (bit-identical: round to nearest even) from an fp32 weight [N][Cin][taps] already on the device */
+int es_pack_conv_f16_dev(const float* d_w, int N, int Cin, int taps, uint16_t* d_out, es_stream stream);
 int es_pack_conv_rows_f16(const float* h_w, int N, int Cin, int taps, uint16_t* h_out);
 
 typedef struct es_gn_args {

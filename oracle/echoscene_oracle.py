@@ -85,7 +85,23 @@ def mlp(sd, p, x, final_nonlinearity=True):
 # --------------------------------------------------------------------------------------
 # a1/a2  GraphTripleConv / GraphTripleConvNet  (model/graph.py:124-211, 246-250)
 # --------------------------------------------------------------------------------------
-def graph_triple_conv(sd, p, obj, pred, edges):
+def weight_net_gcn(sd, q, s, p, o):
+    """WeightNetGCN.forward (model/graph.py:66-86): a weight in (0, 1) per triple for its subject and its object slot."""
+    s = _linear(sd, q + '.down_sample_obj', s)                        # :68
+    p = _linear(sd, q + '.down_sample_pred', p)                       # :69
+    o = _linear(sd, q + '.down_sample_obj', o)                        # :70
+    feat = torch.cat([s, o, p], 1)                                    # :73 / :76 / :79
+
+    def head(h):
+        return torch.sigmoid(_linear(sd, f'{q}.{h}.2', F.relu(_linear(sd, f'{q}.{h}.0', feat))))   # :43-48
+    if (q + '.Net_s.0.weight') in sd:                                 # separate_s_o=True (the constructor's default)
+        return head('Net_s'), head('Net_o')
+    w = head('Net')
+    return w, w
+
+
+def graph_triple_conv(sd, p, obj, pred, edges, pooling='avg'):
+    assert pooling in ('sum', 'avg', 'wAvg')                          # graph.py:105
     O, T = obj.shape[0], pred.shape[0]
     H = sd[p + '.net2.0.weight'].shape[1]
     Dp = pred.shape[1]
@@ -94,12 +110,21 @@ def graph_triple_conv(sd, p, obj, pred, edges):
     t_out = mlp(sd, p + '.net1', t_in)                                # :152
     new_s, new_p, new_o = t_out[:, :H], t_out[:, H:H + Dp], t_out[:, H + Dp:]   # :156-158
     pooled = torch.zeros(O, H, dtype=obj.dtype)
+    if pooling == 'wAvg':                                                       # :163-170
+        w_s, w_o = weight_net_gcn(sd, p + '.weightNet', new_s, new_p, new_o)
+        new_s = w_s * new_s
+        new_o = w_o * new_o
     pooled = pooled.scatter_add(0, s_idx.view(-1, 1).expand_as(new_s), new_s)   # :176
     pooled = pooled.scatter_add(0, o_idx.view(-1, 1).expand_as(new_o), new_o)   # :177
-    counts = torch.zeros(O, dtype=obj.dtype)
-    ones = torch.ones(T, dtype=obj.dtype)
-    counts = counts.scatter_add(0, s_idx, ones).scatter_add(0, o_idx, ones)     # :189-192
-    pooled = pooled / counts.clamp(min=1).view(-1, 1)                           # :198-199
+    if pooling == 'wAvg':                                                       # :179-184
+        wsum = torch.zeros(O, 1, dtype=obj.dtype)
+        wsum = wsum.scatter_add(0, o_idx.view(-1, 1), w_o).scatter_add(0, s_idx.view(-1, 1), w_s)
+        pooled = pooled / (wsum + 0.0001)
+    if pooling == 'avg':
+        counts = torch.zeros(O, dtype=obj.dtype)
+        ones = torch.ones(T, dtype=obj.dtype)
+        counts = counts.scatter_add(0, s_idx, ones).scatter_add(0, o_idx, ones)     # :189-192
+        pooled = pooled / counts.clamp(min=1).view(-1, 1)                           # :198-199
     new_obj = mlp(sd, p + '.net2', pooled)                                      # :203
     if (p + '.linear_projection.weight') in sd:                                # residual, :205-209
         new_obj = new_obj + _linear(sd, p + '.linear_projection', obj)
@@ -107,10 +132,10 @@ def graph_triple_conv(sd, p, obj, pred, edges):
     return new_obj, new_p
 
 
-def gcn_net(sd, p, obj, pred, edges):
+def gcn_net(sd, p, obj, pred, edges, pooling='avg'):
     n = 1 + max(int(k[len(p) + 8:].split('.')[0]) for k in sd if k.startswith(p + '.gconvs.'))
     for i in range(n):
-        obj, pred = graph_triple_conv(sd, f'{p}.gconvs.{i}', obj, pred, edges)
+        obj, pred = graph_triple_conv(sd, f'{p}.gconvs.{i}', obj, pred, edges, pooling)
     return obj, pred
 
 

@@ -931,7 +931,31 @@ def case_gcn_ragged():
              cfg=np.array([96, 32, 3, 64, 1, 1, 80]))
 
 
-CASES = dict(sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+def case_gcn_pooling():
+    """GraphTripleConvNet with the two poolings no shipped config selects (model/graph.py:105): 'sum' and the learned 'wAvg'
+    (WeightNetGCN, graph.py:37-86, 163-184 -- its down_sample_pred is built for output_dim inputs and fed predicate vectors, so
+    the net only runs when output_dim == input_dim_pred at every layer), on the 8-node synthetic graph and on the ragged graph
+    of case_gcn_ragged (a node without triples: 0 / (0 + 1e-4))."""
+    from model.graph import GraphTripleConvNet
+    tri = [[0, 1, 1], [0, 2, 2], [0, 3, 4], [0, 4, 5], [0, 5, 6], [2, 3, 0], [4, 1, 0], [1, 2, 2], [1, 5, 2], [6, 3, 6],
+           [5, 2, 4], [7, 1, 0], [0, 6, 7]]
+    _, tri8 = synth.synthetic_graph(8, seed=1)
+    graphs = dict(g8=tri8, ragged=torch.tensor(tri, dtype=torch.int64))
+    for pool, code, (din, dp, H, dout) in (('sum', 1, (96, 32, 64, 80)), ('wAvg', 2, (64, 64, 96, 64))):
+        net = GraphTripleConvNet(input_dim_obj=din, input_dim_pred=dp, num_layers=3, hidden_dim=H,
+                                 residual=True, pooling=pool, mlp_normalization='batch', output_dim=dout)
+        fill(net, 'gcn_%s.' % pool)
+        for gname, triples in graphs.items():
+            obj = rnd((8, din), 31)
+            pred = rnd((triples.shape[0], dp), 32)
+            edges = torch.stack([triples[:, 0], triples[:, 2]], 1)
+            with torch.no_grad():
+                o, p = net(obj, pred, edges)
+            save('gcn_%s_%s' % (pool.lower(), gname), obj=obj, pred=pred, triples=triples, out_obj=o, out_pred=p,
+                 cfg=np.array([din, dp, 3, H, 1, 1, dout, code]))
+
+
+CASES = dict(gcn_pooling=case_gcn_pooling, sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

@@ -43,7 +43,7 @@ def _run_linear(dev, segs_cpu, W, b, M, prologue=0, gamma=None, beta=None, eps=0
         v = View(t, col=s.get('col', 0), ld=s.get('ld', None), width=s['width'])
         mk = lambda a: None if a is None else bld.dev(a, torch.int32)
         segs.append(seg(v, s.get('mode', 0), idx=mk(s.get('idx')), ent_row=mk(s.get('ent_row')),
-                        ent_off=mk(s.get('ent_off'))))
+                        ent_off=mk(s.get('ent_off')), ent_wt=None if s.get('ent_wt') is None else View(bld.dev(s['ent_wt']))))
     out = bld.buf(M, pl.N, zero=True)
     g = None if gamma is None else bld.dev(gamma)
     be = None if beta is None else bld.dev(beta)
@@ -132,6 +132,18 @@ def test_linear_gather_and_csr_mean(dev):
     _close(out, F.linear(pooled * cnt[:, None], W2), 2e-5)
 
 
+@pytest.mark.parametrize('N,K,geglu', [(512, 512, False), (8, 512, False), (2, 128, False), (100, 72, False), (4096, 512, True), (48, 40, True)])
+def test_weight_relayout_on_the_device_equals_the_host_loop(dev, N, K, geglu):
+    """es_pack_linear_f32_dev (what the planner uses) against es_pack_linear_f32 / es_pack_linear_geglu_f32: identical images."""
+    from echoscene_amd.plan import PackedLinear
+    rs = np.random.RandomState(N + K)
+    W = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(N).astype(np.float32))
+    d, h = PackedLinear(W, b, dev, geglu=geglu), PackedLinear(W, b, 'cpu', geglu=geglu)
+    torch.cuda.synchronize()
+    assert d.w.is_cuda and torch.equal(d.w.cpu(), h.w) and torch.equal(d.b.cpu(), h.b)
+
+
 def test_bad_args_raise(dev):
     from echoscene_amd import hip
     X = torch.zeros(4, 6)
@@ -153,6 +165,49 @@ def test_gcn_vs_reference_golden(dev, tag):
     o, p = gcn_forward(sd, 'n', g['obj'], g['pred'], g['triples'], dev)
     _close(o, g['out_obj'], 3e-5)
     _close(p, g['out_pred'], 3e-5)
+
+
+@pytest.mark.parametrize('tag', ['sum_g8', 'sum_ragged', 'wavg_g8', 'wavg_ragged'])
+def test_gcn_other_poolings_vs_reference_golden(dev, tag):
+    """pooling='sum' and pooling='wAvg' (the learned weights of WeightNetGCN, model/graph.py:37-86, 163-184: SEG_CSRWAVG +
+    ACT_SIGMOID) against the reference's GraphTripleConvNet."""
+    from echoscene_amd.model.graph import GraphTripleConvNet
+    from echoscene_amd.samplers import gcn_forward
+    g = load_golden('gcn_' + tag)
+    din, dp, nl, H, res, bn, dout, code = [int(v) for v in g['cfg']]
+    pool = ('avg', 'sum', 'wAvg')[code]
+    net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res), pooling=pool,
+                             mlp_normalization='batch' if bn else 'none', output_dim=dout)
+    sd = {'n.' + k: v for k, v in seeded_state_dict(net, 'gcn_%s.' % pool).items()}
+    o, p = gcn_forward(sd, 'n', g['obj'], g['pred'], g['triples'], dev, pooling=pool)
+    _close(o, g['out_obj'], 3e-5)
+    _close(p, g['out_pred'], 3e-5)
+
+
+def test_csr_weighted_mean(dev):
+    """SEG_CSRWAVG alone: sum_e w_e v_e / (sum_e w_e + 1e-4) with the reference's rounding points (the product w * v is rounded,
+    then summed in scatter_add order; the weights are summed object slots first), model/graph.py:169-184."""
+    from echoscene_amd import hip
+    rs = np.random.RandomState(9)
+    O, T, Dp, H = 7, 23, 8, 32
+    s = torch.from_numpy(rs.randint(0, O - 1, T)).long()          # node O-1 appears in no triple
+    o = torch.from_numpy(rs.randint(0, O - 1, T)).long()
+    msg = torch.from_numpy(rs.standard_normal((T, 2 * H + Dp)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(0.05, 0.95, (T, 2)).astype(np.float32))
+    pooled = torch.zeros(O, H).index_add_(0, s, w[:, :1] * msg[:, :H]).index_add_(0, o, w[:, 1:] * msg[:, H + Dp:])
+    wsum = torch.zeros(O, 1).index_add_(0, o, w[:, 1:]).index_add_(0, s, w[:, :1])
+    pooled = pooled / (wsum + 0.0001)
+    rows, offs, ptr = [], [], [0]
+    for n in range(O):
+        ts, to = (s == n).nonzero().flatten().tolist(), (o == n).nonzero().flatten().tolist()
+        rows += ts + to
+        offs += [0] * len(ts) + [H + Dp] * len(to)
+        ptr.append(len(rows))
+    W2 = torch.eye(H)                                             # the product with the identity is exact: the pooled rows themselves
+    out = _run_linear(dev, [dict(src=msg, width=H, ld=2 * H + Dp, mode=hip.SEG_CSRWAVG, idx=torch.tensor(ptr),
+                                 ent_row=torch.tensor(rows), ent_off=torch.tensor(offs), ent_wt=w)], W2, None, O)
+    assert torch.equal(out.cpu(), pooled), (out.cpu() - pooled).abs().max()
+    assert out[O - 1].abs().max() == 0
 
 
 def _layout(dev, mc, ctx, prefix, time_num, t_emb=True):

@@ -45,6 +45,21 @@ def _ncdhw(y, O, D, H, W):
     return y.reshape(O, D, H, W, -1).permute(0, 4, 1, 2, 3).contiguous()
 
 
+@pytest.mark.parametrize('N,cin,taps,geglu', [(224, 224, 27, False), (672, 1344, 27, False), (3, 224, 27, False), (100, 40, 1, False),
+                                              (448, 5, 27, False), (3584, 448, 1, True)])
+def test_conv_weight_relayout_on_the_device_equals_the_host_loop(dev, N, cin, taps, geglu):
+    """es_pack_conv_f16_dev (what the planner uses) against es_pack_conv_f16: the same tiled, swizzled fp16 image bit for bit
+    (padding rows / channels zero, round to nearest even)."""
+    from echoscene_amd.plan_vol import PackedConv
+    rs = np.random.RandomState(N + cin)
+    shape = (N, cin) if taps == 1 else (N, cin, 3, 3, 3)
+    W = torch.from_numpy((rs.standard_normal(shape) * rs.choice([1e-6, 1e-3, 1.0, 300.0], shape)).astype(np.float32))   # subnormals .. near overflow
+    b = torch.from_numpy(rs.standard_normal(N).astype(np.float32))
+    d, h = PackedConv(W, b, dev, geglu=geglu), PackedConv(W, b, 'cpu', geglu=geglu)
+    torch.cuda.synchronize()
+    assert d.w.is_cuda and d.geglu == h.geglu and torch.equal(d.w.cpu(), h.w) and torch.equal(d.b.cpu(), h.b)
+
+
 @pytest.mark.parametrize('O,Cin,N,dims,bias', [(3, 224, 3, (16, 16, 16), True), (2, 96, 5, (4, 8, 16), False), (1, 128, 16, (8, 4, 32), True)])
 def test_output_conv_narrow_n_kernel(dev, O, Cin, N, dims, bias):
     """The UNet's output conv (out.2: 3x3x3, 224 -> 3, NCDHW fp32; openai_model_3d.py:735-739) on k_conv_n16 (a halo'd LDS image per

@@ -40,6 +40,30 @@ def test_gcn(tag):
     _close(p, g['out_pred'], 1e-5)
 
 
+@pytest.mark.parametrize('tag', ['sum_g8', 'sum_ragged', 'wavg_g8', 'wavg_ragged'])
+def test_gcn_other_poolings(tag):
+    """pooling='sum' and the learned pooling='wAvg' (WeightNetGCN, model/graph.py:37-86, 163-184) against the reference's own
+    GraphTripleConvNet; 'ragged' holds a node without triples (wAvg: 0 / (0 + 1e-4))."""
+    g = load_golden('gcn_' + tag)
+    din, dp, nl, H, res, bn, dout, code = [int(v) for v in g['cfg']]
+    pool = ('avg', 'sum', 'wAvg')[code]
+    net = GraphTripleConvNet(din, dp, num_layers=nl, hidden_dim=H, residual=bool(res), pooling=pool,
+                             mlp_normalization='batch' if bn else 'none', output_dim=dout)
+    sd = seeded_state_dict(net, 'gcn_%s.' % pool)
+    if pool == 'wAvg':
+        assert 'gconvs.0.weightNet.Net_s.0.weight' in sd and 'gconvs.2.weightNet.down_sample_pred.bias' in sd
+    tri = g['triples']
+    edges = torch.stack([tri[:, 0], tri[:, 2]], 1)
+    o, p = orc.gcn_net({'n.' + k: v for k, v in sd.items()}, 'n', g['obj'], g['pred'], edges, pooling=pool)
+    _close(o, g['out_obj'], 1e-5)
+    _close(p, g['out_pred'], 1e-5)
+
+
+def test_gcn_pooling_argument_is_checked():
+    with pytest.raises(ValueError):
+        GraphTripleConvNet(8, 8, pooling='max')
+
+
 def _unet1d_sd(mc, ctx, prefix, t_emb=True):
     kw = dict(escfg.layout_denoiser_kwargs(mc))
     kw['concat_dim'] = kw['crossattn_dim'] = ctx
