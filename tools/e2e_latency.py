@@ -12,6 +12,7 @@ from model.SGDiff import SGDiff
 ap = argparse.ArgumentParser()
 ap.add_argument('--nodes', type=int, default=32)
 ap.add_argument('--concat', action='store_true')
+ap.add_argument('--profile-first', action='store_true', help='cProfile of the first call (weight re-layouts, plan build, graph capture): top functions')
 a = ap.parse_args()
 opt = escfg.default_diff_opt('cuda', concat=a.concat)
 m = SGDiff('echoscene', opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True, gconv_pooling='avg',
@@ -28,10 +29,19 @@ tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
 args = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
 for i in range(3):
     torch.cuda.synchronize()
+    prof = None
+    if a.profile_first and i == 0:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     d = m.sample_box_and_shape(*args, gen_shape=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats('tottime').print_stats(18)
     print('call %d: %.3f s  (shapes %s, finite %s)' % (i, dt, tuple(d['shapes'].shape), bool(torch.isfinite(d['shapes']).all())), flush=True)
 
 # ---- breakdown (each part synchronised) ----
