@@ -50,6 +50,27 @@ inline void es_parallel_for(long n, F f) {
         }                                                                                    \
     } while (0)
 
+// x combined with the value of lane ^ 16 / lane ^ 32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap (gfx950) exchange
+// the odd 16- / 32-lane rows of one operand with the even rows of the other, so both results hold, in EVERY lane, the even-row and the
+// odd-row value of its pair (two VALU instructions instead of a ds_bpermute round trip in a dependent chain).
+typedef unsigned es_u2 __attribute__((ext_vector_type(2)));
+// (both results pass through an empty asm: hipcc 7.2 folds `f(r[0], r[1])` of this intrinsic to `f(r[0], r[0])` at -O3 -- the IR keeps
+//  only extractvalue 0 and the reduction silently loses the odd rows; tools/probes/probe_permlane_swap.hip holds the semantics)
+__device__ __forceinline__ void es_pair16(float x, float& even, float& odd) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const es_u2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    unsigned e = r[0], o = r[1];
+    asm volatile("" : "+v"(e), "+v"(o));
+    even = __builtin_bit_cast(float, e); odd = __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ void es_pair32(float x, float& even, float& odd) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const es_u2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    unsigned e = r[0], o = r[1];
+    asm volatile("" : "+v"(e), "+v"(o));
+    even = __builtin_bit_cast(float, e); odd = __builtin_bit_cast(float, o);
+}
+
 // x * sigmoid(x) with the hardware exp2 / rcp (relative error ~1e-6, far inside the 1e-4 parity budget)
 __device__ __forceinline__ float es_silu(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float es_silu_fast(float x) { return x / (1.0f + __expf(-x)); } // volume path (fp16 operands follow)

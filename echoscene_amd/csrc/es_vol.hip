@@ -1551,19 +1551,27 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
     constexpr int NT = 64 * NWV, CPR = DP / 4, NITEM = AT_K * CPR, NIT = (NITEM + NT - 1) / NT;
     constexpr bool PREFETCH = DP <= 96;                      // (DP = 256, the VQ-VAE block: 16 items per thread would not fit; load in place)
     h4 kreg[NIT], vreg[NIT];
+    // Buffer loads whose descriptor ends behind the last key row: an item past Ntok, past the head's channels or past the tile returns
+    // zeros by the range check -- no compare / select per item and tile (they were ~75 of the ~330 instructions of a K tile).
+    unsigned kvoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        const int key = idx / CPR, d = (idx - key * CPR) * 4;
+        kvoff[it] = (idx < NITEM && d < a.dhead) ? (unsigned)(key * ldq + d) * 2u : 0x80000000u;
+    }
+    const int nrec = (int)(((long)(a.Ntok - 1) * ldq + a.dhead) * 2);
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(base + C), (short)0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(base + 2 * C), (short)0, nrec, 0x00020000);
     auto gload = [&](int k0) __attribute__((always_inline)) {
+        const unsigned koff = (unsigned)k0 * (unsigned)ldq * 2u;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NT;
-            const int key = idx / CPR, d = (idx - key * CPR) * 4;
-            kreg[it] = h4{0, 0, 0, 0}; vreg[it] = h4{0, 0, 0, 0};
-            if (idx < NITEM && d < a.dhead && k0 + key < a.Ntok) {
-                const _Float16* p = base + (long)(k0 + key) * ldq + d;
-                kreg[it] = *(const h4*)(p + C);
-                vreg[it] = *(const h4*)(p + 2 * C);
-            }
+            kreg[it] = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rK, (int)(kvoff[it] + koff), 0, 0));
+            vreg[it] = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rV, (int)(kvoff[it] + koff), 0, 0));
         }
     };
+    // (a second K / V buffer with ONE barrier per tile was measured in round 4: 115 us against 113 at 1024 tokens -- no gain, not kept)
     if (PREFETCH) gload(0);
     for (int k0 = 0; k0 < a.Ntok; k0 += AT_K) {
         __syncthreads();                                      // the previous tile's fragment reads are done
@@ -1609,19 +1617,34 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
         h8 pf[NRT][2];
         typedef float f2 __attribute__((ext_vector_type(2)));
         const float c2 = a.scale * 1.44269504088896340736f;
-        const bool ragged = k0 + AT_K > a.Ntok;              // wave-uniform
+        // (the mask of the keys past Ntok sits behind a real branch: written as `if (ragged && key >= Ntok)` inside the loops below it
+        //  was if-converted into 16 compares + 16 selects per row tile in EVERY K tile -- a third of the instructions of this phase,
+        //  for a case only the last tile of a ragged sequence can meet)
+        if (k0 + AT_K > a.Ntok) {                            // wave-uniform
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = k0 + t * 16 + q4 * 4 + r >= a.Ntok ? -INFINITY : s[rt][t][r];
+                        asm volatile("" : "+v"(v));           // (not speculatable: keeps the selects inside the branch)
+                        s[rt][t][r] = v;
+                    }
+        }
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ragged && k0 + t * 16 + q4 * 4 + r >= a.Ntok) s[rt][t][r] = -INFINITY;
-                    mx = fmaxf(mx, s[rt][t][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[rt][t][r]);
+            {                                                // over the four 16-lane rows (lane ^ 16, lane ^ 32), no LDS round trip
+                float e, o;
+                es_pair16(mx, e, o); mx = fmaxf(e, o);
+                es_pair32(mx, e, o); mx = fmaxf(e, o);
+            }
             const float mnew = fmaxf(mrow[rt], mx * c2);     // running maximum, exp2 domain
             const float alpha = __builtin_amdgcn_exp2f(mrow[rt] - mnew);
             const f2 c22 = {c2, c2}, nm2 = {-mnew, -mnew};
@@ -1638,8 +1661,11 @@ __global__ __launch_bounds__(64 * NWV, MINW) void k_attention(const es_attn_args
                     pf[rt][t >> 1][(t & 1) * 4 + 2 * hf + 1] = (_Float16)pp[1];
                 }
             float ps = ps2[0] + ps2[1];
-            ps += __shfl_xor(ps, 16);
-            ps += __shfl_xor(ps, 32);
+            {
+                float e, o;
+                es_pair16(ps, e, o); ps = e + o;
+                es_pair32(ps, e, o); ps = e + o;
+            }
             lrow[rt] = lrow[rt] * alpha + ps;
             mrow[rt] = mnew;
             if (__ballot(alpha != 1.0f) != 0) {              // some row's maximum moved: rescale O (wave-uniform branch)
