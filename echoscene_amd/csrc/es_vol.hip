@@ -494,11 +494,17 @@ __device__ __forceinline__ void conv_epilogue(const es_conv_args& a, const ConvG
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const float s0 = lo ? acc[i][j][2] : acc[i][j][0], s1 = lo ? acc[i][j][3] : acc[i][j][1];
-                const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0x128, 0xf, 0xf, false));   // row_ror:8
-                const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x128, 0xf, 0xf, false));
-                const float v0 = lo ? acc[i][j][0] : r0, g0 = lo ? r0 : acc[i][j][2];
-                const float v1 = lo ? acc[i][j][1] : r1, g1 = lo ? r1 : acc[i][j][3];
+                // row_ror:8 with a BANK mask: the rotation is written only into lanes 0-7 (banks 0, 1) resp. 8-15 (banks 2, 3) of a row, the
+                // other half keeps `old` -- the exchange and the selection in one instruction per operand (the first version selected
+                // with six v_cndmask per pair around two unmasked rotations).  Low lanes (value columns) take the gates of their rows
+                // 0, 1 from the partner and keep their values; high lanes (gate columns) take the values of rows 2, 3 and keep their gates.
+                auto dpp8 = [](float old, float src, int bank_mask_lo) __attribute__((always_inline)) {
+                    return bank_mask_lo
+                        ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0x3, false))
+                        : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0xc, false));
+                };
+                const float g0 = dpp8(acc[i][j][2], acc[i][j][0], 1), g1 = dpp8(acc[i][j][3], acc[i][j][1], 1);
+                const float v0 = dpp8(acc[i][j][0], acc[i][j][2], 0), v1 = dpp8(acc[i][j][1], acc[i][j][3], 0);
                 const es_f2 ge = es_gelu_fast2(es_f2{g0, g1});      // (packed fp32 polynomial: two evaluations per issue slot)
                 hslab[rr * HLD + j * 8 + cw] = (_Float16)(v0 * ge[0]);
                 hslab[(rr + 1) * HLD + j * 8 + cw] = (_Float16)(v1 * ge[1]);
