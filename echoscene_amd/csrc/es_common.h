@@ -72,8 +72,10 @@ __device__ __forceinline__ void es_pair32(float x, float& even, float& odd) {
 }
 
 // x * sigmoid(x) with the hardware exp2 / rcp (relative error ~1e-6, far inside the 1e-4 parity budget)
-__device__ __forceinline__ float es_silu(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float es_silu_fast(float x) { return x / (1.0f + __expf(-x)); } // volume path (fp16 operands follow)
+// (v_rcp_f32, 1 ulp: `__frcp_rn` and `/` are the correctly rounded quotient -- v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup,
+//  ten instructions per evaluation in the staging prologue of every GroupNorm + SiLU launch of the latency-bound layout chain)
+__device__ __forceinline__ float es_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float es_silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); } // volume path (fp16 operands follow)
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float es_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for the volume path (the result is rounded to fp16 right after): erfc(|x|/sqrt 2) by Abramowitz & Stegun 7.1.26

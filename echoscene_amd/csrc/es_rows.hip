@@ -205,13 +205,13 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
                             //  duplicates too, because w4 is a multiple of lpg -- no foreign value enters a real group)
                             float sm = (y[0] + y[1]) + (y[2] + y[3]);
                             for (int o = 1; o < lpg; o <<= 1) sm += __shfl_xor(sm, o, LPR);
-                            const float inv_gs = 1.0f / (float)sg.gs;          // gs is a power of two: the multiplies below are exact divisions
+                            const float inv_gs = __builtin_amdgcn_rcpf((float)sg.gs);   // gs is a power of two: v_rcp is exact there, the multiplies below are exact divisions
                             const float mean = sm * inv_gs;
                             float sq = 0.f;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { const float d = y[q] - mean; sq += d * d; }
                             for (int o = 1; o < lpg; o <<= 1) sq += __shfl_xor(sq, o, LPR);
-                            const float rstd = 1.0f / sqrtf(sq * inv_gs + sg.eps);
+                            const float rstd = __builtin_amdgcn_rsqf(sq * inv_gs + sg.eps);      // v_rsq_f32 (1 ulp) instead of sqrt + quotient (~25 instructions)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float z = (y[q] - mean) * rstd * gav[PROC >= 1 ? u : 0][q] + bev[PROC >= 1 ? u : 0][q];
@@ -272,7 +272,7 @@ __device__ __forceinline__ void stage_ln(const es_linear_args& a, float* x, int 
     }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, LPR);
-    const float rstd = 1.0f / sqrtf(q / (float)K + sg.eps);
+    const float rstd = __builtin_amdgcn_rsqf(q / (float)K + sg.eps);
 #pragma unroll
     for (int u = 0; u < LNU; ++u) {
         const int c = 4 * (cl + LPR * u);

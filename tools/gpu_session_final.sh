@@ -14,6 +14,6 @@ timeout 300 python tools/aux_launch_table.py > $OUT/aux_table.txt 2>&1
 bash tools/gpu_session_profile.sh ${1:-final}
 timeout 600 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
 timeout 600 python tools/emulate_shards.py --steps 20 --tuned 2>&1 | grep "^world" > $OUT/shards_tuned.txt
-ES_CONV_DEEP=0 timeout 600 python tools/emulate_shards.py --steps 20 --tuned --worlds 1,4,8 2>&1 | grep "^world" > $OUT/shards_tuned_nodeep.txt
+
 timeout 300 python tools/model_file_size.py > $OUT/model_file_size.txt 2>&1
-cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; grep -v amdgpu $OUT/scene_sizes.txt; cat $OUT/shards_default.txt $OUT/shards_tuned.txt $OUT/shards_tuned_nodeep.txt; grep -v amdgpu $OUT/model_file_size.txt; du -sh $OUT
+cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; grep -v amdgpu $OUT/scene_sizes.txt; cat $OUT/shards_default.txt $OUT/shards_tuned.txt; grep -v amdgpu $OUT/model_file_size.txt; du -sh $OUT
