@@ -79,19 +79,20 @@ __device__ __forceinline__ float es_silu_fast(float x) { return x * __builtin_am
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float es_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for the volume path (the result is rounded to fp16 right after): erfc(|x|/sqrt 2) by Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7), evaluated on the side where it does not cancel: gelu(x) = x < 0 ? x E / 2 : x - x E / 2.  Max abs error
-// 2.2e-7 over [-12, 12] (tests/test_hip_vol.py); ~14 VALU ops instead of erff's ~40 with divergent branches -- the exact
+// (|error| <= 1.5e-7), evaluated on the side where it does not cancel: gelu(x) = max(x, 0) - (|x| / 2) E(|x| / sqrt 2).  Max abs error
+// 2.2e-7 over [-12, 12] (tests/test_hip_vol.py); ~12 VALU ops instead of erff's ~40 with divergent branches -- the exact
 // version cost ~9 us of the ~27 us a 256 x 224 FeedForward tile took (56 evaluations per lane).
 __device__ __forceinline__ float es_gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
+    // gelu(x) = max(x, 0) - (|x| / 2) E(|x| / sqrt 2): one expression for both signs (E = erfc of the A&S form, never cancelling)
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, z, 1.0f));     // v_rcp_f32 (1 ulp), see es_gelu_fast2
     float pl = __fmaf_rn(t, 1.061405429f, -1.453152027f);
     pl = __fmaf_rn(t, pl, 1.421413741f);
     pl = __fmaf_rn(t, pl, -0.284496736f);
     pl = __fmaf_rn(t, pl, 0.254829592f);
-    const float E = pl * t * __expf(-z * z);
-    const float h = 0.5f * x * E;
-    return x < 0.f ? h : x - h;
+    const float E = pl * t * __builtin_amdgcn_exp2f(ax * ax * -0.72134752044448170368f);    // exp(-z^2) = 2^(-x^2 log2(e) / 2)
+    return __fmaf_rn(-0.5f * ax, E, fmaxf(x, 0.f));
 }
 
 // Two evaluations of es_gelu_fast at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: one issue slot for two lanes' worth of
@@ -111,11 +112,11 @@ __device__ __forceinline__ es_f2 es_gelu_fast2(es_f2 x) {
     pl = __builtin_elementwise_fma(t, pl, es_f2{1.421413741f, 1.421413741f});
     pl = __builtin_elementwise_fma(t, pl, es_f2{-0.284496736f, -0.284496736f});
     pl = __builtin_elementwise_fma(t, pl, es_f2{0.254829592f, 0.254829592f});
-    const es_f2 mz2 = -z * z;
-    const es_f2 ex = {__expf(mz2[0]), __expf(mz2[1])};
+    const es_f2 w = ax * ax * -0.72134752044448170368f;                 // exp(-z^2) = 2^(-x^2 log2(e) / 2): no separate log2(e) multiply
+    const es_f2 ex = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
     const es_f2 E = pl * t * ex;
-    const es_f2 h = (x * 0.5f) * E;
-    return es_f2{x[0] < 0.f ? h[0] : x[0] - h[0], x[1] < 0.f ? h[1] : x[1] - h[1]};
+    // max(x, 0) - (|x| / 2) E: one expression for both signs instead of compare / subtract / select
+    return __builtin_elementwise_fma(ax * -0.5f, E, es_f2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
 }
 
 // Kernel arguments are read with scalar loads as the code reaches each field: several s_load -> s_waitcnt -> branch steps in a row
