@@ -94,12 +94,15 @@ __device__ __forceinline__ f4 sum_slabs(const f4 (&t)[NS], int nslab) {
 // PROC: prologue class compiled in -- 0: none (raw / ReLU'd operands), 1: + GroupNorm(+SiLU) segments, 2: + SiLU / GEGLU
 // (tables, tests).  CSR: the segmented-mean gather is compiled in.  A launch costs ~4 us of which ~1 us was instruction fetch
 // when every path lived in one 31 KB kernel (each launch starts with a cold instruction cache): one lean kernel per class.
-template <int NS, int PROC, bool CSR>
+// U1: ONE pass per batch (UB = 1) -- the variant for launches of MORE than one round of workgroups (a rider on a GCN launch: 352
+// workgroups): 87-120 VGPRs instead of 106-194, i.e. two workgroups per CU instead of one, at the price of one load batch per
+// 128 columns of a slice (the riders' slices ARE 128 columns).  Same loads, same arithmetic, same order: the same bits.
+template <int NS, int PROC, bool CSR, bool U1 = false>
 __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, int ldx, int m0, int c0, int kc, int tid) {
     // passes (32 lanes x float4 = 128 columns of a row) per batch: up to 16 float4 loads in flight per thread.  A pass that lies
     // wholly past the region is skipped (wave-uniform): in the 4-wave version with 32-load batches the clamped duplicates of a 64-column
     // slice cost +1.9 us per launch -- at one wave per SIMD nothing hides the dependent VALU chain of the prologue.
-    constexpr int UB = NS >= 8 ? 2 : 4;
+    constexpr int UB = U1 ? 1 : NS >= 8 ? 2 : 4;
     const int r = tid >> 5, cl = tid & (LPR - 1);
     const int m = m0 + r;
     const bool row_ok = m < a.M;
@@ -291,16 +294,19 @@ __device__ __forceinline__ void stage_ln(const es_linear_args& a, float* x, int 
 // grid.x = column tiles x K slices (slice fastest: with the observed block -> XCD b % 8 placement the column tiles of one
 // slice share an XCD, i.e. one L2 copy of that slice of A -- speed only), grid.y = row tiles, grid.z = batch.
 // One launch = up to 3 INDEPENDENT problems (es_linear_rows_multi_f32): problem i owns the blockIdx.x range [wg0[i], wg0[i+1]) and
-// the first ny[i] row tiles.
+// the first ny[i] row tiles.  A problem with FEWER row tiles than the launch (a node-row product riding on a triple-row launch:
+// 2 row tiles against 8) is FOLDED: its xw[i] x ny[i] tiles are laid row-major over fw[i] columns of ALL gridDim.y rows, so that
+// the launch carries no workgroups that exit at entry (768 of 1024 for a 512-column product on an 8-row launch).
 struct RowsLaunch {
     es_linear_args p[3];
     int S[3], kbps[3], wg0[3], ny[3];
+    int xw[3], fw[3];            // tiles per row of the problem (column tiles x slices); folded width (0 = not folded)
     int n, ldx, dbg;
 };
 
 // NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
 // unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
-template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI>
+template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI, bool U1 = false>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     kernarg_warm<sizeof(RowsLaunch)>();
@@ -310,12 +316,17 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     if (dbg & 4) return;                                 // (calibration of the launch floor, tools/microbench_rows.py)
     const int pi = (L.n > 1 && (int)blockIdx.x >= L.wg0[1] ? 1 : 0) + (L.n > 2 && (int)blockIdx.x >= L.wg0[2] ? 1 : 0);
     const es_linear_args& a = L.p[pi];
-    if ((int)blockIdx.y >= L.ny[pi]) return;
+    int bx = (int)blockIdx.x - L.wg0[pi], by = (int)blockIdx.y;
+    if (L.fw[pi] > 0) {                                  // folded problem: tile v of xw x ny, row-major over fw columns x gridDim.y rows
+        const int v = by * L.fw[pi] + bx, xw = L.xw[pi];
+        if (v >= xw * L.ny[pi]) return;
+        by = v / xw;
+        bx = v - by * xw;
+    } else if (by >= L.ny[pi]) return;
     const int S = L.S[pi], kbps = L.kbps[pi];
-    const int bx = (int)blockIdx.x - L.wg0[pi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = bx % S, nt = bx / S;
-    const int m0 = blockIdx.y * MT;
+    const int m0 = by * MT;
     const int nkb_total = (a.K + 15) >> 4;
     const int kb0 = slice * kbps, kb1 = slice == S - 1 ? nkb_total : kb0 + kbps;
     const int bz = blockIdx.z;                           // batched launch: z-th problem of identical shape
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
         if (c0 > kb0 * 16) __syncthreads();
         if (dbg & 2) { }
         else if (LNU > 0) stage_ln<NS, (LNU > 0 ? LNU : 1)>(a, x, ldx, m0, c0, kc, tid);
-        else stage_chunk<NS, PROC, CSR>(a, x, ldx, m0, c0, kc, tid);
+        else stage_chunk<NS, PROC, CSR, U1>(a, x, ldx, m0, c0, kc, tid);
         __syncthreads();
         // (3) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block
 #pragma unroll
@@ -659,14 +670,20 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
 int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     RowsLaunch L;
     memset(&L, 0, sizeof(L));
-    int nsmax = 1, proc = 0, kcmax = 16, gx = 0, gy = 1;
+    int nsmax = 1, proc = 0, kcmax = 16, gx = 0, gy = 1, wg_real = 0;
     bool csr = false, has_ln = false, gepi = false;
+    for (int i = 0; i < n; ++i) {
+        const int ny = (pr[i].a.M + MT - 1) / MT;
+        gy = ny > gy ? ny : gy;
+    }
     for (int i = 0; i < n; ++i) {
         L.p[i] = pr[i].a; L.S[i] = pr[i].S; L.kbps[i] = pr[i].kbps;
         L.wg0[i] = gx;
         L.ny[i] = (pr[i].a.M + MT - 1) / MT;
-        gx += ((pr[i].a.N + 15) / 16) * pr[i].S;
-        gy = L.ny[i] > gy ? L.ny[i] : gy;
+        L.xw[i] = ((pr[i].a.N + 15) / 16) * pr[i].S;
+        L.fw[i] = (n > 1 && L.ny[i] < gy) ? (L.xw[i] * L.ny[i] + gy - 1) / gy : 0;      // fewer row tiles than the launch: folded
+        gx += L.fw[i] > 0 ? L.fw[i] : L.xw[i];
+        wg_real += L.xw[i] * L.ny[i];
         nsmax = pr[i].nsmax > nsmax ? pr[i].nsmax : nsmax;
         proc = pr[i].proc > proc ? pr[i].proc : proc;
         csr = csr || pr[i].csr; has_ln = has_ln || pr[i].has_ln; gepi = gepi || pr[i].gepi;
@@ -692,11 +709,22 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
         {(const void*)k_linear_rows<1, 0, false, 4, true>, (const void*)k_linear_rows<2, 0, false, 4, true>},
         {(const void*)k_linear_rows<1, 0, false, 8, true>, (const void*)k_linear_rows<2, 0, false, 8, true>}};
     static const void* const k_csr = (const void*)k_linear_rows<1, 0, true, 0, false>;
+    // two-workgroups-per-CU variants (stage_chunk U1) of the plain family for launches of more than one round
+    static const void* const k_plain_u1[3][2] = {
+        {(const void*)k_linear_rows<1, 0, false, 0, false, true>, (const void*)k_linear_rows<1, 1, false, 0, false, true>},
+        {(const void*)k_linear_rows<2, 0, false, 0, false, true>, (const void*)k_linear_rows<2, 1, false, 0, false, true>},
+        {(const void*)k_linear_rows<4, 0, false, 0, false, true>, (const void*)k_linear_rows<4, 1, false, 0, false, true>}};
     const int nsi = nsmax <= 1 ? 0 : nsmax <= 2 ? 1 : nsmax <= 4 ? 2 : 3;
+    static const char* u1_env = getenv("ES_ROWS_U1");            // timing-only A/B switch: 0 = never, 2 = every fused plain launch
+    const int u1_mode = u1_env ? atoi(u1_env) : 1;
+    // default rule: a FUSED launch of more than 256 workgroups whose ordinary variant holds one workgroup per CU (GroupNorm
+    // prologue or 4-slab operands: 146-194 VGPRs): two per CU run 257-512 workgroups in ONE round instead of two
+    const bool one_per_cu = proc == 1 || nsi == 2;
+    const bool u1 = n > 1 && nsi <= 2 && (u1_mode == 2 || (u1_mode == 1 && one_per_cu && wg_real > 256));
     const void* fn = nullptr;
     if (has_ln) fn = k_ln[pr[0].a.K <= 512 ? 0 : 1][nsi];
     else if (csr && proc == 0 && nsmax == 1 && !gepi) fn = k_csr;
-    else if (!csr && proc <= 1 && !gepi) fn = k_plain[nsi][proc];
+    else if (!csr && proc <= 1 && !gepi) fn = u1 ? k_plain_u1[nsi][proc] : k_plain[nsi][proc];
     else fn = k_general[nsi];
     {   // one-off per process, thread-safe: dynamic LDS limit (a 1024-column chunk needs 73 KiB)
         static std::once_flag once;
@@ -708,6 +736,7 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
                 if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
             };
             for (int i = 0; i < 4; ++i) { set(k_plain[i][0]); set(k_plain[i][1]); set(k_general[i]); }
+            for (int i = 0; i < 3; ++i) { set(k_plain_u1[i][0]); set(k_plain_u1[i][1]); }
             for (int i = 0; i < 2; ++i) { set(k_ln[i][0]); set(k_ln[i][1]); }
             set(k_csr);
         });

@@ -24,6 +24,11 @@ ROWS_CAV_SLICES = 1      # cross-attention-vector product: 1 / 2 / 3 / 4 slices 
 ROWS_LN_SPLIT = 2        # slices of a product whose consumer is a LayerNorm (whole-row statistics): 1 -> 1067, 2 -> 1093
 ROWS_VO1_SLICES = 2      # attention-with-one-token product: 2 / 1 -> 1124 / 1122
 ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's launch: measured -1.1 %
+# The head of the UNet1D trunk (conv_in ... the first transformer's proj_in: 9 dependent products that do not need the GCN output)
+# rides on the launches of the GCN chain instead of following it: 9 launches off the critical path of a layout step.  Not a numerical
+# choice (every product keeps its own K slices: same bits), a planner switch for the A/B: 0 = off, 1 = conv_in on the box embedding's
+# launch + one product on net2's output launch of every GCN layer, 2 = also one on net1's second Linear (320 + 256 workgroups).
+ROWS_RIDE = int(os.environ.get('ES_ROWS_RIDE', '2'))
 
 
 class View:
@@ -243,6 +248,36 @@ class GraphIndex:
         return self._csr[key]
 
 
+class Rider:
+    """Hands out the ops of an op-emitting generator ONE at a time, so that a chain of products which does not depend on another
+    chain can ride on that chain's launches (``Builder.ride``: the runtime launches an op marked ``fuse_next`` and its successor
+    as one grid).  The generator yields None after every op it has emitted and the string 'CTX' -- having emitted nothing --
+    in front of the first op that needs the other chain's result; from then on nothing rides."""
+
+    def __init__(self, gen):
+        self.gen, self.blocked, self.done = gen, False, False
+
+    def step(self):
+        """emit ONE more op if it is independent of the host chain; True when an op was appended"""
+        if self.blocked or self.done:
+            return False
+        try:
+            r = next(self.gen)
+        except StopIteration:
+            self.done = True
+            return False
+        if r == 'CTX':
+            self.blocked = True
+            return False
+        return True
+
+    def finish(self):
+        """emit everything that is left"""
+        for _ in self.gen:
+            pass
+        self.done = True
+
+
 class Builder:
     """Accumulates ops + keeps every referenced device tensor alive."""
 
@@ -342,6 +377,28 @@ class Builder:
         self.weight_bytes += pl.weight_bytes
         self.flops += 2 * M * pl.K * pl.N * pl.nbatch
         return out
+
+    def ride(self, rider):
+        """The op emitted LAST (a rows product, or the last member of a fused group of two) takes the next independent op of
+        ``rider`` onto its launch: the rider's op is appended right behind it and the pair is marked for one grid.  Problems of one
+        launch must be independent -- the rider's chain only reads its own earlier ops and inputs of the step."""
+        if rider is None or self.use_lanes or not ROWS_RIDE:
+            return False
+        i = len(self.ops) - 1
+        host = self.ops[i]
+        if host.kind != hip.OP_LINEAR or host.u.linear.nbatch > 1 or host.u.linear.act == hip.ACT_GEGLU:
+            return False
+        n_group = 1
+        if i > 0 and self.ops[i - 1].kind == hip.OP_LINEAR and self.ops[i - 1].u.linear.fuse_next:
+            n_group = 2
+            if i > 1 and self.ops[i - 2].kind == hip.OP_LINEAR and self.ops[i - 2].u.linear.fuse_next:
+                return False                       # three problems already
+        if not rider.step():
+            return False
+        assert len(self.ops) == i + 2 and self.ops[i + 1].kind == hip.OP_LINEAR and not self.ops[i + 1].u.linear.fuse_next, \
+            'a rider step emits exactly one rows product'
+        self.ops[i].u.linear.fuse_next = 1
+        return n_group + 1
 
     def update(self, kind, x, eps, coef, step, noise=None, noise_stride=0, inc_step=True, clip_x0=False):
         """eps: tensor or (slab) View"""
@@ -573,9 +630,11 @@ class GCNWeights:
             raise KeyError('no GraphTripleConvNet under ' + prefix)
 
 
-def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
+def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False, rider=None):
     """obj: View [O, Dobj]; pred: View [T, Dp]; returns View of the last layer's object output
     (and the predicate output when ``want_pred`` -- the samplers never consume it).
+    ``rider`` (Rider): an independent chain of products that rides on this chain's launches -- one op on net1's second Linear
+    and one on net2's second Linear of every layer (the gather / segmented-mean launches keep their lean kernels).
     The two hidden products of a layer (net1's first Linear over the gathered triples, net2's first Linear over the pooled
     messages) split K over workgroups: their ReLU is applied by the consumer to the slab sum (``pre_act``)."""
     O, T = g.O, g.T
@@ -603,6 +662,8 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
             proj = None
         t2 = View(b.buf(T, W2))
         b.linear([seg(t1, pre_act=hip.ACT_RELU)], L['n1b'], T, t2, act=hip.ACT_RELU)
+        if ROWS_RIDE >= 2:
+            b.ride(rider)
         ptr, rows, offs = g.csr(0, H + Dp)
         pooling = getattr(gw, 'pooling', 'avg')
         wts = None
@@ -629,6 +690,7 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False):
         if proj is not None:
             b.join(2)
         b.linear([seg(n1, pre_act=hip.ACT_RELU)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
+        b.ride(rider)
         obj, Dobj = dst, Dout
         if not last or want_pred:
             pred = newp
@@ -785,18 +847,25 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     objbuf = b.buf(O, Dobj)
     oe_w = obj_embed_dev.shape[1]
     objbuf[:, :oe_w].copy_(obj_embed_dev)        # constant over the loop: written once at plan build
+    # The trunk below is emitted by a generator: its head (conv_in ... the first transformer's proj_in) needs x and the time
+    # tables only, not the GCN output, and rides on the launches of the GCN chain (Rider / Builder.ride) -- conv_in on the box
+    # embedding's launch (both read x_t), then one product per net1 / net2 output launch of the GCN layers.
+    box = {}
+    rider = Rider(_trunk(b, w, O, x, emb_all, emb_ld, box, eps_out))
     b.linear([seg(View(x))], w.box_emb, O, View(objbuf, col=oe_w, ld=Dobj, width=gdim))
+    b.ride(rider)
     if w.enable_t_emb:
         if tables is not None:
             b.rowsel(tables['t_lin'], step, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim), rows=O)
         else:
             b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
     pred = b.pred_rows = b.dev(w.pred_table[torch.from_numpy(g.p_host)])     # refreshed in place for a new graph
-    ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1])
+    ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1], rider=rider)
+    box['ctx'] = ctx
     b.tags.update(ctx=ctx, gcn_in=View(objbuf))
     if emb is not None:
         b.tags['emb'] = emb
-    cavo = {}
+    cavo = box['cavo'] = {}
     if not w.concat:
         # the cross-attention vectors of all transformer blocks: one product (folded to_out2 . to_v2 matrices)
         cs_ = ROWS_CAV_SLICES
@@ -810,7 +879,16 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
             cavo[name] = cavv.cols(coff, Cc)
             coff += Cc
     b.join(1)                                  # emb_all (side lane, forked after the time MLP)
+    rider.finish()                             # the rest of the trunk
+    return objbuf
 
+
+def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
+    """The UNet1D trunk (input / middle / output blocks and the output conv) as a GENERATOR of rows products for ``Rider``: it
+    yields None after every product it has emitted and 'CTX' -- without emitting -- in front of a product that needs the GCN
+    output: ``box['ctx']`` (concat conditioning: the very first product) or ``box['cavo']`` (crossattn: the attention product of
+    the first transformer block), both filled in by emit_unet1d_step once the GCN chain is emitted."""
+    mc = w.mc
     # Every trunk product writes a slab tensor (K split over workgroups) unless its consumer needs whole rows cheaply:
     # the two LayerNorm operands of a transformer block (t0, t2) are produced with ``ln_split`` slices.
     ln_split = ROWS_LN_SPLIT
@@ -827,14 +905,19 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
             kind = it[0]
             if kind == 'conv_in':
                 o = b.linear([seg(v) for v in h_segs], d['conv'], O)
+                yield
                 h_segs, hC = [o], mc
             elif kind == 'res':
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
                 skip_early = 'skip' in d and ROWS_SKIP_EARLY
+                if skip_early:
+                    yield 'CTX'                  # (this variant fuses conv1 with the skip projection itself: nothing rides from here on)
                 h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
                               res=View(emb_all, col=eo, ld=emb_ld, width=cout), fuse_next=skip_early)
+                if not skip_early:
+                    yield
                 gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
                 if skip_early:
                     # skip_connection(x) depends only on the block input: it rides on conv1's launch as a second, independent problem
@@ -848,20 +931,26 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 else:
                     if 'skip' in d:
                         resv = b.linear([seg(v) for v in h_segs], d['skip'], O)
+                        yield
                     else:
                         assert len(h_segs) == 1
                         resv = h_segs[0]
                     o = b.linear(gn2, d['conv2'], O, res=resv)
+                yield
                 h_segs, hC = [o], cout
             elif kind == 'attn' and w.concat:
                 C = it[1]
                 xin = h_segs[0]
                 o = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-5, False, C=C), d['av'], O, res=xin)
+                yield
                 h_segs, hC = [o], C
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
                 t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C), d['proj_in'], O, split=ln_kbps(C))
+                yield
+                yield 'CTX'                      # the next product adds the cross-attention vector of the GCN output
+                cavo = box['cavo']
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
                 # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
@@ -869,14 +958,18 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
                 t2 = b.linear([seg(t0, pro=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5, gs=C)], d['vo1'], O,
                               res=t0, res2=cavo[name],
                               split=(False if vs_ <= 1 else max(8, ((C + 15) // 16 + vs_ - 1) // vs_)))
+                yield
                 b.tags[name + '.transformer_blocks.0:in'] = t0
                 b.tags[name + '.transformer_blocks.0:attn2'] = t2
                 # GEGLU applied in the ff1 epilogue (needs finished sums: one slice, 16 * 4C / 16 column tiles)
                 gl = b.linear([seg(t2, pro=hip.PRO_LN, gamma=d['ln3'][0], beta=d['ln3'][1], eps=1e-5, gs=C)], d['ff1'], O)
+                yield
                 o = b.linear([seg(gl), seg(t2)], d['ff2po'], O, res=xin)
+                yield
                 h_segs, hC = [o], C
             elif kind in ('down', 'up'):
                 o = b.linear([seg(v) for v in h_segs], d['conv'], O)
+                yield
                 h_segs = [o]
             b.tags[name] = h_segs[0]
         return h_segs, hC
@@ -885,17 +978,18 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     hs = []
     h_segs, hC = [View(x)], w.in_ch
     if w.concat:                               # box vector and GCN output as input channels (denoise_net.py:789-790)
-        h_segs, hC = [View(x), ctx], w.in_ch + w.ctx_dim
+        yield 'CTX'
+        h_segs, hC = [View(x), box['ctx']], w.in_ch + w.ctx_dim
     for i, blk in enumerate(inp):
-        h_segs, hC = run_block(f'input_blocks.{i}', blk, h_segs, hC)
+        h_segs, hC = yield from run_block(f'input_blocks.{i}', blk, h_segs, hC)
         hs.append((h_segs[0], hC))
-    h_segs, hC = run_block('middle_block', mid, h_segs, hC)
+    h_segs, hC = yield from run_block('middle_block', mid, h_segs, hC)
     for i, blk in enumerate(out):
         sk, sC = hs.pop()
-        h_segs, hC = run_block(f'output_blocks.{i}', blk, [h_segs[0], sk], hC + sC)
+        h_segs, hC = yield from run_block(f'output_blocks.{i}', blk, [h_segs[0], sk], hC + sC)
     # (eps stays an ordinary tensor: it is also the result of the step-level API; one slice)
     b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O, View(eps_out))
-    return objbuf
+    yield
 
 
 # the volume-path ops (conv, groupnorm, attention, ...) are attached to Builder by plan_vol; importing it here makes

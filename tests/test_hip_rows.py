@@ -487,6 +487,68 @@ def test_linear_multi_problem_launch(dev):
         assert torch.equal(x, y)
 
 
+def test_linear_folded_rider_with_groupnorm_prologue(dev):
+    """A node-row product (GroupNorm + SiLU over a SLAB operand, K split) riding on a triple-row launch with more row tiles (8 against
+    3): the rider is FOLDED over all rows of the grid (RowsLaunch.fw, its 3 x 6 tiles do not fill the 3 x 8 block: the tail exits) --
+    identical to launching the two one after the other, and equal to torch."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg, norm_segs
+    rs = np.random.RandomState(33)
+    T, O, C = 124, 33, 128
+    tri = torch.from_numpy(rs.standard_normal((T, 64)).astype(np.float32))
+    x0 = torch.from_numpy(rs.standard_normal((O, 256)).astype(np.float32))
+    W0 = torch.from_numpy((rs.standard_normal((C, 256)) / 16).astype(np.float32))          # producer of the slab operand (K split)
+    Wh = torch.from_numpy((rs.standard_normal((80, 64)) / 8).astype(np.float32))
+    Wr = torch.from_numpy((rs.standard_normal((40, C)) / 11).astype(np.float32))
+    ga = torch.from_numpy(rs.standard_normal(C).astype(np.float32))
+    be = torch.from_numpy(rs.standard_normal(C).astype(np.float32))
+    emb = torch.from_numpy(rs.standard_normal((1, 40)).astype(np.float32))
+    outs = []
+    for fuse in (True, False):
+        b = Builder(dev)
+        h = b.linear([seg(View(b.dev(x0)))], PackedLinear(W0, None, dev), O, split=8)    # 2 slabs of [O, C]
+        assert h.nslab == 2
+        a1 = b.linear([seg(View(b.dev(tri)))], PackedLinear(Wh, torch.zeros(80), dev), T, View(b.buf(T, 80)), act=hip.ACT_RELU,
+                      fuse_next=fuse)
+        a2 = b.linear(norm_segs([h], b.dev(ga), b.dev(be), 1e-5, True, C=C), PackedLinear(Wr, None, dev), O,
+                      res=View(b.dev(emb), ld=0, width=40), split=4)
+        assert a2.nslab == 2
+        b.finish().run()
+        torch.cuda.synchronize()
+        outs.append([a1.value().cpu(), a2.value().cpu()])
+    hh = F.linear(x0, W0)
+    _close(outs[0][0], F.relu(F.linear(tri, Wh)), 2e-5)
+    _close(outs[0][1], F.linear(F.silu(F.group_norm(hh, 32, ga, be, 1e-5)), Wr) + emb, 1e-4, 1e-4)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+
+
+def test_unet1d_riding_modes_are_bit_identical(dev):
+    """The head of the UNet1D trunk rides on the GCN chain's launches (plan.ROWS_RIDE): eps of one step is BIT-identical with riding
+    off (0), on net2's output launches (1) and on net1's / net2's (2) -- only the launch grouping differs."""
+    from echoscene_amd import plan, synth, config as escfg
+    from echoscene_amd.model.unet import UNet1DModel
+    from echoscene_amd.samplers import LayoutDenoiser
+    net = UNet1DModel(**escfg.layout_denoiser_kwargs(128))
+    synth.seeded_fill_(net, prefix='ride.')
+    O = 12
+    _, triples = synth.synthetic_graph(O, seed=5)
+    oe = torch.randn(O, 640, generator=torch.Generator().manual_seed(5))
+    x = torch.randn(O, 8, generator=torch.Generator().manual_seed(6))
+    old, res, nops = plan.ROWS_RIDE, [], []
+    try:
+        for mode in (0, 1, 2):
+            plan.ROWS_RIDE = mode
+            den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(1000), dev)
+            res.append(den.eps(x, oe, triples, 3).cpu())
+            res.append(den.sample(oe, triples, noise=synth.layout_noise(O, 8, 6), n_steps=6, use_graph=True).cpu())
+    finally:
+        plan.ROWS_RIDE = old
+    assert torch.isfinite(res[0]).all() and float(res[0].abs().max()) > 0
+    for k in (2, 4):
+        assert torch.equal(res[0], res[k]) and torch.equal(res[1], res[k + 1])
+
+
 def test_plan_reuse_across_scene_graphs(dev):
     """eval_3dfront.py visits a different scene graph on every call: plans are cached by (node count, triple-row capacity)
     and a new graph of the same size class only rewrites index arrays in place -- same plan object, same captured hipGraph,

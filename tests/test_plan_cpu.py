@@ -1,0 +1,76 @@
+"""Host-side checks of the layout planner (no GPU): the op list of one UNet1D step is emitted with a CPU Builder and examined from
+its pointers alone (tools/plan_dryrun.py).  Since round 4 the head of the trunk rides on the launches of the GCN chain
+(plan.Rider / Builder.ride): the problems of one launch must be independent, every operand must come from an earlier launch, and
+riding must not change any product (same K slices: same bits)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+def _emit(monkeypatch, mode, **kw):
+    import plan_dryrun
+    from echoscene_amd import plan
+    monkeypatch.setattr(plan, 'ROWS_RIDE', mode)
+    b, _ = plan_dryrun.emit_layout_step_cpu(**kw)
+    return plan_dryrun, b
+
+
+def _products(b):
+    from echoscene_amd import hip
+    out = []
+    for op in b.ops:
+        if op.kind == hip.OP_LINEAR:
+            a = op.u.linear
+            out.append((a.M, a.K, a.N, a.kb_per_slice, a.act, a.nseg, a.wpack, a.out, a.out_slab_stride,
+                        tuple((a.seg[s].ptr, a.seg[s].nslab, a.seg[s].pro, a.seg[s].mode) for s in range(a.nseg))))
+    return out
+
+
+@pytest.mark.parametrize('variant', [dict(), dict(enable_t_emb=False), dict(concat=True)], ids=['crossattn', 'no_t_emb', 'concat'])
+def test_layout_step_launch_groups_are_independent_and_ordered(monkeypatch, variant):
+    counts = {}
+    for mode in (0, 1, 2):
+        dry, b = _emit(monkeypatch, mode, mc=128, O=8, **variant)
+        n, problems = dry.check(b)
+        assert problems == [], problems
+        counts[mode] = n
+        for _, grp in dry.launches(b):
+            assert len(grp) <= 3
+    if variant.get('concat'):
+        # the first trunk product already reads the GCN output: nothing can ride
+        assert counts[0] == counts[1] == counts[2]
+    else:
+        # conv_in on the box embedding's launch + 5 (mode 1) / 8 (mode 2) trunk products on GCN launches
+        assert counts[1] == counts[0] - 6 and counts[2] == counts[0] - 9, counts
+
+
+def test_riding_changes_the_order_of_the_ops_only(monkeypatch):
+    """same products (shape, K slices, epilogue, operand slab counts, prologues) whatever rides where: only the order differs"""
+    from collections import Counter
+    ref = None
+    for mode in (0, 1, 2):
+        _, b = _emit(monkeypatch, mode, mc=128, O=8)
+        sig = Counter((p[:6] + tuple((s[1], s[2], s[3]) for s in p[9])) for p in _products(b))
+        if ref is None:
+            ref = sig
+        assert sig == ref
+
+
+def test_the_checker_sees_a_broken_order(monkeypatch):
+    """negative control: a trunk product moved in front of the launch that produces its operand is reported"""
+    from echoscene_amd import hip
+    dry, b = _emit(monkeypatch, 0, mc=128, O=8)
+    lin = [i for i, op in enumerate(b.ops) if op.kind == hip.OP_LINEAR]
+    i, j = lin[-2], lin[-1]                     # the last ResBlock product and the output conv that reads it
+    b.ops[i], b.ops[j] = b.ops[j], b.ops[i]
+    _, problems = dry.check(b)
+    assert problems
+    # ... and two dependent products marked as ONE launch are reported as well
+    b.ops[i], b.ops[j] = b.ops[j], b.ops[i]
+    b.ops[i].u.linear.fuse_next = 1
+    _, problems = dry.check(b)
+    assert any('same launch' in p for p in problems), problems
