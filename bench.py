@@ -155,7 +155,7 @@ def sub_records(dev, lay, use_graph, a):
     the full step of a 16-node scene."""
     recs = [{'config': 'configs[1]: EchoLayout box diffusion, 32-node graph, 1000-step DDPM', 'metric': 'layout steps/s',
              'value': lay['steps_per_s'], 'ms_per_step': lay['ms_per_step'], 'kernels_per_step': lay['kernels_per_step'],
-             'hbm_GBps_algorithmic': lay['hbm_GBps_algorithmic']}]
+             'launches_per_step': lay['launches_per_step'], 'hbm_GBps_algorithmic': lay['hbm_GBps_algorithmic']}]
     O = 16
     net, den, obj_embed, triples = build_layout(dev, O, seed=116)
     df, sden, uc = build_shape(dev, O, 116, triples)
@@ -592,7 +592,8 @@ def main():
                'layout_ms_per_step': _stats(lay_reps), 'shape_ms_per_step': _stats(shp_reps) if full else None}
         lay = {'steps_per_s': round(a.steps / (lay_ms * 1e-3), 2), 'ms_per_step': round(lay_ms / a.steps, 4),
                'ms_per_step_min_max': [rep['layout_ms_per_step']['min'], rep['layout_ms_per_step']['max']],
-               'kernels_per_step': st['plan'].n_ops, 'weight_bytes_per_step': st['plan'].weight_bytes,
+               'kernels_per_step': st['plan'].n_ops, 'launches_per_step': st['plan'].n_launches,
+               'weight_bytes_per_step': st['plan'].weight_bytes,
                'hbm_GBps_algorithmic': round(st['plan'].weight_bytes / (lay_ms * 1e-3 / a.steps) / 1e9, 1)}
         if full:
             flops = ss['plan'].flops          # this rank's share of the step

@@ -460,6 +460,24 @@ class Plan:
         if not self.handle:
             raise RuntimeError('es_plan_create: ' + hip.lib().es_last_error().decode())
 
+    @property
+    def n_launches(self):
+        """kernel launches of one execution: the runtime's grouping of rows products marked ``fuse_next`` (es_plan_run: up to three
+        independent products per grid), one launch per other op, + the step increment behind a sampler update"""
+        ops, i, n = self._arr, 0, 0
+        while i < len(ops):
+            op, k = ops[i], 1
+            if op.kind == hip.OP_LINEAR and op.u.linear.fuse_next:
+                while k < 3 and ops[i + k - 1].u.linear.fuse_next and i + k < len(ops) and ops[i + k].kind == hip.OP_LINEAR \
+                        and ops[i + k].lane == op.lane:
+                    k += 1
+            if op.kind not in (hip.OP_FORK, hip.OP_JOIN):
+                n += 1
+            if op.kind in (hip.OP_DDPM, hip.OP_DDIM) and op.u.update.inc_step:
+                n += 1
+            i += k
+        return n
+
     def run(self):
         hip.check(hip.lib().es_plan_run(C.c_void_p(self.handle), hip.current_stream()), 'es_plan_run')
 
