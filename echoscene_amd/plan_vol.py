@@ -15,9 +15,6 @@ from . import hip
 from .hip import ConvArgs, GNArgs, LNArgs, AttnArgs, GegluArgs, ToClArgs, StemArgs, Op
 from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn)
 
-# A shard's GCN chain as a parallel graph branch of its main plan (emit_unet3d_step, 'side branch'): scheduling only, same bits.
-SHARD_SIDE_LANE = os.environ.get('ES_SHARD_SIDE', '1') != '0'
-
 
 class PackedConv:
     """f16 [Npad][taps][Cin32] image of a conv / linear weight + fp32 bias on the device."""
@@ -548,21 +545,15 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     side_join = {'pending': False}
     # (not with ES_LANES=1: emit_gcn's own FORK/JOIN pairs would then be nested inside this branch and every inner JOIN would
     #  make the main stream wait for the whole echo chain)
-    # A SHARD's step is two plans -- ops[:split] (its stem codes), the echo all-gather, ops[split:] -- and until round 4 its GCN
-    # chain (copy of the gathered codes, 20 dependent launches, the cross-attention vectors: ~0.3 ms with the GPU all but idle) ran
-    # IN FRONT of the volume path.  Now the branch starts at the split point: the main plan opens with the FORK, the GCN chain runs
-    # beside conv_in and the first ResBlocks exactly as on one GPU (SHARD_SIDE_LANE, a scheduling switch: same kernels, same bits).
-    sharded = Ol != Ofull or bool(getattr(b, 'force_exchange', False))
-    if (w.mp and not w.concat and tables is not None and len(b.ops) > side0 and not b.use_lanes
-            and (not sharded or SHARD_SIDE_LANE)):
-        first = b.split if sharded else side0
-        for k in range(first, len(b.ops)):
+    if (w.mp and not w.concat and Ol == Ofull and tables is not None and len(b.ops) > side0 and not b.use_lanes
+            and not getattr(b, 'force_exchange', False)):
+        for k in range(side0, len(b.ops)):
             if k not in keep_main:
                 b.ops[k].lane = 2
         fk = Op()
         fk.kind, fk.lane = hip.OP_FORK, 2
-        b.ops.insert(first, fk)
-        b.split += 1 if b.split > first else 0
+        b.ops.insert(side0, fk)
+        b.split += 1 if b.split > side0 else 0
         side_join['pending'] = True
 
     def join_side():
