@@ -1,19 +1,22 @@
 #!/bin/bash
-# full GPU test suite, smoke, then the profile collection of the round
+# final GPU session of a round, in order of importance (every step under its own timeout): full GPU suite, smoke, the bench line of
+# record, the layout line, rocprofv3 kernel stats of the full step and of the layout step, scene-call latency, shard emulation
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-final}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-final}
 mkdir -p $OUT
-timeout 3000 python -m pytest tests -m gpu -q -s > $OUT/tests_gpu.log 2>&1
+timeout 780 python -m pytest tests -m gpu -q > $OUT/tests_gpu.log 2>&1
 echo "gpu tests rc=$?" > $OUT/summary.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
 echo "smoke rc=$?" >> $OUT/summary.txt
-timeout 300 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
-timeout 400 python tools/scene_sizes_latency.py > $OUT/scene_sizes.txt 2>&1
-timeout 300 python tools/aux_launch_table.py > $OUT/aux_table.txt 2>&1
-bash tools/gpu_session_profile.sh ${1:-final}
-timeout 600 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
-timeout 600 python tools/emulate_shards.py --steps 20 --tuned 2>&1 | grep "^world" > $OUT/shards_tuned.txt
-
-timeout 300 python tools/model_file_size.py > $OUT/model_file_size.txt 2>&1
-cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; grep -v amdgpu $OUT/e2e.txt | tail -8; grep -v amdgpu $OUT/scene_sizes.txt; cat $OUT/shards_default.txt $OUT/shards_tuned.txt; grep -v amdgpu $OUT/model_file_size.txt; du -sh $OUT
+timeout 300 python bench.py --steps 100 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err
+timeout 100 python bench.py --workload layout --steps 200 --warmup 5 > $OUT/bench_layout.json 2> $OUT/bench_layout.err
+( cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/prof_final -o st --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --reps 1 --no-cpu-baseline --no-sub-records > $OUT/prof_final.log 2>&1 )
+( cd /tmp && timeout 100 rocprofv3 --kernel-trace --stats -d $OUT/prof_layout -o lay --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --workload layout --steps 50 --warmup 3 --reps 1 --no-cpu-baseline > $OUT/prof_layout.log 2>&1 )
+timeout 120 python tools/e2e_latency.py > $OUT/e2e.txt 2>&1
+timeout 120 python tools/emulate_shards.py --steps 20 2>&1 | grep "^world" > $OUT/shards_default.txt
+timeout 120 python tools/emulate_shards.py --steps 20 --tuned 2>&1 | grep "^world" > $OUT/shards_tuned.txt
+timeout 150 python tools/scene_sizes_latency.py > $OUT/scene_sizes.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -size +6M -delete
+find $OUT -name "*.db" -delete; find $OUT -name "*.rocpd" -delete; find $OUT -name "*agent_info.csv" -delete
+cat $OUT/summary.txt; grep -E "passed|failed" $OUT/tests_gpu.log | tail -3; tail -2 $OUT/smoke.log; tail -1 $OUT/bench_final.json | cut -c1-400; grep -v amdgpu $OUT/e2e.txt | tail -6; cat $OUT/shards_default.txt $OUT/shards_tuned.txt; du -sh $OUT
