@@ -74,3 +74,13 @@ def test_the_checker_sees_a_broken_order(monkeypatch):
     b.ops[i].u.linear.fuse_next = 1
     _, problems = dry.check(b)
     assert any('same launch' in p for p in problems), problems
+
+
+def test_plan_launch_count_matches_the_runtime_grouping(monkeypatch):
+    """Plan.n_launches (the bench line's launches_per_step) counts what es_plan_run launches: fused groups once"""
+    from echoscene_amd import plan
+    dry, b = _emit(monkeypatch, 2, mc=128, O=8)
+
+    class _P:
+        _arr = b.ops
+    assert plan.Plan.n_launches.fget(_P) == len(dry.launches(b))
