@@ -26,9 +26,10 @@ ROWS_VO1_SLICES = 2      # attention-with-one-token product: 2 / 1 -> 1124 / 112
 ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's launch: measured -1.1 %
 # The head of the UNet1D trunk (conv_in ... the first transformer's proj_in: 9 dependent products that do not need the GCN output)
 # rides on the launches of the GCN chain instead of following it: 9 launches off the critical path of a layout step.  Not a numerical
-# choice (every product keeps its own K slices: same bits), a planner switch for the A/B: 0 = off, 1 = conv_in on the box embedding's
+# choice (every product keeps its own K slices: same bits), a planner constant (not an environment switch): 0 = off, 1 = conv_in on the box embedding's
 # launch + one product on net2's output launch of every GCN layer, 2 = also one on net1's second Linear (320 + 256 workgroups).
-ROWS_RIDE = int(os.environ.get('ES_ROWS_RIDE', '2'))
+# Same-box A/B (profiles/r04_layout_ride_ab.txt, tools/ab_layout_ride.py sets this attribute): 0 / 1 / 2 -> 810-823 / 801 / 795 us per step.
+ROWS_RIDE = 2
 
 
 class View:
