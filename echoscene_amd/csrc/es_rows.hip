@@ -306,13 +306,17 @@ struct RowsLaunch {
 
 // NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
 // unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
-template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI, bool U1 = false>
+// NT = 2: a workgroup owns TWO adjacent 16-column tiles (column tiles 2t, 2t + 1) of its 16 rows: ONE staged / normalised A tile, two
+// weight streams, two accumulators, threads 256..511 (idle in the one-tile epilogue) finalise the second tile.  For the GEGLU
+// projection behind a LayerNorm (N = 4096: 512 workgroups each normalising its 16 x 512 rows from two slabs -> 256): half the
+// staging traffic and LayerNorm work per output.  Per output the k-blocks, their order and the reduction are those of NT = 1.
+template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI, bool U1 = false, int NT = 1>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     kernarg_warm<sizeof(RowsLaunch)>();
     const int ldx = L.ldx, dbg = L.dbg;
     float* x = smem;                                     // [MT][ldx]
-    float* red = smem + MT * ldx;                        // [NKG][256]
+    float* red = smem + MT * ldx;                        // [NT][NKG][256]
     if (dbg & 4) return;                                 // (calibration of the launch floor, tools/microbench_rows.py)
     const int pi = (L.n > 1 && (int)blockIdx.x >= L.wg0[1] ? 1 : 0) + (L.n > 2 && (int)blockIdx.x >= L.wg0[2] ? 1 : 0);
     const es_linear_args& a = L.p[pi];
@@ -325,26 +329,30 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     } else if (by >= L.ny[pi]) return;
     const int S = L.S[pi], kbps = L.kbps[pi];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = bx % S, nt = bx / S;
+    const int slice = bx % S, nt = (bx / S) * NT;        // (first) column tile of the workgroup
     const int m0 = by * MT;
     const int nkb_total = (a.K + 15) >> 4;
     const int kb0 = slice * kbps, kb1 = slice == S - 1 ? nkb_total : kb0 + kbps;
     const int bz = blockIdx.z;                           // batched launch: z-th problem of identical shape
     const int nct = (a.N + 15) >> 4;
     const f4* wp = (const f4*)a.wpack + ((size_t)bz * nct + nt) * nkb_total * 64;
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f};
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, q = lane >> 4;
 
     // (0) Epilogue operands depend only on the output coordinates: issued FIRST so that their latency overlaps the weight
     // stream, the staging and the product.  Thread (ml, nl), tid < 256, owns output (ml, nl) of the 16 x 16 tile.
     const int ml = (tid >> 4) & 15, nl = tid & 15;
-    const int n_e = nt * 16 + nl, m_e = m0 + ml;
+    const int te = NT > 1 ? (tid >> 8) : 0;              // the tile this thread finalises (NT = 1: threads 256.. take no part)
+    const int nt_e = nt + te;
+    const int n_e = nt_e * 16 + nl, m_e = m0 + ml;
     const bool geglu = GEGLU_EPI && a.act == ES_ACT_GEGLU;
     const float* bias = a.bias ? a.bias + (long)bz * a.N : nullptr;
-    const int nres = geglu ? nt * 8 + nl : n_e;          // column of the residual / output
+    const int nres = geglu ? nt_e * 8 + nl : n_e;        // column of the residual / output
     const bool first = slice == 0;                       // slice 0 carries bias and residuals
     float e_bias = 0.f, e_res = 0.f, e_res2 = 0.f;
-    const bool ok_e = tid < 256 && m_e < a.M && n_e < a.N;
+    const bool ok_e = tid < 256 * NT && m_e < a.M && n_e < a.N;
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
     float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
     const int ns1 = a.res_nslab > 1 ? a.res_nslab : 1, ns2 = a.res2_nslab > 1 ? a.res2_nslab : 1;
@@ -360,12 +368,16 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
         const int kc = min(KCH, kb1 * 16 - c0);
         const int nkb = kc >> 4;
         // (1) issue this wave's weight-fragment loads first: HBM latency overlaps the staging below
-        f4 bf[MAXJ];
+        f4 bf[NT][MAXJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int kb = kg + j * NKG;
-            bf[j] = f4{1.f, 1.f, 1.f, 1.f};
-            if (kb < nkb && !(dbg & 1)) bf[j] = __builtin_nontemporal_load(&wp[(size_t)((c0 >> 4) + kb) * 64 + lane]);
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int kb = kg + j * NKG;
+                bf[t][j] = f4{1.f, 1.f, 1.f, 1.f};
+                if (kb < nkb && !(dbg & 1))
+                    bf[t][j] = __builtin_nontemporal_load(&wp[(size_t)(t * nkb_total + (c0 >> 4) + kb) * 64 + lane]);
+            }
         }
         // (2) stage the activation slice with its prologue applied
         if (c0 > kb0 * 16) __syncthreads();
@@ -380,23 +392,27 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
             if (kb < nkb) {
                 const f4 a0 = *(const f4*)&x[i16 * ldx + kb * 16 + 4 * q];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bf[j][s], acc0, 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bf[t][j][s], acc[t], 0, 0, 0);
+                }
             }
         }
     }
     // (4) fixed-order reduction over the k-block groups through LDS, then the epilogue: one output per thread
-    *(f4*)&red[wave * 256 + lane * 4] = acc0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *(f4*)&red[(t * NKG + wave) * 256 + lane * 4] = acc[t];
     __syncthreads();
     // D layout of mfma 16x16: lane = (row>>2)*16 + col holds D[row][col] in register row&3
     const int off = ((ml >> 2) * 16 + nl) * 4 + (ml & 3);
     float sres = 0.f;
 #pragma unroll
-    for (int w = 0; w < NKG; ++w) sres += red[w * 256 + off];
+    for (int w = 0; w < NKG; ++w) sres += red[(te * NKG + w) * 256 + off];
     if (has1) e_res = sum_slabs1(r1, pr1, ns1, a.res_slab_stride);
     if (has2) e_res2 = sum_slabs1(r2, pr2, ns2, a.res2_slab_stride);
     float* out = a.out + (long)bz * a.out_bstride + (long)slice * a.out_slab_stride;
     if (GEGLU_EPI && geglu) {
-        // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt + nl, lane nl + 8 its gate
+        // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8*nt_e + nl, lane nl + 8 its gate
         float sb = sres + e_bias;
         const float gate = __shfl_xor(sb, 8, 16);
         if (ok_res) {
@@ -694,7 +710,12 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
                "es_linear_rows_multi_f32: fused problems take no LayerNorm prologue, no GEGLU epilogue and no batching");
     L.n = n;
     L.ldx = kcmax + 8;
-    const size_t lds = (size_t)(MT * L.ldx + NWAVE * 256) * sizeof(float);
+    // two column tiles per workgroup (NT = 2) for the GEGLU projection behind a LayerNorm: timing-only switch ES_ROWS_NT2 (0 = off)
+    static const char* nt2_env = getenv("ES_ROWS_NT2");
+    const bool nt2 = n == 1 && has_ln && gepi && pr[0].nb == 1 && pr[0].S == 1 && ((pr[0].a.N + 15) / 16) % 2 == 0 &&
+                     !(nt2_env && atoi(nt2_env) == 0);
+    if (nt2) gx /= 2;
+    const size_t lds = (size_t)(MT * L.ldx + (nt2 ? 2 : 1) * NWAVE * 256) * sizeof(float);
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)pr[0].nb);
     // kernel table: lean instantiations for what the sampling path launches, one general kernel per slab bound for the rest
     static const void* const k_plain[4][2] = {
@@ -708,6 +729,9 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     static const void* const k_ln[2][2] = {
         {(const void*)k_linear_rows<1, 0, false, 4, true>, (const void*)k_linear_rows<2, 0, false, 4, true>},
         {(const void*)k_linear_rows<1, 0, false, 8, true>, (const void*)k_linear_rows<2, 0, false, 8, true>}};
+    static const void* const k_ln_nt2[2][2] = {
+        {(const void*)k_linear_rows<1, 0, false, 4, true, false, 2>, (const void*)k_linear_rows<2, 0, false, 4, true, false, 2>},
+        {(const void*)k_linear_rows<1, 0, false, 8, true, false, 2>, (const void*)k_linear_rows<2, 0, false, 8, true, false, 2>}};
     static const void* const k_csr = (const void*)k_linear_rows<1, 0, true, 0, false>;
     // two-workgroups-per-CU variants (stage_chunk U1) of the plain family for launches of more than one round
     static const void* const k_plain_u1[3][2] = {
@@ -722,7 +746,7 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     const bool one_per_cu = proc == 1 || nsi == 2;
     const bool u1 = n > 1 && nsi <= 2 && (u1_mode == 2 || (u1_mode == 1 && one_per_cu && wg_real > 256));
     const void* fn = nullptr;
-    if (has_ln) fn = k_ln[pr[0].a.K <= 512 ? 0 : 1][nsi];
+    if (has_ln) fn = (nt2 ? k_ln_nt2 : k_ln)[pr[0].a.K <= 512 ? 0 : 1][nsi];
     else if (csr && proc == 0 && nsmax == 1 && !gepi) fn = k_csr;
     else if (!csr && proc <= 1 && !gepi) fn = u1 ? k_plain_u1[nsi][proc] : k_plain[nsi][proc];
     else fn = k_general[nsi];
@@ -730,14 +754,14 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            constexpr int bytes = (MT * (KCH + 8) + NWAVE * 256) * 4;
+            constexpr int bytes = (MT * (KCH + 8) + 2 * NWAVE * 256) * 4;
             auto set = [](const void* f) {
                 const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
                 if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
             };
             for (int i = 0; i < 4; ++i) { set(k_plain[i][0]); set(k_plain[i][1]); set(k_general[i]); }
             for (int i = 0; i < 3; ++i) { set(k_plain_u1[i][0]); set(k_plain_u1[i][1]); }
-            for (int i = 0; i < 2; ++i) { set(k_ln[i][0]); set(k_ln[i][1]); }
+            for (int i = 0; i < 2; ++i) { set(k_ln[i][0]); set(k_ln[i][1]); set(k_ln_nt2[i][0]); set(k_ln_nt2[i][1]); }
             set(k_csr);
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_linear_rows_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
