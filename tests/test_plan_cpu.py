@@ -84,3 +84,16 @@ def test_plan_launch_count_matches_the_runtime_grouping(monkeypatch):
     class _P:
         _arr = b.ops
     assert plan.Plan.n_launches.fget(_P) == len(dry.launches(b))
+
+
+@pytest.mark.parametrize('consts', [dict(ROWS_SKIP_EARLY=True), dict(ROWS_GCN_SLICES=1), dict(ROWS_GCN_SLICES=4),
+                                    dict(ROWS_LN_SPLIT=1, ROWS_VO1_SLICES=1, ROWS_CAV_SLICES=2)],
+                         ids=['skip_early', 'gcn_1_slice', 'gcn_4_slices', 'other_slices'])
+def test_other_planner_constants_keep_the_order_valid(monkeypatch, consts):
+    """the planner's K-slice / fusion constants (plan.ROWS_*: build constants, A/B'd in round 3) combined with riding"""
+    from echoscene_amd import plan
+    for k, v in consts.items():
+        monkeypatch.setattr(plan, k, v)
+    dry, b = _emit(monkeypatch, 2, mc=128, O=8)
+    n, problems = dry.check(b)
+    assert problems == [], problems
