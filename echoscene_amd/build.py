@@ -6,7 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB = os.path.join(HERE, 'libechoscene_hip.so')
+# ES_BUILD_TAG=_stamp (with ES_BUILD_FLAGS=-DES_STAMP): an instrumented build next to the product library, loaded with ES_LIB_TAG=_stamp
+TAG = os.environ.get('ES_BUILD_TAG', '')
+LIB = os.path.join(HERE, 'libechoscene_hip%s.so' % TAG)
 SOURCES = ['es_runtime.hip', 'es_rows.hip', 'es_vol.hip', 'es_vol32.hip', 'es_chamfer.hip', 'es_mc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ES_BUILD_FLAGS', '').split()
@@ -27,7 +29,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+        obj = os.path.join(CSRC, src.replace('.hip', TAG + '.o'))
         cmd = ['hipcc'] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)

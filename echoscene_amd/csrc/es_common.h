@@ -126,12 +126,12 @@ template <int BYTES>
 __device__ __forceinline__ void kernarg_warm() {
     const unsigned long ka = (unsigned long)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NL = (BYTES + 63) / 64;
-    static_assert(NL <= 24, "kernarg_warm: argument block larger than expected");
-    unsigned d[24];
-#define ES_KW(i) if (i < NL) asm volatile("s_load_dword %0, %1, %2" : "=s"(d[i]) : "s"(ka), "i"(i * 64));
-    ES_KW(0) ES_KW(1) ES_KW(2) ES_KW(3) ES_KW(4) ES_KW(5) ES_KW(6) ES_KW(7) ES_KW(8) ES_KW(9) ES_KW(10) ES_KW(11)
-    ES_KW(12) ES_KW(13) ES_KW(14) ES_KW(15) ES_KW(16) ES_KW(17) ES_KW(18) ES_KW(19) ES_KW(20) ES_KW(21) ES_KW(22) ES_KW(23)
-#undef ES_KW
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_assert(NL <= 28, "kernarg_warm: argument block larger than expected");
+    // ONE asm statement, loads AND wait: the loads are asynchronous, and as separate statements (round 3-4) the compiler was free to put a
+    // load of its own between them into the very SGPR the statements used as their dead destination -- two loads in flight to one
+    // register return in any order (round 5: a kernel read `ny` of its argument block as whatever line 0x180 held; found in the ISA).
+    unsigned d;
+    asm volatile(".set es_kw_off, 0\n\t.rept %c2\n\ts_load_dword %0, %1, es_kw_off\n\t.set es_kw_off, es_kw_off + 64\n\t.endr\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(d) : "s"(ka), "i"(NL) : "memory");
 }
 

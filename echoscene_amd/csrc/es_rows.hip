@@ -302,7 +302,17 @@ struct RowsLaunch {
     int S[3], kbps[3], wg0[3], ny[3];
     int xw[3], fw[3];            // tiles per row of the problem (column tiles x slices); folded width (0 = not folded)
     int n, ldx, dbg;
+#ifdef ES_STAMP
+    unsigned long long* stamp;   // tools/rows_stamps.py: 8 x 100 MHz wall-clock ticks per workgroup (wave 0), slot = launch_id * 1024 + workgroup
+    int launch_id;
+#endif
 };
+
+#ifdef ES_STAMP
+#define ES_RSTAMP(k) do { if (L.stamp) st_[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ES_RSTAMP(k) do { } while (0)
+#endif
 
 // NS: bound of the slab counts of the A segments; LNU > 0: LayerNorm prologue over rows of up to 128 * LNU columns (PROC / CSR
 // unused); GEGLU_EPI: the value * gelu(gate) epilogue is compiled in.
@@ -313,7 +323,12 @@ struct RowsLaunch {
 template <int NS, int PROC, bool CSR, int LNU, bool GEGLU_EPI, bool U1 = false, int NT = 1>
 __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef ES_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    st_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     kernarg_warm<sizeof(RowsLaunch)>();
+    ES_RSTAMP(1);
     const int ldx = L.ldx, dbg = L.dbg;
     float* x = smem;                                     // [MT][ldx]
     float* red = smem + MT * ldx;                        // [NT][NKG][256]
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
     const int ns1 = a.res_nslab > 1 ? a.res_nslab : 1, ns2 = a.res2_nslab > 1 ? a.res2_nslab : 1;
     const bool has1 = first && a.res && ok_res && !(dbg & 8), has2 = first && a.res2 && ok_res && !(dbg & 8);
-    const float* const pr1 = a.res + (long)m_e * a.res_ld + nres;
+    const float* const pr1 = a.res + (long)m_e * a.res_ld + nres + (a.res_step ? (long)(*a.res_step) * a.res_step_stride : 0);
     const float* const pr2 = a.res2 + (long)m_e * a.res2_ld + nres;
     if (has1) issue_slabs1(r1, pr1, ns1, a.res_slab_stride);        // summed in the epilogue
     if (has2) issue_slabs1(r2, pr2, ns2, a.res2_slab_stride);
@@ -384,7 +399,9 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
         if (dbg & 2) { }
         else if (LNU > 0) stage_ln<NS, (LNU > 0 ? LNU : 1)>(a, x, ldx, m0, c0, kc, tid);
         else stage_chunk<NS, PROC, CSR, U1>(a, x, ldx, m0, c0, kc, tid);
+        if (c0 == kb0 * 16) ES_RSTAMP(2);
         __syncthreads();
+        if (c0 == kb0 * 16) ES_RSTAMP(3);
         // (3) MFMA: D[m][n] += X[m][k] * W[n][k]; 4 k-steps per 16-wide block
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
@@ -402,7 +419,9 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
     // (4) fixed-order reduction over the k-block groups through LDS, then the epilogue: one output per thread
 #pragma unroll
     for (int t = 0; t < NT; ++t) *(f4*)&red[(t * NKG + wave) * 256 + lane * 4] = acc[t];
+    ES_RSTAMP(4);
     __syncthreads();
+    ES_RSTAMP(5);
     // D layout of mfma 16x16: lane = (row>>2)*16 + col holds D[row][col] in register row&3
     const int off = ((ml >> 2) * 16 + nl) * 4 + (ml & 3);
     float sres = 0.f;
@@ -420,6 +439,14 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
             if (a.res) v += e_res;
             out[(long)m_e * a.out_ld + nres] = v;
         }
+#ifdef ES_STAMP
+        if (L.stamp && tid == 0) {
+            st_[6] = __builtin_amdgcn_s_memrealtime();
+            st_[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+            unsigned long long* d = L.stamp + ((size_t)L.launch_id * 1024 + (blockIdx.y * gridDim.x + blockIdx.x)) * 8;
+            for (int k = 0; k < 8; ++k) d[k] = st_[k];
+        }
+#endif
         return;
     }
     if (ok_e) {
@@ -433,7 +460,18 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
         }
         out[(long)m_e * a.out_ld + n_e] = sres;
     }
+#ifdef ES_STAMP
+    if (L.stamp && tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) {
+        st_[6] = __builtin_amdgcn_s_memrealtime();
+        // XCC_ID (hwreg 20, 4 bits) | HW_ID (hwreg 4, 32 bits) << 32
+        st_[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+        unsigned long long* d = L.stamp + ((size_t)L.launch_id * 1024 + (blockIdx.y * gridDim.x + blockIdx.x)) * 8;
+        for (int k = 0; k < 8; ++k) d[k] = st_[k];
+    }
+#endif
 }
+
+#include "es_rows_x.h"
 
 __global__ void k_ddpm_update(const es_update_args a) {
 #pragma clang fp contract(off)
@@ -578,6 +616,16 @@ extern "C" int es_linear_rows_slices(const es_linear_args* a, int* kb_per_slice)
     kbps = (kbps + kalign - 1) / kalign * kalign;
     if (kbps >= nkb) { *kb_per_slice = nkb; return 1; }
     *kb_per_slice = kbps;
+    if (a->seg_slices) {
+        // round 5: slices never straddle two segments -- every segment (a multiple of 16 columns wide) is cut into
+        // ceil(width / (16 kbps)) slices of kbps k-blocks, the last one of a segment possibly shorter
+        int S = 0;
+        for (int s = 0; s < a->nseg; ++s) {
+            if (a->seg[s].width % 16) return -1;
+            S += (a->seg[s].width / 16 + kbps - 1) / kbps;
+        }
+        return S;
+    }
     return (nkb + kbps - 1) / kbps;
 }
 
@@ -596,6 +644,20 @@ extern "C" int es_linear_rows_auto_slices(int K, int N, int kalign_cols) {
     kbps = (kbps + kal - 1) / kal * kal;
     return kbps >= nkb ? 0 : kbps;
 }
+
+#ifdef ES_STAMP
+static unsigned long long* g_rows_stamp = nullptr;
+static int g_rows_launch_id = 0;
+static FILE* g_rows_log = nullptr;
+// stamps of every rows launch enqueued (or captured) from now on: slot = launch order; `log` (may be NULL): one line per launch
+extern "C" int es_debug_rows_stamp(void* p, const char* log) {
+    g_rows_stamp = (unsigned long long*)p;
+    g_rows_launch_id = 0;
+    if (g_rows_log) { fclose(g_rows_log); g_rows_log = nullptr; }
+    if (p && log) g_rows_log = fopen(log, "w");
+    return 0;
+}
+#endif
 
 namespace {
 struct RowsPrep { es_linear_args a; int S, kbps, nsmax, proc, nb; bool has_ln, csr, gepi; };
@@ -664,6 +726,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
     ES_REQUIRE(a.act != ES_ACT_GEGLU || (a.N % 16 == 0 && !a.res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
     int kbps = 0;
     const int S = es_linear_rows_slices(&a, &kbps);
+    ES_REQUIRE(S >= 1, "es_linear_rows_f32: segment-aligned slices need segment widths that are multiples of 16");
     ES_REQUIRE(S == 1 || (a.act == ES_ACT_NONE && nb == 1 && a.out_slab_stride >= a.M * a.out_ld),
                "es_linear_rows_f32: a K split (%d slices) needs no activation epilogue, no batching and out_slab_stride >= M * out_ld", S);
     int nsmax = 1;
@@ -681,6 +744,212 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
     out->a = a; out->S = S; out->kbps = kbps; out->nsmax = nsmax; out->proc = proc; out->nb = nb;
     out->has_ln = has_ln; out->csr = csr; out->gepi = a.act == ES_ACT_GEGLU;
     return 0;
+}
+
+// ---- k_rows_x dispatch (es_rows_x.h) ---------------------------------------------------------------------------------------------
+int g_rows_family = 1;       // 1 = k_rows_x where it applies (default), 0 = k_linear_rows only (es_rows_set_kernel_family: A/B tools)
+
+struct XPlan { int S, Jw, cut[XMAXS + 1], segof[XMAXS]; bool uniform; };
+
+// The K slices of a problem as k_rows_x wants them (every slice inside ONE segment); false = not a problem for k_rows_x
+bool x_plan(const RowsPrep& p, XPlan* xp) {
+    const es_linear_args& a = p.a;
+    if (p.nb != 1 || p.csr || a.K % 16) return false;
+    if (p.gepi && !p.has_ln) return false;
+    if (a.res_nslab > XMAXS || a.res2_nslab > XMAXS) return false;
+    int S = 0, koff = 0, maxn = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const es_seg& sg = a.seg[s];
+        if (sg.mode != ES_SEG_DIRECT && sg.mode != ES_SEG_GATHER) return false;
+        if (sg.pro != ES_PRO_NONE && sg.pro != ES_PRO_GN && sg.pro != ES_PRO_GN_SILU && sg.pro != ES_PRO_LN) return false;
+        if (sg.step || sg.nslab > 6 || sg.width % 16) return false;
+        if ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) && sg.gs < 4) return false;
+        koff += sg.width;
+    }
+    const int nkb = a.K / 16;
+    if (a.seg_slices) {
+        int kb = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const int w = a.seg[s].width / 16;
+            for (int c = 0; c < w; c += p.kbps) {
+                if (S >= XMAXS) return false;
+                xp->cut[S] = kb + c; xp->segof[S] = s;
+                const int n = (w - c < p.kbps) ? w - c : p.kbps;
+                maxn = n > maxn ? n : maxn;
+                ++S;
+            }
+            kb += w;
+        }
+        xp->cut[S] = nkb;
+    } else {
+        // legacy uniform cuts: usable when no slice straddles a segment boundary
+        S = p.S;
+        if (S > XMAXS) return false;
+        for (int i = 0; i < S; ++i) {
+            const int k0 = i * p.kbps, k1 = (i + 1) * p.kbps < nkb ? (i + 1) * p.kbps : nkb;
+            int so = -1, c0 = 0;
+            for (int s = 0; s < a.nseg; ++s) {
+                const int c1 = c0 + a.seg[s].width / 16;
+                if (k0 >= c0 && k1 <= c1) so = s;
+                c0 = c1;
+            }
+            if (so < 0) return false;
+            xp->cut[i] = k0; xp->segof[i] = so;
+            maxn = (k1 - k0) > maxn ? (k1 - k0) : maxn;
+        }
+        xp->cut[S] = nkb;
+    }
+    if (S != p.S) return false;
+    int Jw = (maxn + NKG - 1) / NKG;
+    bool gs32 = false;
+    for (int s = 0; s < a.nseg; ++s) gs32 = gs32 || ((a.seg[s].pro == ES_PRO_GN || a.seg[s].pro == ES_PRO_GN_SILU) && a.seg[s].gs == 32);
+    if (gs32 && (Jw & 1)) ++Jw;
+    xp->uniform = true;
+    for (int i = 0; i + 1 < S; ++i) xp->uniform = xp->uniform && (xp->cut[i + 1] - xp->cut[i] == xp->cut[1] - xp->cut[0]);
+    if (p.has_ln) {
+        if (S > 2 || S * Jw > 4 || p.nsmax > 2) return false;
+        if (S == 2 && xp->cut[2] - xp->cut[1] != xp->cut[1] - xp->cut[0]) return false;
+    } else if (Jw > 8) return false;
+    xp->S = S; xp->Jw = Jw;
+    return true;
+}
+
+void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
+    const es_linear_args& a = pr.a;
+    memset(&P, 0, sizeof(P));
+    P.wpack = a.wpack; P.bias = a.bias; P.res = a.res; P.res2 = a.res2; P.out = a.out;
+    P.res_step = a.res_step; P.res_step_stride = a.res_step_stride;
+    P.M = a.M; P.N = a.N; P.K = a.K; P.nkb_total = a.K / 16; P.S = xp.S | (((32768 + xp.S - 1) / xp.S) << 16); P.Jw = xp.Jw; P.act = a.act;
+    P.res_ld = a.res_ld; P.res_nslab = a.res_nslab > 1 ? a.res_nslab : 1; P.res_sstr = a.res_slab_stride;
+    P.res2_ld = a.res2_ld; P.res2_nslab = a.res2_nslab > 1 ? a.res2_nslab : 1; P.res2_sstr = a.res2_slab_stride;
+    P.out_ld = a.out_ld; P.out_sstr = a.out_slab_stride;
+    int segc0[3] = {0, 0, 0};
+    for (int s = 1; s < a.nseg; ++s) segc0[s] = segc0[s - 1] + a.seg[s - 1].width;
+    for (int i = 0; i < xp.S; ++i) {
+        const es_seg& sg = a.seg[xp.segof[i]];
+        XSlice& d = P.sl[i];
+        const int col = xp.cut[i] * 16 - segc0[xp.segof[i]];          // first column of the slice inside its segment
+        const bool ln = sg.pro == ES_PRO_LN;
+        d.a = sg.ptr + (ln ? 0 : col);
+        d.idx = sg.mode == ES_SEG_GATHER ? sg.idx : nullptr;
+        d.gamma = sg.gamma ? sg.gamma + (ln ? 0 : col) : nullptr;
+        d.beta = sg.beta ? sg.beta + (ln ? 0 : col) : nullptr;
+        d.ld = sg.ld; d.nslab = sg.nslab > 1 ? sg.nslab : 1; d.sstr = sg.slab_stride;
+        d.flags = (sg.mode == ES_SEG_GATHER ? 1 : 0) | ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) ? 2 : 0) |
+                  (sg.pro == ES_PRO_GN_SILU ? 4 : 0) | (ln ? 8 : 0) | (sg.pre_act == ES_ACT_RELU ? 16 : 0);
+        d.gs = sg.gs; d.eps = sg.eps; d.nkb = xp.cut[i + 1] - xp.cut[i]; d.kb0 = xp.cut[i];
+    }
+}
+
+template <int NP>
+int x_launch_np(const void* fn, const XLaunch<NP>& L, dim3 grid, es_stream stream) {
+    void* kargs[] = {(void*)&L};
+    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, 0, (hipStream_t)stream));
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// -1: not launched (the caller falls back to k_linear_rows)
+int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, int gx, int gy) {
+    const bool dry = n == 0;                              // n == 0: would pr[0] launch alone?  -2 = yes, -1 = no
+    if (dry) n = 1;
+    XPlan xp[3];
+    int jmax = 1, nsmax = 1, proc = 0;
+    bool has_ln = false;
+    for (int i = 0; i < n; ++i) {
+        if (!x_plan(pr[i], &xp[i])) return -1;
+        jmax = xp[i].Jw > jmax ? xp[i].Jw : jmax;
+        nsmax = pr[i].nsmax > nsmax ? pr[i].nsmax : nsmax;
+        proc = pr[i].proc > proc ? pr[i].proc : proc;
+        has_ln = has_ln || pr[i].has_ln;
+    }
+    if (proc > 1) return -1;
+    bool gather = false;
+    for (int i = 0; i < n; ++i) for (int sgi = 0; sgi < pr[i].a.nseg; ++sgi) gather = gather || pr[i].a.seg[sgi].mode == ES_SEG_GATHER;
+    // kernel classes by load budget (k-blocks per wave, slabs): (2, 6), (4, 2), (8, 1)
+    int cls = -1;
+    if (jmax <= 2 && nsmax <= 4) cls = 0;
+    else if (jmax <= 4 && nsmax <= 4) cls = 1;
+    else if (jmax <= 8 && nsmax <= 2) cls = 2;
+    const void* fn = nullptr;
+    dim3 grid;
+    int nt = 1;
+    if (has_ln) {
+        if (n != 1 || gather) return -1;
+        const RowsPrep& p0 = pr[0];
+        const bool nt2 = p0.gepi && xp[0].S == 1 && ((p0.a.N + 15) / 16) % 2 == 0;
+        nt = nt2 ? 2 : 1;
+        if (xp[0].S == 2) fn = (const void*)k_rows_x<2, 2, 2, 2, 1, true, 1>;
+        else fn = nt2 ? (const void*)k_rows_x<4, 2, 2, 1, 2, true, 1> : (const void*)k_rows_x<4, 2, 2, 1, 1, true, 1>;
+    } else {
+        if (cls < 0) return -1;
+        // [class][GroupNorm compiled in]; the third class (long single-segment K ranges: the feed-forward output product, the
+        // triple-row products of the GCNs) has no GroupNorm variant
+        static const void* const tab1[3][2] = {
+            {(const void*)k_rows_x<2, 4, 0, 1, 1, false, 1>, (const void*)k_rows_x<2, 4, 1, 1, 1, false, 1>},
+            {(const void*)k_rows_x<4, 4, 0, 1, 1, false, 1>, (const void*)k_rows_x<4, 4, 1, 1, 1, false, 1>},
+            {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 1>, nullptr}};
+        static const void* const tab3[3][2] = {
+            {(const void*)k_rows_x<2, 4, 0, 1, 1, false, 3>, (const void*)k_rows_x<2, 4, 1, 1, 1, false, 3>},
+            {(const void*)k_rows_x<4, 4, 0, 1, 1, false, 3>, (const void*)k_rows_x<4, 4, 1, 1, 1, false, 3>},
+            {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 3>, nullptr}};
+        // two column tiles per workgroup (timing-only: the per-output arithmetic does not change): half the workgroups re-read the A slabs
+        static const void* const tab1_nt2[2][2] = {
+            {(const void*)k_rows_x<2, 4, 0, 1, 2, false, 1>, (const void*)k_rows_x<2, 4, 1, 1, 2, false, 1>},
+            {(const void*)k_rows_x<4, 4, 0, 1, 2, false, 1>, (const void*)k_rows_x<4, 4, 1, 1, 2, false, 1>}};
+        static const char* nt_env = getenv("ES_X_NT");
+        fn = (n == 1 ? tab1 : tab3)[cls][proc];
+        if (n == 1 && !gather && cls < 2 && nt_env && atoi(nt_env) == 2 && ((pr[0].a.N + 15) / 16) % 2 == 0 && pr[0].a.N >= 256) {
+            fn = tab1_nt2[cls][proc];
+            nt = 2;
+        }
+        if (gather) {        // gathered rows: the triple-row products of the GCNs (plain operands)
+            if (proc != 0 || nsmax > 2 || jmax > 8) return -1;
+            fn = n == 1 ? (const void*)k_rows_x<8, 2, 0, 1, 1, false, 1, true> : (const void*)k_rows_x<8, 2, 0, 1, 1, false, 3, true>;
+        }
+        if (!fn) return -1;
+    }
+    if (dry) return -2;
+    int launch_id = 0;
+    (void)launch_id;
+#ifdef ES_STAMP
+    launch_id = g_rows_stamp ? g_rows_launch_id++ : 0;
+#endif
+    if (n == 1) {
+        XLaunch<1> L;
+        memset(&L, 0, sizeof(L));
+        x_fill(L.p[0], pr[0], xp[0]);
+        L.n = 1;
+        grid = dim3((unsigned)(((pr[0].a.N + 15) / 16) / nt * xp[0].S), (unsigned)((pr[0].a.M + MT - 1) / MT), 1);
+        L.p[0].ny = (int)grid.y; L.p[0].xw = (int)grid.x;
+        static const char* xcd_env = getenv("ES_X_XCD");                     // timing-only: XCD-aware tile order (k_rows_x)
+        if (xcd_env && atoi(xcd_env) == 1 && (xp[0].S == 2 || xp[0].S == 4 || xp[0].S == 8) && grid.y <= 2 && (grid.x * grid.y) % 8 == 0 &&
+            (grid.x / xp[0].S) % (8 / xp[0].S) == 0)
+            L.p[0].act |= 256;
+        if (grid.x >= 5461) return -1;
+#ifdef ES_STAMP
+        L.stamp = g_rows_stamp; L.launch_id = launch_id;
+        if (g_rows_stamp && g_rows_log) fprintf(g_rows_log, "%d %d %d %d  x M%d K%d N%d S%d Jw%d ns%d proc%d%s\n", launch_id, (int)grid.x, (int)(grid.y * grid.z), n,
+                                                pr[0].a.M, pr[0].a.K, pr[0].a.N, xp[0].S, xp[0].Jw, nsmax, proc, has_ln ? " ln" : "");
+#endif
+        return x_launch_np<1>(fn, L, grid, stream);
+    }
+    if (gx >= 5461) return -1;                       // (the slice lookup of a multi-problem launch divides by multiplication)
+    XLaunch<3> L;
+    memset(&L, 0, sizeof(L));
+    for (int i = 0; i < n; ++i) {
+        x_fill(L.p[i], pr[i], xp[i]);
+        L.p[i].wg0 = RL.wg0[i]; L.p[i].ny = RL.ny[i]; L.p[i].xw = RL.xw[i]; L.p[i].fw = RL.fw[i];
+    }
+    for (int i = n; i < 3; ++i) L.p[i].wg0 = 0x7fffffff;
+    L.n = n;
+    grid = dim3((unsigned)gx, (unsigned)gy, 1);
+#ifdef ES_STAMP
+    L.stamp = g_rows_stamp; L.launch_id = launch_id;
+    if (g_rows_stamp && g_rows_log) fprintf(g_rows_log, "%d %d %d %d  x M%d K%d N%d S%d Jw%d ns%d proc%d multi\n", launch_id, (int)grid.x, (int)grid.y, n,
+                                            pr[0].a.M, pr[0].a.K, pr[0].a.N, xp[0].S, xp[0].Jw, nsmax, proc);
+#endif
+    return x_launch_np<3>(fn, L, grid, stream);
 }
 
 int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
@@ -714,6 +983,28 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     static const char* nt2_env = getenv("ES_ROWS_NT2");
     const bool nt2 = n == 1 && has_ln && gepi && pr[0].nb == 1 && pr[0].S == 1 && ((pr[0].a.N + 15) / 16) % 2 == 0 &&
                      !(nt2_env && atoi(nt2_env) == 0);
+    if (g_rows_family == 1) {
+        const int rc = x_launch(pr, n, stream, L, gx, gy);
+        if (rc >= 0) return rc;
+        if (n > 1) {
+            // a group k_rows_x does not take as a whole: every problem takes the route it would take alone (a product's bits must not
+            // depend on what it is fused with) -- unless none of them is a k_rows_x problem, then the group stays one k_linear_rows launch
+            bool any = false;
+            for (int i = 0; i < n; ++i) { XPlan xp; any = any || (x_plan(pr[i], &xp) && x_launch(pr + i, 0, stream, L, 0, 0) == -2); }
+            if (any) {
+                for (int i = 0; i < n; ++i) if (int rc1 = rows_launch(pr + i, 1, stream)) return rc1;
+                return 0;
+            }
+        }
+    }
+    // k_linear_rows cuts K uniformly: segment-aligned cuts must coincide with that (every segment but the last a multiple of the slice)
+    for (int i = 0; i < n; ++i) {
+        const es_linear_args& a = pr[i].a;
+        if (!a.seg_slices || pr[i].S == 1) continue;
+        for (int sgi = 0; sgi + 1 < a.nseg; ++sgi)
+            ES_REQUIRE((a.seg[sgi].width / 16) % pr[i].kbps == 0,
+                       "es_linear_rows_f32: segment-aligned slices of %d k-blocks do not tile segment %d (%d columns) and the problem is not one k_rows_x handles", pr[i].kbps, sgi, a.seg[sgi].width);
+    }
     if (nt2) gx /= 2;
     const size_t lds = (size_t)(MT * L.ldx + (nt2 ? 2 : 1) * NWAVE * 256) * sizeof(float);
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)pr[0].nb);
@@ -768,12 +1059,24 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     }
     static const char* dbg_env = getenv("ES_ROWS_DBG");          // ablation switches of tools/microbench_rows.py (1: no weight loads, 2: no staging)
     L.dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifdef ES_STAMP
+    L.stamp = g_rows_stamp;
+    L.launch_id = g_rows_stamp ? g_rows_launch_id++ : 0;
+    if (g_rows_stamp && g_rows_log) fprintf(g_rows_log, "%d %d %d %d  M%d K%d N%d S%d ns%d proc%d%s%s%s\n", L.launch_id, (int)grid.x, (int)grid.y, n,
+                                            pr[0].a.M, pr[0].a.K, pr[0].a.N, pr[0].S, nsmax, proc, has_ln ? " ln" : "", csr ? " csr" : "", u1 ? " u1" : "");
+#endif
     void* kargs[] = {(void*)&L};
     ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, lds, (hipStream_t)stream));
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
 }  // namespace
+
+extern "C" int es_rows_set_kernel_family(int family) {
+    ES_REQUIRE(family == 0 || family == 1, "es_rows_set_kernel_family: %d", family);
+    g_rows_family = family;
+    return 0;
+}
 
 extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) {
     RowsPrep pr;

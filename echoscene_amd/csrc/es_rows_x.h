@@ -1,0 +1,380 @@
+// Round 5: the rows product as ONE short instruction stream (included by es_rows.hip inside its anonymous namespace).
+//
+// What round 5 measured first (profiles/r05_rows_stamps_before.txt, tools/probes/probe_l2_persist.hip, probe_icache.hip):
+//   * a launch of the layout step takes 5.4 us on average: 1.0 launch boundary, 0.6 kernarg read, 2.4-3.6 "staging" in k_linear_rows;
+//   * memory is NOT what the staging waits for: a cold 1 KiB wave load returns in 0.43 us, an L2 hit in 0.1 us, and L2 contents survive
+//     kernel boundaries;
+//   * a cold instruction cache costs nothing measurable either (the fetch streams), but every wave64 VALU instruction costs ~5 clocks
+//     of issue: 1000 instructions = 2 us.  k_linear_rows (and the first straight-line rewrite of this round, k_rows_frag: generic
+//     segment selects, 1150 instructions) are INSTRUCTION-COUNT bound.
+// So this kernel is built to execute few instructions:
+//   * the host cuts K so that a slice never straddles two segments and hands every slice its own 64-byte descriptor (base pointer at
+//     the slice's first column, leading dimension, slab count / stride, prologue, affine pointers): a workgroup reads ONE descriptor,
+//     no per-block segment selects, no generic loops;
+//   * no LDS staging of the A operand: a wave loads the MFMA A fragments of its k-blocks straight from global memory -- ONE per-lane
+//     byte offset per wave, blocks and slabs are immediate / scalar offsets of the buffer loads -- and applies the prologue in
+//     registers (a GroupNorm group of 16 channels = the 4 lanes of one row and k-block: two v_permlane*_swap steps);
+//   * every load (weights first: they are the HBM misses) is issued before the first wait; the only workgroup barrier is the one in
+//     front of the fixed-order reduction over the 8 waves (LayerNorm: one more for each of the two row statistics);
+//   * two accumulators per wave (even / odd k-steps) halve the dependent MFMA chain.
+// Arithmetic: exact fp32 products on v_mfma_f32_16x16x4_f32; K order = (wave, k-block, k-step parity), a function of (K, N, slices)
+// only, never of M: per-row results do not depend on the batch.
+//
+// Not handled here (k_linear_rows keeps them): the CSR poolings, SiLU / GEGLU prologues (one-off table builds, tests), batched
+// launches, step-indexed segments, slices that straddle segments.
+
+struct XSlice {                                   // 64 bytes
+    const float* a;                               // A at the slice's first column (LayerNorm: at column 0 of the row)
+    const int32_t* idx;                           // row gather index or NULL
+    const float* gamma; const float* beta;        // affine of the norm prologue at the slice's first channel (LayerNorm: channel 0)
+    int32_t ld, nslab, sstr, flags;               // flags: 1 gather, 2 GroupNorm, 4 SiLU after the norm, 8 LayerNorm, 16 ReLU on the slab sum
+    int32_t gs; float eps; int32_t nkb, kb0;      // k-blocks of the slice, first k-block (index into the weight image)
+};
+constexpr int XMAXS = 6;
+struct XProb {                                    // 128 + 6 * 64 = 512 bytes
+    const float* wpack; const float* bias; const float* res; const float* res2; float* out; const int32_t* res_step;
+    int32_t M, N, nkb_total, S;
+    int32_t res_ld, res_nslab, res_sstr, res2_ld;
+    int32_t res2_nslab, res2_sstr, out_ld, out_sstr;
+    int32_t wg0, ny, xw, fw;
+    int32_t act, res_step_stride, Jw, K;
+    XSlice sl[XMAXS];
+};
+template <int NP>
+struct XLaunch {
+    XProb p[NP];
+    int32_t n, pad;
+#ifdef ES_STAMP
+    unsigned long long* stamp;
+    int32_t launch_id, pad2;
+#endif
+};
+
+__device__ __forceinline__ float quad_sum(float v) {          // sum over the 4 lanes (i16, q = 0..3) of a row: same value in all four
+    float e, o;
+    es_pair16(v, e, o); v = e + o;
+    es_pair32(v, e, o); return e + o;
+}
+__device__ __forceinline__ float pair_sum(float v) {          // lanes q and q ^ 1
+    float e, o;
+    es_pair16(v, e, o); return e + o;
+}
+
+// Buffer descriptor over "everything behind p" (2 GiB window); p == NULL -> zero records: loads return 0 without touching memory.
+constexpr unsigned XOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, p ? (int)XOOB : 0, 0x00020000);      // (p is wave-uniform at every call site)
+}
+__device__ __forceinline__ f4 x_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f4 x_ld4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));  // aux 2 = nt: weights are read once
+}
+__device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// JW: bound of the k-blocks per wave and slice; NS: bound of the slab counts; PROC 0: raw / ReLU'd operands, 1: + GroupNorm(+SiLU),
+// 2: LayerNorm over the row (SLN = slices the row is cut into: the statistics need all of them); NT: column tiles per workgroup;
+// NP: problems the launch may carry (1: single-problem launches read a 3x smaller argument block and skip the problem lookup).
+// GATHER: rows may be gathered through an index (a dependent round trip in front of the A loads: its own variants).
+template <int JW, int NS, int PROC, int SLN, int NT, bool GEGLU_EPI, int NP, bool GATHER = false>
+__global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
+    __shared__ __attribute__((aligned(16))) float red[NT * NKG * 256];
+    __shared__ float lnx[PROC == 2 ? 2 * NKG * 16 : 1];
+    static_assert(PROC == 2 || SLN == 1, "k_rows_x: only LayerNorm reads foreign slices");
+#ifdef ES_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    st_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    kernarg_warm<sizeof(XLaunch<NP>)>();
+    ES_RSTAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pi = 0;
+    if (NP > 1) pi = (L.n > 1 && (int)blockIdx.x >= L.p[1].wg0 ? 1 : 0) + (L.n > 2 && (int)blockIdx.x >= L.p[NP > 2 ? 2 : 0].wg0 ? 1 : 0);
+    const XProb& PP = L.p[pi];
+    struct XHdr { const float* wpack; const float* bias; const float* res; const float* res2; float* out; const int32_t* res_step;
+                  int32_t M, N, nkb_total, S, res_ld, res_nslab, res_sstr, res2_ld, res2_nslab, res2_sstr, out_ld, out_sstr, wg0, ny, xw, fw,
+                          act, res_step_stride, Jw, K; };
+    static_assert(sizeof(XHdr) == 128 && sizeof(XProb) == 128 + XMAXS * 64, "k_rows_x: descriptor layout");
+    const XHdr P = *(const XHdr*)&PP;                      // by VALUE: the whole header in two wide scalar loads, here
+    // tiles of a problem = (column tile, slice) pairs along blockIdx.x, slice fastest, from wg0 on; a problem with fewer row tiles than
+    // its (multi-problem) launch is folded over all grid rows (see RowsLaunch)
+    int bx = (int)blockIdx.x - P.wg0, by = (int)blockIdx.y;
+    const int S = P.S & 0xffff;                            // (high half: ceil(2^15 / S))
+    if (NP > 1 && P.fw > 0) {
+        const int v = by * P.fw + bx, xw = P.xw;
+        if (v >= xw * P.ny) return;
+        by = v / xw;
+        bx = v - by * xw;
+    } else if (by >= P.ny) return;
+    // bx / S without the integer-division sequence: floor(bx * ceil(2^15 / S) / 2^15) is exact for S <= 6, bx < 5461 (host-checked)
+    int ct = (int)(((unsigned)bx * ((unsigned)P.S >> 16)) >> 15);
+    int slice = bx - ct * S;
+    if (NP == 1 && (P.act & 256)) {
+        // XCD-aware tile order (speed only; host: S in {2, 4, 8}, at most two row tiles, a multiple of 8 workgroups): workgroup id runs on
+        // XCD id % 8 (+ a constant), so the 8 / S XCDs {slice * 8 / S ...} own ONE K slice -- an XCD reads 1 / S of the A slabs over the fabric
+        const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x), c = id & 7, r = id >> 3;
+        const int lg = S == 2 ? 2 : S == 4 ? 1 : 0;
+        const int nct = (int)gridDim.x >> (3 - lg);                          // gridDim.x = column tiles x S
+        const int t = (r << lg) | (c & ((1 << lg) - 1));
+        slice = c >> lg;
+        by = t >= nct ? 1 : 0;
+        ct = t - by * nct;
+    }
+    bx = ct;
+    const XSlice SL = PP.sl[slice];                        // by VALUE: one wide scalar load
+    const int Jw = P.Jw, M = P.M, N = P.N, nkb_total = P.nkb_total;
+    const int nt = bx * NT;
+    const int m0 = by * MT;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int m = m0 + i16;
+    const int mc = m < M ? m : M - 1;
+    const int nj = SL.nkb - wave * Jw;                    // k-blocks of this wave inside the slice (may be <= 0 or > Jw)
+
+    // (0) gather: the row index first (a dependent round trip in front of the A loads)
+    int row = mc;
+    if (GATHER && (SL.flags & 1)) {
+        row = SL.idx[mc];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(row) :: "memory");       // (before the weights are issued: vmcnt retires in order)
+    }
+
+    // (1) weights (the HBM misses): the wave's k-blocks x NT tiles, 1 KiB each, contiguous in the packed image
+    const __amdgpu_buffer_rsrc_t rW = x_rsrc((const f4*)P.wpack + ((size_t)nt * nkb_total + SL.kb0 + wave * Jw) * 64);
+    f4 bf[NT][JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        if (j < Jw && j < nj) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[t][j] = x_ld4_nt(rW, (unsigned)lane * 16u + (unsigned)j * 1024u, (unsigned)(t * nkb_total) * 1024u);
+        }
+    }
+
+    // (2) A fragments: lane (i16, q) = columns [16 kb + 4 q, + 4) of its row, every slab of the producer.  LayerNorm: the blocks at the
+    // wave's position in EVERY slice (block v = (slice v / JW, position v % JW)); own blocks are those of slice `slice`.
+    constexpr int NB = JW * SLN;
+    f4 av[NB][NS], gav[PROC >= 1 ? JW : 1], bev[PROC >= 1 ? JW : 1];
+    const __amdgpu_buffer_rsrc_t rA = x_rsrc(SL.a);
+    const unsigned colw = (unsigned)(wave * Jw * 16 + 4 * q);                 // first column of the lane inside the slice
+    const unsigned voff = ((unsigned)row * (unsigned)SL.ld + colw) * 4u;
+    const unsigned sstr4 = (unsigned)SL.sstr * 4u;
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+        const int j = v % JW, sl = v / JW;
+        if (j < Jw && j < nj && sl < S) {
+            const unsigned so = PROC == 2 ? (unsigned)(sl * SL.nkb) * 64u : 0u;     // LayerNorm: SL.a is column 0, slices are nkb blocks apart
+            av[v][0] = x_ld4(rA, voff + (unsigned)j * 64u, so);
+#pragma unroll
+            for (int u = 1; u < NS; ++u) if (u < SL.nslab) av[v][u] = x_ld4(rA, voff + (unsigned)j * 64u, so + (unsigned)u * sstr4);
+        }
+    }
+    if (PROC >= 1 && (SL.flags & (2 | 8))) {
+        const __amdgpu_buffer_rsrc_t rG = x_rsrc(SL.gamma), rB = x_rsrc(SL.beta);
+        const unsigned go = colw * 4u, gso = PROC == 2 ? (unsigned)(slice * SL.nkb) * 64u : 0u;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (j < Jw && j < nj) { gav[j] = x_ld4(rG, go + (unsigned)j * 64u, gso); bev[j] = x_ld4(rB, go + (unsigned)j * 64u, gso); }
+        }
+    }
+
+    ES_RSTAMP(2);
+
+    // (4) prologue in registers
+    f4 a[NB];
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+        const int j = v % JW, sl = v / JW;
+        a[v] = f4{0.f, 0.f, 0.f, 0.f};
+        if (j < Jw && j < nj && sl < S) {
+            f4 y = av[v][0];
+#pragma unroll
+            for (int u = 1; u < NS; ++u) if (u < SL.nslab) y += av[v][u];
+            if (SL.flags & 16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+            }
+            a[v] = y;
+        }
+    }
+    if (PROC == 1 && (SL.flags & 2)) {
+        const int gs = SL.gs;
+        const float inv_gs = __builtin_amdgcn_rcpf((float)gs);      // gs is a power of two: exact
+        f4 o[JW];
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (!(j < Jw && j < nj)) continue;                     // wave-uniform
+            const f4 y = a[j];
+            float sm = (y[0] + y[1]) + (y[2] + y[3]);
+            if (gs >= 8) sm = pair_sum(sm);
+            if (gs >= 16) { float e, od; es_pair32(sm, e, od); sm = e + od; }
+            if (gs >= 32) {                                      // two adjacent k-blocks of this wave (Jw is even then)
+                const f4 z = a[(j ^ 1) < JW ? (j ^ 1) : j];
+                float s2_ = (z[0] + z[1]) + (z[2] + z[3]);
+                s2_ = quad_sum(s2_);
+                sm = (j & 1) ? s2_ + sm : sm + s2_;
+            }
+            const float mean = sm * inv_gs;
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = y[e] - mean; sq += d * d; }
+            if (gs >= 8) sq = pair_sum(sq);
+            if (gs >= 16) { float e, od; es_pair32(sq, e, od); sq = e + od; }
+            if (gs >= 32) {
+                const f4 z = a[(j ^ 1) < JW ? (j ^ 1) : j];
+                float q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = z[e] - mean; q2 += d * d; }
+                q2 = quad_sum(q2);
+                sq = (j & 1) ? q2 + sq : sq + q2;
+            }
+            const float rstd = __builtin_amdgcn_rsqf(sq * inv_gs + SL.eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float zz = (y[e] - mean) * rstd * gav[j][e] + bev[j][e];
+                if (SL.flags & 4) zz = es_silu(zz);
+                o[j][e] = zz;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JW; ++j) if (j < Jw && j < nj) a[j] = o[j];      // (a[] stayed raw for the partner block of a 32-channel group)
+    }
+    if (PROC == 2) {
+        // LayerNorm over the whole row: the 8 waves hold all k-blocks of the row between them
+        float sm = 0.f;
+#pragma unroll
+        for (int v = 0; v < NB; ++v) sm += (a[v][0] + a[v][1]) + (a[v][2] + a[v][3]);      // (blocks that do not exist are zeros)
+        sm = quad_sum(sm);
+        if (q == 0) lnx[wave * 16 + i16] = sm;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NKG; ++w) tot += lnx[w * 16 + i16];
+        const float inv_k = 1.0f / (float)P.K;
+        const float mean = tot * inv_k;
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NB; ++v) {
+            const int j = v % JW, sl = v / JW;
+            if (j < Jw && j < nj && sl < S) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mean; sq += d * d; }
+            }
+        }
+        sq = quad_sum(sq);
+        if (q == 0) lnx[NKG * 16 + wave * 16 + i16] = sq;
+        __syncthreads();
+        float tq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NKG; ++w) tq += lnx[NKG * 16 + w * 16 + i16];
+        const float rstd = __builtin_amdgcn_rsqf(tq * inv_k + SL.eps);
+        // the own slice's blocks, normalised, move to a[0 .. JW)
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            f4 y = a[j];
+#pragma unroll
+            for (int sl = 1; sl < SLN; ++sl) if (slice == sl) y = a[sl * JW + j];
+            if (j < Jw && j < nj) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * gav[j][e] + bev[j][e];
+            }
+            a[j] = y;
+        }
+    }
+    // (4b) epilogue operands, issued only now: only the slice-0 workgroups add bias and residuals, nothing needs them before the
+    // reduction, and vmcnt retires in order -- issued with the A loads they would sit in front of the prologue's wait
+    const int ml = (tid >> 4) & 15, nl = tid & 15;
+    const int te = NT > 1 ? (tid >> 8) : 0;
+    const int nt_e = nt + te;
+    const int n_e = nt_e * 16 + nl, m_e = m0 + ml;
+    const int act = P.act & 255;
+    const bool geglu = GEGLU_EPI && act == ES_ACT_GEGLU;
+    const int nres = geglu ? nt_e * 8 + nl : n_e;
+    const bool first = slice == 0;
+    const bool ok_e = tid < 256 * NT && m_e < M && n_e < N;
+    const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
+    float e_res = 0.f, e_res2 = 0.f, e_bias = 0.f;
+    float rr1[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rr2[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (first) {
+        if (P.res) {
+            const float* rp = P.res;
+            // (the step counter through the scalar cache: a vector load here would wait for every load issued above)
+            if (P.res_step) rp += (long)(*(const __attribute__((address_space(4))) int32_t*)(unsigned long)P.res_step) * P.res_step_stride;
+            const __amdgpu_buffer_rsrc_t rR = x_rsrc(rp);
+            const unsigned ro = ok_res ? ((unsigned)m_e * (unsigned)P.res_ld + (unsigned)nres) * 4u : XOOB;
+            rr1[0] = x_ld1(rR, ro, 0);
+#pragma unroll
+            for (int u = 1; u < XMAXS; ++u) if (u < P.res_nslab) rr1[u] = x_ld1(rR, ro, (unsigned)(u * P.res_sstr) * 4u);
+        }
+        if (P.res2) {
+            const __amdgpu_buffer_rsrc_t rR = x_rsrc(P.res2);
+            const unsigned ro = ok_res ? ((unsigned)m_e * (unsigned)P.res2_ld + (unsigned)nres) * 4u : XOOB;
+            rr2[0] = x_ld1(rR, ro, 0);
+#pragma unroll
+            for (int u = 1; u < XMAXS; ++u) if (u < P.res2_nslab) rr2[u] = x_ld1(rR, ro, (unsigned)(u * P.res2_sstr) * 4u);
+        }
+        if (P.bias) e_bias = x_ld1(x_rsrc(P.bias), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
+    }
+    ES_RSTAMP(3);
+
+    // (5) products: two accumulators (even / odd k-steps), combined once
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (j < Jw && j < nj) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], bf[t][j][0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], bf[t][j][1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], bf[t][j][2], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], bf[t][j][3], c1, 0, 0, 0);
+            }
+        }
+        acc[t] = c0 + c1;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *(f4*)&red[(t * NKG + wave) * 256 + lane * 4] = acc[t];
+    ES_RSTAMP(4);
+    __syncthreads();
+    ES_RSTAMP(5);
+    // D layout of mfma 16x16: lane = (row >> 2) * 16 + col holds D[row][col] in register row & 3
+    const int off = ((ml >> 2) * 16 + nl) * 4 + (ml & 3);
+    float sres = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKG; ++w) sres += red[(te * NKG + w) * 256 + off];
+    if (first) {
+        e_res = rr1[0]; e_res2 = rr2[0];
+#pragma unroll
+        for (int u = 1; u < XMAXS; ++u) { if (u < P.res_nslab) e_res += rr1[u]; if (u < P.res2_nslab) e_res2 += rr2[u]; }
+    }
+    float* out = P.out + (long)slice * P.out_sstr;
+    if (GEGLU_EPI && geglu) {
+        // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8 * nt_e + nl, lane nl + 8 its gate
+        float sb = sres + e_bias;
+        const float gate = __shfl_xor(sb, 8, 16);
+        if (ok_res) out[(long)m_e * P.out_ld + nres] = sb * es_gelu(gate) + e_res;
+    } else if (ok_e) {
+        if (first) {
+            sres += e_bias;
+            if (act == ES_ACT_RELU) sres = fmaxf(sres, 0.f);
+            else if (act == ES_ACT_SILU) sres = es_silu(sres);
+            else if (act == ES_ACT_SIGMOID) sres = 1.0f / (1.0f + expf(-sres));
+            sres += e_res;
+            sres += e_res2;
+        }
+        out[(long)m_e * P.out_ld + n_e] = sres;
+    }
+#ifdef ES_STAMP
+    if (L.stamp && tid == 0) {
+        const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (wg < 1024) {
+            st_[6] = __builtin_amdgcn_s_memrealtime();
+            st_[7] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+            unsigned long long* d = L.stamp + ((size_t)L.launch_id * 1024 + wg) * 8;
+            for (int k = 0; k < 8; ++k) d[k] = st_[k];
+        }
+    }
+#endif
+}

@@ -230,7 +230,7 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
                     v.push_back(b + f);
             }
             for (size_t f : {ES_PTR(linear.wpack), ES_PTR(linear.bias), ES_PTR(linear.gamma), ES_PTR(linear.beta), ES_PTR(linear.res),
-                             ES_PTR(linear.res2), ES_PTR(linear.out)})
+                             ES_PTR(linear.res2), ES_PTR(linear.out), ES_PTR(linear.res_step)})
                 v.push_back(f);
             break;
         case ES_OP_DDPM: case ES_OP_DDIM:

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libechoscene_hip.so')
+# ES_LIB_TAG: an instrumented build of the same sources (tools/: `_stamp` = phase stamps, echoscene_amd/build.py); never set in product use
+LIB_PATH = os.path.join(HERE, 'libechoscene_hip%s.so' % os.environ.get('ES_LIB_TAG', ''))
 
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p
@@ -40,7 +41,8 @@ class LinearArgs(C.Structure):
                 ('res2', C.c_void_p), ('res2_ld', C.c_int32), ('res2_nslab', C.c_int32), ('res2_slab_stride', C.c_int32),
                 ('out', C.c_void_p),
                 ('out_ld', C.c_int32), ('nbatch', C.c_int32), ('a_bstride', C.c_int32), ('out_bstride', C.c_int32),
-                ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32), ('fuse_next', C.c_int32)]
+                ('kb_per_slice', C.c_int32), ('out_slab_stride', C.c_int32), ('fuse_next', C.c_int32),
+                ('res_step', C.c_void_p), ('res_step_stride', C.c_int32), ('seg_slices', C.c_int32)]
 
 
 class UpdateArgs(C.Structure):
@@ -133,6 +135,7 @@ EXPORTS = {
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_linear_rows_multi_f32': (C.c_int, [C.POINTER(C.POINTER(LinearArgs)), C.c_int, C.c_void_p]),
+    'es_rows_set_kernel_family': (C.c_int, [C.c_int]),
     'es_linear_rows_slices': (C.c_int, [C.POINTER(LinearArgs), C.POINTER(C.c_int)]),
     'es_linear_rows_auto_slices': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),
@@ -202,7 +205,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 6:
+        if L.es_abi_version() != 7:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

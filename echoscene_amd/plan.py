@@ -32,6 +32,36 @@ ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's laun
 ROWS_RIDE = 2
 
 
+# Round 5: the K cuts of a rows product (planner constants: they decide where an fp32 sum is cut, i.e. the bits; A/B tools set the attributes).
+# A consumer workgroup loads its 16-row A slice once per slab of the producer, whatever the slice count: per-workgroup A bytes are
+# 64 x K and the L2 -> L1 traffic of a launch is that times its workgroups (round-5 stamps: a launch with 384 workgroups spends 1.5 us
+# ISSUING loads) -- so at most one workgroup per CU and at most 4 slabs.
+ROWS_MAX_SLABS = 4
+ROWS_MAX_WGS = 256
+
+
+def seg_aligned_kbps(seg_widths, K, N, kalign_cols=16):
+    """k-blocks (16 columns) per K slice of a rows product whose output may be a slab tensor -- round 5 rule: slices never straddle two
+    segments (the low-latency kernel k_rows_x reads ONE segment per workgroup): every segment is cut into ceil(width / slice) slices.
+    The smallest slice (a multiple of the largest GroupNorm group, at least 128 columns) that keeps the slab count <= ROWS_MAX_SLABS and
+    the workgroups of two 16-row tiles <= ROWS_MAX_WGS.  A function of the segment widths and N only -- never of M.  0 = one slice."""
+    if K % 16 or any(w % 16 for w in seg_widths):
+        return 0
+    wk = [w // 16 for w in seg_widths]
+    kal = max(1, kalign_cols // 16)
+    nct = (N + 15) // 16
+    smax = min(ROWS_MAX_SLABS, ROWS_MAX_WGS // (2 * nct))
+    if smax < 2:
+        return 0
+    for kbps in range(8, max(wk) + 1):
+        if kbps % kal:
+            continue
+        S = sum((w + kbps - 1) // kbps for w in wk)
+        if S <= smax:
+            return kbps if S >= 2 else 0
+    return 0
+
+
 class View:
     """Pointer + leading dimension into a device matrix (column slices without copies).
     ``nslab`` > 1: a SLAB tensor -- the split-K output of a rows launch, whose value is the fixed-order sum of ``nslab``
@@ -357,8 +387,9 @@ class Builder:
                 else:
                     kal = max([sg.gs for sg in segs if sg.pro in (hip.PRO_GN, hip.PRO_GN_SILU)] +
                               ([pl.K // 32] if prologue in (hip.PRO_GN, hip.PRO_GN_SILU) else []) + [16])
-                    kbps = hip.lib().es_linear_rows_auto_slices(pl.K, pl.N, kal)
+                    kbps = seg_aligned_kbps([sg.width for sg in segs], pl.K, pl.N, kal)
                 a.kb_per_slice = kbps
+                a.seg_slices = 1 if all(sg.width % 16 == 0 for sg in segs) else 0
                 got = C.c_int(0)
                 S = hip.lib().es_linear_rows_slices(C.byref(a), C.byref(got))
                 a.kb_per_slice = got.value if S > 1 else 0
@@ -699,16 +730,19 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False, rider=Non
             b.linear([seg(hid)], L['wn_w'], T, wts, act=hip.ACT_SIGMOID)
         mode = {'avg': hip.SEG_CSRMEAN, 'sum': hip.SEG_CSRSUM, 'wAvg': hip.SEG_CSRWAVG}[pooling]
         n1 = b.linear([seg(View(t2.t, col=0, ld=W2, width=H), mode, idx=ptr, ent_row=rows, ent_off=offs, ent_wt=wts)],
-                      L['n2a'], O, fuse_next=need_newp)                                      # relu deferred
+                      L['n2a'], O)                                                           # relu deferred
+        dst = out if (last and out is not None) else View(b.buf(O, Dout))
+        if proj is not None:
+            b.join(2)
+        # net2's second Linear and the predicate projection (it needs net1's predicate columns and the layer's predicates, nothing of
+        # net2) are independent: ONE launch.  (Round 5: the projection sat on the pooling launch before; a fused group takes ONE kernel
+        # family, the pooling is k_linear_rows', and a product must take the same route -- the same bits -- whatever it is fused with.)
+        b.linear([seg(n1, pre_act=hip.ACT_RELU)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj, fuse_next=need_newp)
         if need_newp:
             newp = View(b.buf(T, Dp))
             b.linear([seg(pred, width=Dp)], L['projp'], T, newp, res=View(t2.t, col=H, ld=W2, width=Dp), lane=2)
         elif not has_proj:
             newp = View(t2.t, col=H, ld=W2, width=Dp)
-        dst = out if (last and out is not None) else View(b.buf(O, Dout))
-        if proj is not None:
-            b.join(2)
-        b.linear([seg(n1, pre_act=hip.ACT_RELU)], L['n2b'], O, dst, act=hip.ACT_RELU, res=proj)
         b.ride(rider)
         obj, Dobj = dst, Dout
         if not last or want_pred:

@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 6
+#define ES_ABI_VERSION 7
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -117,6 +117,15 @@ typedef struct es_linear_args {
      * projection of a GraphTripleConv layer, model/graph.py:146-211) -- the runtime launches them as ONE grid
      * (es_linear_rows_multi_f32; up to 3 problems), one dependent launch less per pair.  Ignored by es_linear_rows_f32 itself. */
     int32_t fuse_next;
+    /* round 5: the residual may be a row of a per-schedule table selected by the device step counter -- res + (*res_step) *
+     * res_step_stride floats (with res_ld = 0 the row is broadcast over the M rows): the 22 ResBlock time projections of the layout
+     * denoiser are read in place by their consumers instead of being copied out by a row-select launch every step.  NULL = off. */
+    const int32_t* res_step;
+    int32_t res_step_stride;
+    /* round 5: 1 = the K slices never straddle two segments -- every segment (a multiple of 16 columns wide) is cut into
+     * ceil(width / (16 kb_per_slice)) slices of kb_per_slice k-blocks (the last slice of a segment may be shorter); the slab count is
+     * es_linear_rows_slices().  What the low-latency kernel of round 5 (k_rows_x) needs: one workgroup reads ONE segment. */
+    int32_t seg_slices;
 } es_linear_args;
 
 /* host-side helper: number of floats of the packed image of W[N,K], and the packing itself
@@ -132,6 +141,11 @@ int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int 
 int es_linear_rows_f32(const es_linear_args* args, es_stream stream);
 /* n <= 3 independent problems as one launch (same kernel class: no LayerNorm prologue, no GEGLU epilogue, no batching) */
 int es_linear_rows_multi_f32(const es_linear_args* const* args, int n, es_stream stream);
+/* Kernel family of the rows products, process-wide: 1 (default) = k_rows_frag (round 5: A fragments loaded straight into registers,
+ * one barrier per workgroup) wherever it applies, 0 = k_linear_rows (LDS-staged operand) for everything.  Both compute exact fp32
+ * products with the same K slices; the order of additions inside a slice differs, so results agree to rounding, not bit for bit.
+ * For A/B tools and tests -- set it before plans are captured. */
+int es_rows_set_kernel_family(int family);
 /* number of slices the launch will run for `args` (and the rounded kb_per_slice) -- the planner sizes the slab buffer with it */
 int es_linear_rows_slices(const es_linear_args* args, int* kb_per_slice);
 /* the library's default kb_per_slice for a [*, K] x [K, N] product whose slices must be multiples of kalign_cols columns
