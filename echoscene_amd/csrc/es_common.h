@@ -14,6 +14,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 void es_set_error(const char* fmt, ...);
+// plan executor -> rows launcher: the single-problem rows product the plan runs NEXT (NULL: unknown / not one); consumed by the next
+// rows launch of this thread, whose extra wave prefetches that product's weights (es_rows_x.h)
+struct es_linear_args;
+void es_rows_hint_next(const struct es_linear_args* next);
 
 // Host-side parallel loop for the one-off weight re-layouts (es_pack_*): 430 M shape-UNet weights through a scalar loop were 9 of the
 // 9.2 s of a process's first scene call.  f(i) for i in [0, n), strided over up to 32 threads; serial when threads cannot be had.

@@ -217,7 +217,8 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
                             const float rstd = __builtin_amdgcn_rsqf(sq * inv_gs + sg.eps);      // v_rsq_f32 (1 ulp) instead of sqrt + quotient (~25 instructions)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                float z = (y[q] - mean) * rstd * gav[PROC >= 1 ? u : 0][q] + bev[PROC >= 1 ? u : 0][q];
+                                float z = (y[q] - mean) * rstd;
+                                if (sg.gamma) z = z * gav[PROC >= 1 ? u : 0][q] + bev[PROC >= 1 ? u : 0][q];      // (NULL: affine folded into the weights)
                                 if (pro == ES_PRO_GN_SILU) z = es_silu(z);
                                 y[q] = z;
                             }
@@ -280,10 +281,11 @@ __device__ __forceinline__ void stage_ln(const es_linear_args& a, float* x, int 
     for (int u = 0; u < LNU; ++u) {
         const int c = 4 * (cl + LPR * u);
         if (c >= c0 && c < c0 + kc && c < K) {
-            const f4 ga = *(const f4*)(sg.gamma + c), be = *(const f4*)(sg.beta + c);
+            f4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+            if (sg.gamma) { ga = *(const f4*)(sg.gamma + c); be = *(const f4*)(sg.beta + c); }     // (NULL: affine folded into the weights)
             f4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = row_ok ? (v[u][e] - mean) * rstd * ga[e] + be[e] : 0.f;
+            for (int e = 0; e < 4; ++e) y[e] = row_ok ? (sg.gamma ? (v[u][e] - mean) * rstd * ga[e] + be[e] : (v[u][e] - mean) * rstd) : 0.f;
             *(f4*)&x[r * ldx + (c - c0)] = y;
         }
     }
@@ -473,18 +475,24 @@ __global__ __launch_bounds__(NTHREAD) void k_linear_rows(const RowsLaunch L) {
 
 #include "es_rows_x.h"
 
+// ONE_BLOCK: the whole state in one workgroup (n <= 4096: one scene) -- the step counter is advanced by the same kernel, after every
+// thread has read it (a launch less per step of the latency-bound layout loop)
+template <bool ONE_BLOCK>
 __global__ void k_ddpm_update(const es_update_args a) {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int st = *a.step;
-    if (i < a.n) {
-        const float* c = a.coef + (long)st * a.coef_stride;
+    const float* c = a.coef + (long)st * a.coef_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += ONE_BLOCK ? (int)blockDim.x : a.n) {
         const float x = a.x[i], e = load_slabs1(a.eps + i, a.eps_nslab > 1 ? a.eps_nslab : 1, a.eps_slab_stride);
         const float nz = a.noise[(long)st * a.noise_stride + i];
         float x0 = c[0] * x - c[1] * e;
         if (a.clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);          // clip_denoised=True: torch.clamp(x_recon, -1, 1), diffusion_ddpm.py:243-244
         const float mean = c[2] * x0 + c[3] * x;
         a.x[i] = mean + c[4] * nz;
+    }
+    if (ONE_BLOCK && a.inc_step) {
+        __syncthreads();
+        if (threadIdx.x == 0) *a.step = st + 1;
     }
 }
 
@@ -659,6 +667,9 @@ extern "C" int es_debug_rows_stamp(void* p, const char* log) {
 }
 #endif
 
+static thread_local const es_linear_args* g_rows_next = nullptr;
+void es_rows_hint_next(const es_linear_args* next) { g_rows_next = next; }
+
 namespace {
 struct RowsPrep { es_linear_args a; int S, kbps, nsmax, proc, nb; bool has_ln, csr, gepi; };
 
@@ -703,13 +714,13 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
         for (int s = 0; s < a.nseg; ++s) {
             const es_seg& sg = a.seg[s];
             if (sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) {
-                ES_REQUIRE(sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta, "es_linear_rows_f32: GroupNorm segments are direct, with an affine");
+                ES_REQUIRE(sg.mode == ES_SEG_DIRECT && (sg.gamma != nullptr) == (sg.beta != nullptr), "es_linear_rows_f32: GroupNorm segments are direct, with gamma AND beta or neither (affine folded into the weights)");
                 ES_REQUIRE(sg.gs >= 4 && sg.gs <= 32 && (sg.gs & (sg.gs - 1)) == 0 && sg.width % sg.gs == 0 && koff % sg.gs == 0,
                            "es_linear_rows_f32: GroupNorm group size %d (4..32, power of two, dividing the segment width %d and its offset %d)",
                            sg.gs, sg.width, koff);
             } else if (sg.pro == ES_PRO_LN) {
-                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta && sg.width <= 1024,
-                           "es_linear_rows_f32: LayerNorm prologue needs ONE direct segment of width <= 1024 with an affine");
+                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && (sg.gamma != nullptr) == (sg.beta != nullptr) && sg.width <= 1024,
+                           "es_linear_rows_f32: LayerNorm prologue needs ONE direct segment of width <= 1024 (gamma AND beta, or neither: affine folded into the weights)");
                 has_ln = true;
             } else if (sg.pro == ES_PRO_GEGLU) {
                 ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
@@ -809,7 +820,7 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
     if (p.has_ln) {
         if (S > 2 || S * Jw > 4 || p.nsmax > 2) return false;
         if (S == 2 && xp->cut[2] - xp->cut[1] != xp->cut[1] - xp->cut[0]) return false;
-    } else if (Jw > 8) return false;
+    } else if (Jw > 12) return false;
     xp->S = S; xp->Jw = Jw;
     return true;
 }
@@ -841,10 +852,34 @@ void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
     }
 }
 
+// the prefetch descriptor of the hinted next launch (w == NULL when there is none or it is not a single-problem k_rows_x launch)
+XPre x_prefetch_of_next() {
+    XPre pf;
+    memset(&pf, 0, sizeof(pf));
+    const es_linear_args* nx = g_rows_next;
+    g_rows_next = nullptr;
+    static const char* pre_env = getenv("ES_ROWS_PREFETCH");        // timing-only: 0 = no prefetch wave
+    if (!nx || (pre_env && atoi(pre_env) == 0)) return pf;
+    RowsPrep pr;
+    if (rows_prepare(nx, &pr)) return pf;
+    XPlan xp;
+    if (!x_plan(pr, &xp)) return pf;
+    const int nct = (pr.a.N + 15) / 16;
+    const int nt = (pr.has_ln && pr.gepi && xp.S == 1 && nct % 2 == 0) ? 2 : 1;
+    pf.w = (const char*)pr.a.wpack;
+    pf.gx = nct / nt * xp.S;
+    pf.smagic = xp.S | (((32768 + xp.S - 1) / xp.S) << 16);
+    pf.nkb_total = pr.a.K / 16;
+    pf.nt = nt;
+    for (int i = 0; i <= xp.S; ++i) pf.cut[i] = xp.cut[i];
+    if (pf.gx >= 5461) pf.w = nullptr;
+    return pf;
+}
+
 template <int NP>
 int x_launch_np(const void* fn, const XLaunch<NP>& L, dim3 grid, es_stream stream) {
     void* kargs[] = {(void*)&L};
-    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD), kargs, 0, (hipStream_t)stream));
+    ES_CHECK_HIP(hipLaunchKernel(fn, grid, dim3(NTHREAD + (L.pf.w ? 64 : 0)), kargs, 0, (hipStream_t)stream));
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -871,6 +906,7 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
     if (jmax <= 2 && nsmax <= 4) cls = 0;
     else if (jmax <= 4 && nsmax <= 4) cls = 1;
     else if (jmax <= 8 && nsmax <= 2) cls = 2;
+    else if (jmax <= 12 && nsmax <= 1 && n == 1) cls = 3;          // (the cross-attention-vector product: K 1280 in one slice)
     const void* fn = nullptr;
     dim3 grid;
     int nt = 1;
@@ -885,24 +921,16 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
         if (cls < 0) return -1;
         // [class][GroupNorm compiled in]; the third class (long single-segment K ranges: the feed-forward output product, the
         // triple-row products of the GCNs) has no GroupNorm variant
-        static const void* const tab1[3][2] = {
+        static const void* const tab1[4][2] = {
             {(const void*)k_rows_x<2, 4, 0, 1, 1, false, 1>, (const void*)k_rows_x<2, 4, 1, 1, 1, false, 1>},
             {(const void*)k_rows_x<4, 4, 0, 1, 1, false, 1>, (const void*)k_rows_x<4, 4, 1, 1, 1, false, 1>},
-            {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 1>, nullptr}};
+            {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 1>, nullptr},
+            {(const void*)k_rows_x<12, 1, 0, 1, 1, false, 1>, nullptr}};
         static const void* const tab3[3][2] = {
             {(const void*)k_rows_x<2, 4, 0, 1, 1, false, 3>, (const void*)k_rows_x<2, 4, 1, 1, 1, false, 3>},
             {(const void*)k_rows_x<4, 4, 0, 1, 1, false, 3>, (const void*)k_rows_x<4, 4, 1, 1, 1, false, 3>},
             {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 3>, nullptr}};
-        // two column tiles per workgroup (timing-only: the per-output arithmetic does not change): half the workgroups re-read the A slabs
-        static const void* const tab1_nt2[2][2] = {
-            {(const void*)k_rows_x<2, 4, 0, 1, 2, false, 1>, (const void*)k_rows_x<2, 4, 1, 1, 2, false, 1>},
-            {(const void*)k_rows_x<4, 4, 0, 1, 2, false, 1>, (const void*)k_rows_x<4, 4, 1, 1, 2, false, 1>}};
-        static const char* nt_env = getenv("ES_X_NT");
-        fn = (n == 1 ? tab1 : tab3)[cls][proc];
-        if (n == 1 && !gather && cls < 2 && nt_env && atoi(nt_env) == 2 && ((pr[0].a.N + 15) / 16) % 2 == 0 && pr[0].a.N >= 256) {
-            fn = tab1_nt2[cls][proc];
-            nt = 2;
-        }
+        fn = n == 1 ? tab1[cls][proc] : cls < 3 ? tab3[cls][proc] : nullptr;
         if (gather) {        // gathered rows: the triple-row products of the GCNs (plain operands)
             if (proc != 0 || nsmax > 2 || jmax > 8) return -1;
             fn = n == 1 ? (const void*)k_rows_x<8, 2, 0, 1, 1, false, 1, true> : (const void*)k_rows_x<8, 2, 0, 1, 1, false, 3, true>;
@@ -915,17 +943,15 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
 #ifdef ES_STAMP
     launch_id = g_rows_stamp ? g_rows_launch_id++ : 0;
 #endif
+    const XPre pf = x_prefetch_of_next();
     if (n == 1) {
         XLaunch<1> L;
         memset(&L, 0, sizeof(L));
         x_fill(L.p[0], pr[0], xp[0]);
         L.n = 1;
+        L.pf = pf;
         grid = dim3((unsigned)(((pr[0].a.N + 15) / 16) / nt * xp[0].S), (unsigned)((pr[0].a.M + MT - 1) / MT), 1);
         L.p[0].ny = (int)grid.y; L.p[0].xw = (int)grid.x;
-        static const char* xcd_env = getenv("ES_X_XCD");                     // timing-only: XCD-aware tile order (k_rows_x)
-        if (xcd_env && atoi(xcd_env) == 1 && (xp[0].S == 2 || xp[0].S == 4 || xp[0].S == 8) && grid.y <= 2 && (grid.x * grid.y) % 8 == 0 &&
-            (grid.x / xp[0].S) % (8 / xp[0].S) == 0)
-            L.p[0].act |= 256;
         if (grid.x >= 5461) return -1;
 #ifdef ES_STAMP
         L.stamp = g_rows_stamp; L.launch_id = launch_id;
@@ -943,6 +969,7 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
     }
     for (int i = n; i < 3; ++i) L.p[i].wg0 = 0x7fffffff;
     L.n = n;
+    L.pf = pf;
     grid = dim3((unsigned)gx, (unsigned)gy, 1);
 #ifdef ES_STAMP
     L.stamp = g_rows_stamp; L.launch_id = launch_id;
@@ -1100,8 +1127,12 @@ extern "C" int es_row_select(const es_rowsel_args* a, es_stream stream) {
 
 extern "C" int es_ddpm_update(const es_update_args* a, es_stream stream) {
     ES_REQUIRE(a->n > 0 && a->step && a->noise, "es_ddpm_update: bad args");
-    hipLaunchKernelGGL(k_ddpm_update, dim3((a->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
-    if (a->inc_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, a->step);
+    if (a->n <= 4096) {
+        hipLaunchKernelGGL(k_ddpm_update<true>, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+    } else {
+        hipLaunchKernelGGL(k_ddpm_update<false>, dim3((a->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+        if (a->inc_step) hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, a->step);
+    }
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -40,9 +40,18 @@ struct XProb {                                    // 128 + 6 * 64 = 512 bytes
     int32_t act, res_step_stride, Jw, K;
     XSlice sl[XMAXS];
 };
+// What the NEXT rows launch of the plan will read of its weight image (single-problem launches): the extra wave of this launch pulls
+// those bytes into the L2 of the XCD that will read them (L2 contents survive kernel boundaries, workgroup id -> XCD is the same function
+// in every launch: tools/probes/probe_l2_persist.hip, tools/rows_stamps.py).  w == NULL: nothing to fetch.
+struct XPre {
+    const char* w;
+    int32_t gx, smagic, nkb_total, nt;            // tiles of one grid row (column tiles x slices), S | ceil(2^15 / S) << 16, k-blocks of a weight tile, NT
+    int32_t cut[XMAXS + 1], pad;                  // first k-block of every slice, and the end
+};
 template <int NP>
 struct XLaunch {
     XProb p[NP];
+    XPre pf;
     int32_t n, pad;
 #ifdef ES_STAMP
     unsigned long long* stamp;
@@ -65,6 +74,13 @@ constexpr unsigned XOOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, p ? (int)XOOB : 0, 0x00020000);      // (p is wave-uniform at every call site)
 }
+// the same window, or no records at all when `on` is false (wave-uniform): the load is issued either way and returns zeros -- the load
+// phase of the kernel has NO branches, so every load is in flight before the first wait and vmcnt is counted exactly.  (Round 5, from
+// the ISA: with `if (present) load` the register allocator treated the fragment arrays as one tuple and copied it around -- behind
+// `s_waitcnt vmcnt(0)` -- between the loads: 2.8 us to ISSUE 16 loads in the LayerNorm variant.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc_if(const void* p, bool on) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (p && on) ? (int)XOOB : 0, 0x00020000);
+}
 __device__ __forceinline__ f4 x_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
@@ -80,7 +96,7 @@ __device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // NP: problems the launch may carry (1: single-problem launches read a 3x smaller argument block and skip the problem lookup).
 // GATHER: rows may be gathered through an index (a dependent round trip in front of the A loads: its own variants).
 template <int JW, int NS, int PROC, int SLN, int NT, bool GEGLU_EPI, int NP, bool GATHER = false>
-__global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
+__global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
     __shared__ __attribute__((aligned(16))) float red[NT * NKG * 256];
     __shared__ float lnx[PROC == 2 ? 2 * NKG * 16 : 1];
     static_assert(PROC == 2 || SLN == 1, "k_rows_x: only LayerNorm reads foreign slices");
@@ -111,20 +127,32 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
         bx = v - by * xw;
     } else if (by >= P.ny) return;
     // bx / S without the integer-division sequence: floor(bx * ceil(2^15 / S) / 2^15) is exact for S <= 6, bx < 5461 (host-checked)
-    int ct = (int)(((unsigned)bx * ((unsigned)P.S >> 16)) >> 15);
-    int slice = bx - ct * S;
-    if (NP == 1 && (P.act & 256)) {
-        // XCD-aware tile order (speed only; host: S in {2, 4, 8}, at most two row tiles, a multiple of 8 workgroups): workgroup id runs on
-        // XCD id % 8 (+ a constant), so the 8 / S XCDs {slice * 8 / S ...} own ONE K slice -- an XCD reads 1 / S of the A slabs over the fabric
-        const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x), c = id & 7, r = id >> 3;
-        const int lg = S == 2 ? 2 : S == 4 ? 1 : 0;
-        const int nct = (int)gridDim.x >> (3 - lg);                          // gridDim.x = column tiles x S
-        const int t = (r << lg) | (c & ((1 << lg) - 1));
-        slice = c >> lg;
-        by = t >= nct ? 1 : 0;
-        ct = t - by * nct;
-    }
+    const int ct = (int)(((unsigned)bx * ((unsigned)P.S >> 16)) >> 15);
+    const int slice = bx - ct * S;
     bx = ct;
+    if (wave == NKG) {
+        // the PREFETCH wave (launched only when the host knows the next launch: 9 waves): fetch the weight bytes that the workgroups
+        // of the next launch with this workgroup's id (mod 8: the same XCD) will read.  Its loads have their own vmcnt; nobody waits
+        // for them but the end of this wave.
+        const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x), w8 = (int)(gridDim.x * gridDim.y) & ~7;
+        f4 sink = {0.f, 0.f, 0.f, 0.f};
+        const int pS = L.pf.smagic & 0xffff, pnt = L.pf.nt, pnkb = L.pf.nkb_total, pgx = L.pf.gx;
+        const unsigned pmag = (unsigned)L.pf.smagic >> 16;
+        for (int b = id; b < pgx && w8 > 0; b += w8) {
+            const int pct = (int)(((unsigned)b * pmag) >> 15), psl = __builtin_amdgcn_readfirstlane(b - pct * pS);
+            const int k0 = L.pf.cut[psl], nk = L.pf.cut[psl + 1] - k0;          // (scalar loads from the argument block)
+            for (int t = 0; t < pnt; ++t) {
+                const char* base = L.pf.w + ((size_t)(pct * pnt + t) * pnkb + k0) * 1024 + lane * 16;
+                // the destination is an in / out operand: it stays allocated (loads in flight must not land in a register the compiler
+                // has handed to something else) and the loads are ordered; nothing ever reads it
+                for (int kb = 0; kb < nk; ++kb) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(base + (size_t)kb * 1024));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (PROC == 2 ? 3 : 1); ++i) __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink));
+        return;
+    }
     const XSlice SL = PP.sl[slice];                        // by VALUE: one wide scalar load
     const int Jw = P.Jw, M = P.M, N = P.N, nkb_total = P.nkb_total;
     const int nt = bx * NT;
@@ -144,39 +172,39 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
     // (1) weights (the HBM misses): the wave's k-blocks x NT tiles, 1 KiB each, contiguous in the packed image
     const __amdgpu_buffer_rsrc_t rW = x_rsrc((const f4*)P.wpack + ((size_t)nt * nkb_total + SL.kb0 + wave * Jw) * 64);
     f4 bf[NT][JW];
+    unsigned vj[JW];                                      // per-block byte offset of the lane inside the wave's range, or out of range
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        if (j < Jw && j < nj) {
+        const bool on = j < Jw && j < nj;
+        vj[j] = on ? (unsigned)j * 64u : XOOB;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bf[t][j] = x_ld4_nt(rW, (unsigned)lane * 16u + (unsigned)j * 1024u, (unsigned)(t * nkb_total) * 1024u);
-        }
+        for (int t = 0; t < NT; ++t) bf[t][j] = x_ld4_nt(rW, on ? (unsigned)lane * 16u + (unsigned)j * 1024u : XOOB, (unsigned)(t * nkb_total) * 1024u);
     }
 
-    // (2) A fragments: lane (i16, q) = columns [16 kb + 4 q, + 4) of its row, every slab of the producer.  LayerNorm: the blocks at the
-    // wave's position in EVERY slice (block v = (slice v / JW, position v % JW)); own blocks are those of slice `slice`.
+    // (2) A fragments: lane (i16, q) = columns [16 kb + 4 q, + 4) of its row, every slab of the producer (absent slabs: descriptors
+    // without records).  LayerNorm: the blocks at the wave's position in EVERY slice (block v = (slice v / JW, position v % JW)); own
+    // blocks are those of slice `slice`.
     constexpr int NB = JW * SLN;
     f4 av[NB][NS], gav[PROC >= 1 ? JW : 1], bev[PROC >= 1 ? JW : 1];
-    const __amdgpu_buffer_rsrc_t rA = x_rsrc(SL.a);
     const unsigned colw = (unsigned)(wave * Jw * 16 + 4 * q);                 // first column of the lane inside the slice
     const unsigned voff = ((unsigned)row * (unsigned)SL.ld + colw) * 4u;
     const unsigned sstr4 = (unsigned)SL.sstr * 4u;
 #pragma unroll
-    for (int v = 0; v < NB; ++v) {
-        const int j = v % JW, sl = v / JW;
-        if (j < Jw && j < nj && sl < S) {
-            const unsigned so = PROC == 2 ? (unsigned)(sl * SL.nkb) * 64u : 0u;     // LayerNorm: SL.a is column 0, slices are nkb blocks apart
-            av[v][0] = x_ld4(rA, voff + (unsigned)j * 64u, so);
+    for (int u = 0; u < NS; ++u) {
+        const __amdgpu_buffer_rsrc_t rA = x_rsrc_if(SL.a, u < SL.nslab);
 #pragma unroll
-            for (int u = 1; u < NS; ++u) if (u < SL.nslab) av[v][u] = x_ld4(rA, voff + (unsigned)j * 64u, so + (unsigned)u * sstr4);
+        for (int v = 0; v < NB; ++v) {
+            const int j = v % JW, sl = v / JW;
+            const unsigned so = PROC == 2 ? (unsigned)(sl * SL.nkb) * 64u : 0u;     // LayerNorm: SL.a is column 0, slices are nkb blocks apart
+            av[v][u] = x_ld4(rA, (sl < S ? voff : XOOB) + vj[j], so + (unsigned)u * sstr4);
         }
     }
-    if (PROC >= 1 && (SL.flags & (2 | 8))) {
-        const __amdgpu_buffer_rsrc_t rG = x_rsrc(SL.gamma), rB = x_rsrc(SL.beta);
+    const bool aff = PROC >= 1 && SL.gamma != nullptr;     // NULL: the affine of the norm is folded into the weights (host)
+    if (PROC >= 1) {
+        const __amdgpu_buffer_rsrc_t rG = x_rsrc_if(SL.gamma, (SL.flags & (2 | 8)) != 0), rB = x_rsrc_if(SL.beta, (SL.flags & (2 | 8)) != 0);
         const unsigned go = colw * 4u, gso = PROC == 2 ? (unsigned)(slice * SL.nkb) * 64u : 0u;
 #pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            if (j < Jw && j < nj) { gav[j] = x_ld4(rG, go + (unsigned)j * 64u, gso); bev[j] = x_ld4(rB, go + (unsigned)j * 64u, gso); }
-        }
+        for (int j = 0; j < JW; ++j) { gav[j] = x_ld4(rG, go + vj[j], gso); bev[j] = x_ld4(rB, go + vj[j], gso); }
     }
 
     ES_RSTAMP(2);
@@ -186,17 +214,15 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
 #pragma unroll
     for (int v = 0; v < NB; ++v) {
         const int j = v % JW, sl = v / JW;
-        a[v] = f4{0.f, 0.f, 0.f, 0.f};
-        if (j < Jw && j < nj && sl < S) {
-            f4 y = av[v][0];
+        (void)j; (void)sl;
+        f4 y = av[v][0];                                       // (blocks / slabs that do not exist are zeros: x + 0 = x)
 #pragma unroll
-            for (int u = 1; u < NS; ++u) if (u < SL.nslab) y += av[v][u];
-            if (SL.flags & 16) {
+        for (int u = 1; u < NS; ++u) y += av[v][u];
+        if (SL.flags & 16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-            }
-            a[v] = y;
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
         }
+        a[v] = y;
     }
     if (PROC == 1 && (SL.flags & 2)) {
         const int gs = SL.gs;
@@ -232,7 +258,8 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
             const float rstd = __builtin_amdgcn_rsqf(sq * inv_gs + SL.eps);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float zz = (y[e] - mean) * rstd * gav[j][e] + bev[j][e];
+                float zz = (y[e] - mean) * rstd;
+                if (aff) zz = zz * gav[j][e] + bev[j][e];
                 if (SL.flags & 4) zz = es_silu(zz);
                 o[j][e] = zz;
             }
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
             for (int sl = 1; sl < SLN; ++sl) if (slice == sl) y = a[sl * JW + j];
             if (j < Jw && j < nj) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * gav[j][e] + bev[j][e];
+                for (int e = 0; e < 4; ++e) { y[e] = (y[e] - mean) * rstd; if (aff) y[e] = y[e] * gav[j][e] + bev[j][e]; }
             }
             a[j] = y;
         }
@@ -288,7 +315,7 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
     const int te = NT > 1 ? (tid >> 8) : 0;
     const int nt_e = nt + te;
     const int n_e = nt_e * 16 + nl, m_e = m0 + ml;
-    const int act = P.act & 255;
+    const int act = P.act;
     const bool geglu = GEGLU_EPI && act == ES_ACT_GEGLU;
     const int nres = geglu ? nt_e * 8 + nl : n_e;
     const bool first = slice == 0;
@@ -296,25 +323,18 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
     float e_res = 0.f, e_res2 = 0.f, e_bias = 0.f;
     float rr1[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rr2[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (first) {
-        if (P.res) {
-            const float* rp = P.res;
-            // (the step counter through the scalar cache: a vector load here would wait for every load issued above)
-            if (P.res_step) rp += (long)(*(const __attribute__((address_space(4))) int32_t*)(unsigned long)P.res_step) * P.res_step_stride;
-            const __amdgpu_buffer_rsrc_t rR = x_rsrc(rp);
-            const unsigned ro = ok_res ? ((unsigned)m_e * (unsigned)P.res_ld + (unsigned)nres) * 4u : XOOB;
-            rr1[0] = x_ld1(rR, ro, 0);
+    if (first) {                                          // (a branch is harmless here: the loads the prologue waited for are behind us)
+        const float* rp = P.res;
+        // (the step counter through the scalar cache: a vector load here would wait for every load issued above)
+        if (P.res_step) rp += (long)(*(const __attribute__((address_space(4))) int32_t*)(unsigned long)P.res_step) * P.res_step_stride;
+        const unsigned ro1 = ok_res ? ((unsigned)m_e * (unsigned)P.res_ld + (unsigned)nres) * 4u : XOOB;
+        const unsigned ro2 = ok_res ? ((unsigned)m_e * (unsigned)P.res2_ld + (unsigned)nres) * 4u : XOOB;
 #pragma unroll
-            for (int u = 1; u < XMAXS; ++u) if (u < P.res_nslab) rr1[u] = x_ld1(rR, ro, (unsigned)(u * P.res_sstr) * 4u);
+        for (int u = 0; u < XMAXS; ++u) {
+            if (u < P.res_nslab) rr1[u] = x_ld1(x_rsrc_if(rp, true), ro1, (unsigned)(u * P.res_sstr) * 4u);
+            if (u < P.res2_nslab) rr2[u] = x_ld1(x_rsrc_if(P.res2, true), ro2, (unsigned)(u * P.res2_sstr) * 4u);
         }
-        if (P.res2) {
-            const __amdgpu_buffer_rsrc_t rR = x_rsrc(P.res2);
-            const unsigned ro = ok_res ? ((unsigned)m_e * (unsigned)P.res2_ld + (unsigned)nres) * 4u : XOOB;
-            rr2[0] = x_ld1(rR, ro, 0);
-#pragma unroll
-            for (int u = 1; u < XMAXS; ++u) if (u < P.res2_nslab) rr2[u] = x_ld1(rR, ro, (unsigned)(u * P.res2_sstr) * 4u);
-        }
-        if (P.bias) e_bias = x_ld1(x_rsrc(P.bias), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
+        e_bias = x_ld1(x_rsrc_if(P.bias, true), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
     }
     ES_RSTAMP(3);
 
@@ -344,11 +364,9 @@ __global__ __launch_bounds__(NTHREAD) void k_rows_x(const XLaunch<NP> L) {
     float sres = 0.f;
 #pragma unroll
     for (int w = 0; w < NKG; ++w) sres += red[(te * NKG + w) * 256 + off];
-    if (first) {
-        e_res = rr1[0]; e_res2 = rr2[0];
+    e_res = rr1[0]; e_res2 = rr2[0];
 #pragma unroll
-        for (int u = 1; u < XMAXS; ++u) { if (u < P.res_nslab) e_res += rr1[u]; if (u < P.res2_nslab) e_res2 += rr2[u]; }
-    }
+    for (int u = 1; u < XMAXS; ++u) { e_res += rr1[u]; e_res2 += rr2[u]; }         // (absent slabs are zeros)
     float* out = P.out + (long)slice * P.out_sstr;
     if (GEGLU_EPI && geglu) {
         // tile rows: [8 value | 8 gate]; lane nl < 8 holds the value of output column 8 * nt_e + nl, lane nl + 8 its gate

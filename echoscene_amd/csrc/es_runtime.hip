@@ -150,6 +150,22 @@ extern "C" int es_plan_run(es_plan* p, es_stream stream) {
             fprintf(stderr, "\n");
             fflush(stderr);
         }
+        if (op.kind == ES_OP_LINEAR) {
+            // tell the rows launcher which (single) rows product the plan runs next -- wrapping around: a sampling loop replays the
+            // plan -- so that this launch's extra wave can pull its weights into L2
+            const es_op* base = p->ops.data();
+            const size_t nops = p->ops.size();
+            size_t k = (size_t)(&op - base);
+            while (k < nops && base[k].kind == ES_OP_LINEAR && base[k].u.linear.fuse_next) ++k;      // end of this fused group
+            const es_linear_args* nxt = nullptr;
+            for (size_t step_ = 1; step_ <= nops; ++step_) {
+                const es_op& o2 = base[(k + step_) % nops];
+                if (o2.kind != ES_OP_LINEAR) continue;
+                if (!o2.u.linear.fuse_next && &o2 != &op) nxt = &o2.u.linear;
+                break;
+            }
+            es_rows_hint_next(nxt);
+        }
         static const char* fuse_env = getenv("ES_ROWS_FUSE");       // A/B switch: 0 = one launch per product
         if (op.kind == ES_OP_LINEAR && op.u.linear.fuse_next && !(fuse_env && atoi(fuse_env) == 0)) {
             // independent row products marked by the planner: one launch for up to 3 of them

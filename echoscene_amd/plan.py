@@ -67,7 +67,9 @@ class View:
     ``nslab`` > 1: a SLAB tensor -- the split-K output of a rows launch, whose value is the fixed-order sum of ``nslab``
     matrices ``slab_stride`` floats apart; whoever reads it (A segment, residual, DDPM update) sums the slabs."""
 
-    def __init__(self, t, col=0, ld=None, width=None, row=0, nslab=1, slab_stride=0):
+    def __init__(self, t, col=0, ld=None, width=None, row=0, nslab=1, slab_stride=0, step=None, step_stride=0):
+        # step / step_stride: the view is row (*step) of a per-schedule table, step_stride floats apart (residual operands only)
+        self.step, self.step_stride = step, step_stride
         self.t = t
         self.col = col
         self.row = row
@@ -207,6 +209,16 @@ def fold_bn(sd, lin, bn):
     b = sd[lin + '.bias'].double()
     s = sd[bn + '.weight'].double() / torch.sqrt(sd[bn + '.running_var'].double() + 1e-5)
     return (W * s[:, None]).float(), ((b - sd[bn + '.running_mean'].double()) * s + sd[bn + '.bias'].double()).float()
+
+
+def fold_affine(W, b, gamma, beta):
+    """Linear(norm(x) * gamma + beta) = (W diag(gamma)) norm(x) + (W beta + b): the affine of a GroupNorm / LayerNorm that feeds a
+    product directly (no SiLU in between) moves into the weights (fp64 fold) -- the kernels then neither load nor apply it
+    (round 5: the norm prologue of 32 launches per layout step lost a third of its loads)."""
+    Wd = W.detach().double()
+    g, be = gamma.detach().double(), beta.detach().double()
+    bb = (b.detach().double() if b is not None else torch.zeros(W.shape[0], dtype=torch.float64)) + Wd @ be
+    return (Wd * g[None, :]).float(), bb.float()
 
 
 def centre_tap(w):
@@ -375,6 +387,9 @@ class Builder:
         a.res = res.ptr if res is not None else None
         a.res_ld = res.ld if res is not None else 0
         a.res_nslab, a.res_slab_stride = (res.nslab, res.slab_stride) if res is not None else (0, 0)
+        if res is not None and getattr(res, 'step', None) is not None:
+            a.res_step, a.res_step_stride = res.step.data_ptr(), res.step_stride
+            self.keep.append(res.step)
         a.res2 = res2.ptr if res2 is not None else None
         a.res2_ld = res2.ld if res2 is not None else 0
         a.res2_nslab, a.res2_slab_stride = (res2.nslab, res2.slab_stride) if res2 is not None else (0, 0)
@@ -505,8 +520,8 @@ class Plan:
                     k += 1
             if op.kind not in (hip.OP_FORK, hip.OP_JOIN):
                 n += 1
-            if op.kind in (hip.OP_DDPM, hip.OP_DDIM) and op.u.update.inc_step:
-                n += 1
+            if op.kind in (hip.OP_DDPM, hip.OP_DDIM) and op.u.update.inc_step and not (op.kind == hip.OP_DDPM and op.u.update.n <= 4096):
+                n += 1                           # (the one-workgroup DDPM update advances the step counter itself)
             i += k
         return n
 
@@ -707,7 +722,8 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False, rider=Non
                       split=max(8, (nkb1 + gs_ - 1) // gs_) if gs_ > 1 else False)                        # relu deferred
         if has_proj:
             b.fork(2)
-            proj = b.linear([seg(obj, width=Dobj)], L['proj'], O, lane=2)                     # slab tensor: read as a residual
+            # (one K slice: with the triple-row product the launch then stays within the 512 workgroups that are resident at once)
+            proj = b.linear([seg(obj, width=Dobj)], L['proj'], O, lane=2, split=False)
         else:
             proj = None
         t2 = View(b.buf(T, W2))
@@ -832,20 +848,24 @@ class UNet1DWeights:
                 Wv = centre_tap(sd[name + '.qkv.weight']).double()[vrows]
                 bv = sd[name + '.qkv.bias'].double()[vrows]
                 Wp = centre_tap(sd[name + '.proj_out.weight']).double()
-                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
-                d['av'] = PackedLinear((Wp @ Wv).float(), (Wp @ bv + sd[name + '.proj_out.bias'].double()).float(), device)
+                d['gn'] = (None, None)               # (affine folded into the product)
+                d['av'] = PackedLinear(*fold_affine(Wp @ Wv, Wp @ bv + sd[name + '.proj_out.bias'].double(),
+                                                    sd[name + '.norm.weight'], sd[name + '.norm.bias']), device)
             elif kind == 'attn':
                 tb = name + '.transformer_blocks.0'
-                d['gn'] = (dv(name + '.norm.weight'), dv(name + '.norm.bias'))
-                d['proj_in'] = P(name + '.proj_in.weight', name + '.proj_in.bias')
-                d['ln1'] = (dv(tb + '.norm1.weight'), dv(tb + '.norm1.bias'))
-                d['ln3'] = (dv(tb + '.norm3.weight'), dv(tb + '.norm3.bias'))
+                # the three norms of a transformer block feed a product directly: their affines are folded into its weights
+                d['gn'] = (None, None)
+                d['proj_in'] = PackedLinear(*fold_affine(centre_tap(sd[name + '.proj_in.weight']), sd[name + '.proj_in.bias'],
+                                                         sd[name + '.norm.weight'], sd[name + '.norm.bias']), device)
+                d['ln1'] = (None, None)
+                d['ln3'] = (None, None)
                 # one token, one key: softmax == 1, so attention(x) = to_out(to_v(.)) exactly
                 # ... and the two linears fold into one matrix (fp64): to_out . to_v
-                d['vo1'] = PackedLinear((sd[tb + '.attn1.to_out.0.weight'].double() @ sd[tb + '.attn1.to_v.weight'].double()).float(),
-                                        sd[tb + '.attn1.to_out.0.bias'], device)
+                d['vo1'] = PackedLinear(*fold_affine(sd[tb + '.attn1.to_out.0.weight'].double() @ sd[tb + '.attn1.to_v.weight'].double(),
+                                                     sd[tb + '.attn1.to_out.0.bias'], sd[tb + '.norm1.weight'], sd[tb + '.norm1.bias']), device)
                 d['o2'] = (sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_out.0.bias'])
-                d['ff1'] = PackedLinear(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'], device, geglu=True)
+                d['ff1'] = PackedLinear(*fold_affine(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'],
+                                                     sd[tb + '.norm3.weight'], sd[tb + '.norm3.bias']), device, geglu=True)
                 # x_out = proj_out(ff2(g) + b2 + t2) + x_in is linear in (g, t2): ONE op over the K-concatenation [g | t2] with
                 # [Wpo.Wff2 | Wpo] (folded in fp64) -- one dependent launch less per transformer block
                 Wpo = centre_tap(sd[name + '.proj_out.weight']).double()
@@ -881,8 +901,8 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     emb_ld = w.emb_all.N
     if tables is not None:
         emb = None
-        emb_all = b.buf(1, w.emb_all.N)
-        b.rowsel(tables['emb_all'], step, View(emb_all))
+        # (round 5: the consumers read row *step of the table in place -- es_linear_args.res_step -- instead of a row-select launch)
+        emb_all = (tables['emb_all'], step)
         emb_ld = 0                               # one row, broadcast over the nodes
         b.fork(1)
     else:
@@ -905,13 +925,17 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     # embedding's launch (both read x_t), then one product per net1 / net2 output launch of the GCN layers.
     box = {}
     rider = Rider(_trunk(b, w, O, x, emb_all, emb_ld, box, eps_out))
+    if w.enable_t_emb and tables is not None:
+        # the time slot of the node vectors = row *step of the t_lin table, broadcast: an IDENTITY product over a step-indexed segment
+        # (exact: sums of x * 1 and zeros), a third independent problem of the box-embedding launch instead of a row-select launch
+        if not hasattr(w, 'eye_t'):
+            w.eye_t = PackedLinear(torch.eye(gdim), None, b.device)
+        b.linear([seg(View(tables['t_lin'], ld=0, width=gdim), step=step, step_stride=gdim)], w.eye_t, O,
+                 View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim), fuse_next=True)
     b.linear([seg(View(x))], w.box_emb, O, View(objbuf, col=oe_w, ld=Dobj, width=gdim))
     b.ride(rider)
-    if w.enable_t_emb:
-        if tables is not None:
-            b.rowsel(tables['t_lin'], step, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim), rows=O)
-        else:
-            b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
+    if w.enable_t_emb and tables is None:
+        b.linear([seg(emb)], w.box_t, O, View(objbuf, col=oe_w + gdim, ld=Dobj, width=gdim))
     pred = b.pred_rows = b.dev(w.pred_table[torch.from_numpy(g.p_host)])     # refreshed in place for a new graph
     ctx = emit_gcn(b, w.gcn, g, View(objbuf), Dobj, View(pred), pred.shape[1], rider=rider)
     box['ctx'] = ctx
@@ -968,7 +992,8 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
                 if skip_early:
                     yield 'CTX'                  # (this variant fuses conv1 with the skip projection itself: nothing rides from here on)
                 h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
-                              res=View(emb_all, col=eo, ld=emb_ld, width=cout), fuse_next=skip_early)
+                              res=(View(emb_all[0], col=eo, ld=0, width=cout, step=emb_all[1], step_stride=emb_all[0].shape[1])
+                                   if isinstance(emb_all, tuple) else View(emb_all, col=eo, ld=emb_ld, width=cout)), fuse_next=skip_early)
                 if not skip_early:
                     yield
                 gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
@@ -1041,7 +1066,13 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
         sk, sC = hs.pop()
         h_segs, hC = yield from run_block(f'output_blocks.{i}', blk, [h_segs[0], sk], hC + sC)
     # (eps stays an ordinary tensor: it is also the result of the step-level API; one slice)
-    b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O, View(eps_out))
+    # eps: a slab tensor too when the caller takes it as a View (eps_out None: the DDPM update sums the slabs) -- two workgroups
+    # multiplying the whole K range were the slowest launch of the trunk's tail
+    if eps_out is None:
+        b.tags['eps'] = b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O)
+    else:
+        b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O, View(eps_out))
+        b.tags['eps'] = View(eps_out)
     yield
 
 

@@ -72,11 +72,11 @@ class LayoutDenoiser:
             b = Builder(self.device)
             D = self.net.in_channels
             x = b.buf(O, D)
-            eps = b.buf(O, self.net.out_channels)
             step = b.buf(1, dtype=torch.int32, zero=True)
             noise = b.buf(self.T + 1, O, D)
             oe = b.dev(obj_embed)
-            objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, eps, tables=self.tables)
+            objbuf = emit_unet1d_step(b, self.w, g, x, oe, self.temb, step, None, tables=self.tables)
+            eps = b.tags['eps']                                  # View: the output conv's K slices (the update sums the slabs)
             n_eps_ops = len(b.ops)
             b.update(hip.OP_DDPM, x, eps, self.coef, step, noise=View(noise[1:].reshape(self.T, O * D), ld=O * D),
                      noise_stride=O * D, inc_step=True, clip_x0=clip)
@@ -114,7 +114,8 @@ class LayoutDenoiser:
         st = self._plan_for(obj_embed, triples)
         st['x'].copy_(x.to(self.device))
         st['eps_plan'].sample(st['step'], int(iteration), 1, use_graph=False)
-        return st['eps'].clone()
+        torch.cuda.synchronize()
+        return st['eps'].value()
 
     def sample(self, obj_embed, triples, noise=None, n_steps=None, use_graph=True, clip_denoised=False):
         """p_sample_loop_sg: returns x_0 [O, 8].  ``noise`` f32[T+1, O, 8] (row 0 = x_T, row 1+i = draw of

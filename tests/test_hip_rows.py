@@ -299,6 +299,8 @@ def test_unet1d_tiny_blockwise_vs_oracle(dev):
     orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'], trace=trace)
     bad = []
     for name, v in st['eps_plan'].tags.items():
+        if name == 'eps':
+            continue                        # (the step's result: checked by the golden tests)
         ref = trace[name]
         ref = ref.reshape(ref.shape[0], -1)
         got = v.value().cpu()                     # (slab tensors: the fixed-order sum of their slabs)
@@ -417,8 +419,8 @@ def test_linear_split_k_slab_chain_and_rowsel(dev):
         h = b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
                      PackedLinear(W, bias, dev), M, res=View(b.dev(R)))
         assert h.nslab == 3 and h.slab_stride == M * N, (h.nslab, h.slab_stride)       # round 5: one slice per 512-column segment (at most 4 slabs, 256 workgroups)
-        h2 = b.linear([seg(View(x, col=0, width=512)), seg(View(x, col=512, width=512)), seg(View(x, col=1024, width=512))],
-                      PackedLinear(W, bias, dev), M, res=View(b.dev(R)), split=48)
+        # (K slices never straddle segments since round 5: the same operand as ONE segment cut in two)
+        h2 = b.linear([seg(View(x, col=0, width=1536))], PackedLinear(W, bias, dev), M, res=View(b.dev(R)), split=48)
         assert h2.nslab == 2
         # (a) + (b): [GN(+SiLU)(h) | raw x] @ W2 + h
         o = b.linear(norm_segs([h], b.dev(ga), b.dev(be), 1e-5, silu) + [seg(View(x, col=0, width=512))],

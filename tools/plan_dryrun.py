@@ -52,11 +52,32 @@ def _linear_io(a, hip):
     Nout = a.N // 2 if a.act == hip.ACT_GEGLU else a.N
     S = 1
     if a.kb_per_slice > 0:
-        nkb = (a.K + 15) // 16
-        S = (nkb + a.kb_per_slice - 1) // a.kb_per_slice
+        import ctypes as C
+        got = C.c_int(0)
+        S = hip.lib().es_linear_rows_slices(C.byref(a), C.byref(got))       # (the library's rule: segment-aligned cuts since round 5)
     for j in range(S):
-        writes.append((a.out + 4 * j * a.out_slab_stride, 4 * (a.out_ld * (a.M - 1) + Nout)))
+        writes.append(Rect(a.out + 4 * j * a.out_slab_stride, 4 * (a.out_ld * (a.M - 1) + Nout), 4 * a.out_ld, 4 * Nout))
     return reads, writes
+
+
+class Rect(tuple):
+    """a written range (ptr, bytes) that also knows its row pitch and row width: two column blocks of one matrix do not overlap"""
+
+    def __new__(cls, ptr, nbytes, pitch=0, width=0):
+        r = super().__new__(cls, (ptr, nbytes))
+        r.pitch, r.width = pitch, width
+        return r
+
+
+def rects_overlap(a, b):
+    if not (a[0] < b[0] + b[1] and b[0] < a[0] + a[1]):
+        return False
+    pa, pb = getattr(a, 'pitch', 0), getattr(b, 'pitch', 0)
+    if pa and pa == pb and a.width <= pa and b.width <= pa:
+        ca, cb = a[0] % pa, (b[0] - (a[0] - a[0] % pa)) % pa             # column offsets relative to a common row start
+        if ca + a.width <= pa and cb + b.width <= pa and (ca + a.width <= cb or cb + b.width <= ca):
+            return False
+    return True
 
 
 def launches(b):
@@ -122,7 +143,7 @@ def check(b, inputs=()):
                         if overlaps(wp, wp + wn, rp, rp + (4 if gathered else rn)) or (gathered and wp <= rp < wp + wn):
                             problems.append('launch %d (op %d): problem %d reads what problem %d of the same launch writes' % (li, i0, k2, k))
                     for (wp2, wn2) in wr2:
-                        if k2 > k and overlaps(wp, wp + wn, wp2, wp2 + wn2):
+                        if k2 > k and rects_overlap(next(w for w in wr if w[0] == wp), next(w for w in wr2 if w[0] == wp2)):
                             problems.append('launch %d (op %d): problems %d and %d write overlapping ranges' % (li, i0, k, k2))
         for (rd, wr) in ios:
             for (wp, wn) in wr:
