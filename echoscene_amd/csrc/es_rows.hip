@@ -627,10 +627,13 @@ extern "C" int es_linear_rows_slices(const es_linear_args* a, int* kb_per_slice)
     if (a->seg_slices) {
         // round 5: slices never straddle two segments -- every segment (a multiple of 16 columns wide) is cut into
         // ceil(width / (16 kbps)) slices of kbps k-blocks, the last one of a segment possibly shorter
+        // bits 1..3 of seg_slices: segment 0..2 is cut with HALF the slice length (a GroupNorm segment next to plain ones: its
+        // k-blocks cost a wave ~2.5x a plain block)
         int S = 0;
         for (int s = 0; s < a->nseg; ++s) {
             if (a->seg[s].width % 16) return -1;
-            S += (a->seg[s].width / 16 + kbps - 1) / kbps;
+            const int kb = (a->seg_slices >> (1 + s)) & 1 ? (kbps + 1) / 2 : kbps;
+            S += (a->seg[s].width / 16 + kb - 1) / kb;
         }
         return S;
     }
@@ -760,7 +763,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
 // ---- k_rows_x dispatch (es_rows_x.h) ---------------------------------------------------------------------------------------------
 int g_rows_family = 1;       // 1 = k_rows_x where it applies (default), 0 = k_linear_rows only (es_rows_set_kernel_family: A/B tools)
 
-struct XPlan { int S, Jw, cut[XMAXS + 1], segof[XMAXS]; bool uniform; };
+struct XPlan { int S, Jw, cut[XMAXS + 1], segof[XMAXS], jws[XMAXS]; bool uniform; };
 
 // The K slices of a problem as k_rows_x wants them (every slice inside ONE segment); false = not a problem for k_rows_x
 bool x_plan(const RowsPrep& p, XPlan* xp) {
@@ -782,10 +785,11 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
         int kb = 0;
         for (int s = 0; s < a.nseg; ++s) {
             const int w = a.seg[s].width / 16;
-            for (int c = 0; c < w; c += p.kbps) {
+            const int kbs = (a.seg_slices >> (1 + s)) & 1 ? (p.kbps + 1) / 2 : p.kbps;
+            for (int c = 0; c < w; c += kbs) {
                 if (S >= XMAXS) return false;
                 xp->cut[S] = kb + c; xp->segof[S] = s;
-                const int n = (w - c < p.kbps) ? w - c : p.kbps;
+                const int n = (w - c < kbs) ? w - c : kbs;
                 maxn = n > maxn ? n : maxn;
                 ++S;
             }
@@ -822,6 +826,13 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
         if (S == 2 && xp->cut[2] - xp->cut[1] != xp->cut[1] - xp->cut[0]) return false;
     } else if (Jw > 12) return false;
     xp->S = S; xp->Jw = Jw;
+    // per slice: k-blocks per wave (an even count under 32-channel GroupNorm groups: a group is two adjacent blocks of one wave)
+    for (int i = 0; i < S; ++i) {
+        const es_seg& sg = a.seg[xp->segof[i]];
+        int j = (xp->cut[i + 1] - xp->cut[i] + NKG - 1) / NKG;
+        if ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) && sg.gs == 32 && (j & 1)) ++j;
+        xp->jws[i] = p.has_ln ? Jw : j;
+    }
     return true;
 }
 
@@ -847,7 +858,7 @@ void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
         d.beta = sg.beta ? sg.beta + (ln ? 0 : col) : nullptr;
         d.ld = sg.ld; d.nslab = sg.nslab > 1 ? sg.nslab : 1; d.sstr = sg.slab_stride;
         d.flags = (sg.mode == ES_SEG_GATHER ? 1 : 0) | ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) ? 2 : 0) |
-                  (sg.pro == ES_PRO_GN_SILU ? 4 : 0) | (ln ? 8 : 0) | (sg.pre_act == ES_ACT_RELU ? 16 : 0);
+                  (sg.pro == ES_PRO_GN_SILU ? 4 : 0) | (ln ? 8 : 0) | (sg.pre_act == ES_ACT_RELU ? 16 : 0) | (xp.jws[i] << 8);
         d.gs = sg.gs; d.eps = sg.eps; d.nkb = xp.cut[i + 1] - xp.cut[i]; d.kb0 = xp.cut[i];
     }
 }
@@ -1028,6 +1039,7 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     for (int i = 0; i < n; ++i) {
         const es_linear_args& a = pr[i].a;
         if (!a.seg_slices || pr[i].S == 1) continue;
+        ES_REQUIRE((a.seg_slices >> 1) == 0, "es_linear_rows_f32: per-segment slice lengths need k_rows_x (the problem is not one it handles)");
         for (int sgi = 0; sgi + 1 < a.nseg; ++sgi)
             ES_REQUIRE((a.seg[sgi].width / 16) % pr[i].kbps == 0,
                        "es_linear_rows_f32: segment-aligned slices of %d k-blocks do not tile segment %d (%d columns) and the problem is not one k_rows_x handles", pr[i].kbps, sgi, a.seg[sgi].width);

@@ -27,7 +27,7 @@ struct XSlice {                                   // 64 bytes
     const float* a;                               // A at the slice's first column (LayerNorm: at column 0 of the row)
     const int32_t* idx;                           // row gather index or NULL
     const float* gamma; const float* beta;        // affine of the norm prologue at the slice's first channel (LayerNorm: channel 0)
-    int32_t ld, nslab, sstr, flags;               // flags: 1 gather, 2 GroupNorm, 4 SiLU after the norm, 8 LayerNorm, 16 ReLU on the slab sum
+    int32_t ld, nslab, sstr, flags;               // flags: 1 gather, 2 GroupNorm, 4 SiLU after the norm, 8 LayerNorm, 16 ReLU on the slab sum; bits 8..: k-blocks per wave
     int32_t gs; float eps; int32_t nkb, kb0;      // k-blocks of the slice, first k-block (index into the weight image)
 };
 constexpr int XMAXS = 6;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         return;
     }
     const XSlice SL = PP.sl[slice];                        // by VALUE: one wide scalar load
-    const int Jw = P.Jw, M = P.M, N = P.N, nkb_total = P.nkb_total;
+    const int Jw = SL.flags >> 8, M = P.M, N = P.N, nkb_total = P.nkb_total;     // k-blocks per wave in THIS slice (slices may differ in length)
     const int nt = bx * NT;
     const int m0 = by * MT;
     const int i16 = lane & 15, q = lane >> 4;

@@ -405,6 +405,17 @@ class Builder:
                     kbps = seg_aligned_kbps([sg.width for sg in segs], pl.K, pl.N, kal)
                 a.kb_per_slice = kbps
                 a.seg_slices = 1 if all(sg.width % 16 == 0 for sg in segs) else 0
+                if a.seg_slices and kbps and not (isinstance(split, int) and not isinstance(split, bool)):
+                    # a GroupNorm(+SiLU) segment next to plain ones is cut twice as fine while the slab / workgroup bounds allow it: the
+                    # norm makes its k-blocks the expensive ones of the launch (the K = 1536 conv2 + skip products: 16 | 16 | 32 | 32 k-blocks)
+                    gn = [sg.pro in (hip.PRO_GN, hip.PRO_GN_SILU) for sg in segs]
+                    if any(gn) and not all(gn):
+                        cuts = lambda half: sum((sg.width // 16 + (kbps + 1) // 2 - 1) // ((kbps + 1) // 2) if h else (sg.width // 16 + kbps - 1) // kbps
+                                                for sg, h in zip(segs, half))
+                        nct_ = (pl.N + 15) // 16
+                        if ((kbps + 1) // 2) % max(1, kal // 16) == 0 and (kbps + 1) // 2 >= 8 and \
+                                cuts(gn) <= min(ROWS_MAX_SLABS, ROWS_MAX_WGS // (2 * nct_)):
+                            a.seg_slices |= sum(2 << i for i, h in enumerate(gn) if h)
                 got = C.c_int(0)
                 S = hip.lib().es_linear_rows_slices(C.byref(a), C.byref(got))
                 a.kb_per_slice = got.value if S > 1 else 0

@@ -124,7 +124,8 @@ typedef struct es_linear_args {
     int32_t res_step_stride;
     /* round 5: 1 = the K slices never straddle two segments -- every segment (a multiple of 16 columns wide) is cut into
      * ceil(width / (16 kb_per_slice)) slices of kb_per_slice k-blocks (the last slice of a segment may be shorter); the slab count is
-     * es_linear_rows_slices().  What the low-latency kernel of round 5 (k_rows_x) needs: one workgroup reads ONE segment. */
+     * es_linear_rows_slices().  What the low-latency kernel of round 5 (k_rows_x) needs: one workgroup reads ONE segment.
+     * Bits 1..3: segment 0..2 is cut with HALF the slice length (a GroupNorm segment next to plain ones). */
     int32_t seg_slices;
 } es_linear_args;
 
