@@ -917,7 +917,7 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
     if (jmax <= 2 && nsmax <= 4) cls = 0;
     else if (jmax <= 4 && nsmax <= 4) cls = 1;
     else if (jmax <= 8 && nsmax <= 2) cls = 2;
-    else if (jmax <= 12 && nsmax <= 1 && n == 1) cls = 3;          // (the cross-attention-vector product: K 1280 in one slice)
+    else if (jmax <= 12 && nsmax <= 1 && (n == 1 || gather)) cls = 3;          // (the cross-attention-vector product: K 1280 in one slice)
     const void* fn = nullptr;
     dim3 grid;
     int nt = 1;
@@ -943,8 +943,11 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
             {(const void*)k_rows_x<8, 2, 0, 1, 1, false, 3>, nullptr}};
         fn = n == 1 ? tab1[cls][proc] : cls < 3 ? tab3[cls][proc] : nullptr;
         if (gather) {        // gathered rows: the triple-row products of the GCNs (plain operands)
-            if (proc != 0 || nsmax > 2 || jmax > 8) return -1;
-            fn = n == 1 ? (const void*)k_rows_x<8, 2, 0, 1, 1, false, 1, true> : (const void*)k_rows_x<8, 2, 0, 1, 1, false, 3, true>;
+            if (proc != 0) return -1;
+            if (jmax <= 8 && nsmax <= 2) fn = n == 1 ? (const void*)k_rows_x<8, 2, 0, 1, 1, false, 1, true> : (const void*)k_rows_x<8, 2, 0, 1, 1, false, 3, true>;
+            else if (jmax <= 12 && nsmax <= 1)       // (the wide node vectors of the set-up GCNs: 1344 + 640 + 1344 columns)
+                fn = n == 1 ? (const void*)k_rows_x<12, 1, 0, 1, 1, false, 1, true> : (const void*)k_rows_x<12, 1, 0, 1, 1, false, 3, true>;
+            else return -1;
         }
         if (!fn) return -1;
     }

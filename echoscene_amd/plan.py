@@ -58,7 +58,8 @@ def seg_aligned_kbps(seg_widths, K, N, kalign_cols=16):
             continue
         S = sum((w + kbps - 1) // kbps for w in wk)
         if S <= smax:
-            return kbps if S >= 2 else 0
+            # (slices of more than 96 k-blocks are beyond k_rows_x -- 12 blocks per wave --, and k_linear_rows cuts K uniformly only)
+            return kbps if S >= 2 and kbps <= 96 else 0
     return 0
 
 
@@ -728,9 +729,11 @@ def emit_gcn(b, gw, g, obj, Dobj, pred, Dp, out=None, want_pred=False, rider=Non
         #  8 the (K, N) rule would pick -- the consumer reads S slabs of [T x H]; a planner constant, not a function of M)
         gs_ = ROWS_GCN_SLICES
         nkb1 = (2 * Dobj + Dp + 15) // 16
+        kb1 = max(8, (nkb1 + gs_ - 1) // gs_) if gs_ > 1 else 0
+        seg_ok = Dobj % 16 == 0 and Dp % 16 == 0
         t1 = b.linear([seg(obj, hip.SEG_GATHER, idx=g.s, width=Dobj), seg(pred, width=Dp),
                        seg(obj, hip.SEG_GATHER, idx=g.o, width=Dobj)], L['n1a'], T, fuse_next=has_proj,
-                      split=max(8, (nkb1 + gs_ - 1) // gs_) if gs_ > 1 else False)                        # relu deferred
+                      split=kb1 if kb1 and (not seg_ok or max(Dobj, Dp) // 16 <= 96) else False)             # relu deferred
         if has_proj:
             b.fork(2)
             # (one K slice: with the triple-row product the launch then stays within the 512 workgroups that are resident at once)
