@@ -1114,6 +1114,8 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
 }
 }  // namespace
 
+extern "C" int es_rows_get_kernel_family(void) { return g_rows_family; }
+
 extern "C" int es_rows_set_kernel_family(int family) {
     ES_REQUIRE(family == 0 || family == 1, "es_rows_set_kernel_family: %d", family);
     g_rows_family = family;

@@ -278,7 +278,8 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
 }
 
 namespace {
-constexpr char ES_MODEL_MAGIC[8] = {'E', 'S', 'M', 'O', 'D', 'E', 'L', '1'};
+constexpr char ES_MODEL_MAGIC[8] = {'E', 'S', 'M', 'O', 'D', 'E', 'L', '2'};     // '2' (round 5): the route options follow the header
+constexpr int ES_MODEL_OPT_BYTES = 512;
 struct ModelHeader { char magic[8]; uint32_t abi, n_buffers, n_ops, n_regions, op_size, pad; };
 struct RegionRec { char name[32]; uint32_t buffer, pad; uint64_t offset, bytes; };
 constexpr uint64_t OFF_BITS = 40;
@@ -339,6 +340,12 @@ extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buf
     h.abi = ES_ABI_VERSION; h.n_buffers = (uint32_t)n_buffers; h.n_ops = (uint32_t)ops.size(); h.n_regions = (uint32_t)n_regions;
     h.op_size = (uint32_t)sizeof(es_op);
     bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
+    {   // the route options this plan was built (and validated) under: a replay under other values would cut fp32 sums elsewhere
+        char opt[ES_MODEL_OPT_BYTES];
+        memset(opt, 0, sizeof(opt));
+        es_options_string(opt, ES_MODEL_OPT_BYTES);
+        ok = ok && fwrite(opt, 1, ES_MODEL_OPT_BYTES, fp) == ES_MODEL_OPT_BYTES;
+    }
     for (int i = 0; i < n_buffers && ok; ++i) { const uint64_t b = buffers[i].bytes | (scratch[i] ? ES_BUF_SCRATCH : 0); ok = fwrite(&b, 8, 1, fp) == 1; }
     for (int i = 0; i < n_regions && ok; ++i) {
         RegionRec r{};
@@ -362,6 +369,32 @@ extern "C" int es_model_save(const char* path, const es_plan* plan, const es_buf
     return 0;
 }
 
+// every numerics-affecting route option of the library as one string: "rows_family=1;conv_tile=0;..."
+extern "C" int es_options_string(char* out, int cap) {
+    std::string s = "rows_family=" + std::to_string(es_rows_get_kernel_family()) + ";";
+    char v[ES_MODEL_OPT_BYTES];
+    es_vol_options(v, (int)sizeof(v));
+    s += v;
+    if (out && cap > 0) { strncpy(out, s.c_str(), (size_t)cap - 1); out[cap - 1] = 0; }
+    return (int)s.size() + 1;
+}
+
+// the route options recorded in a model file (no device needed)
+extern "C" int es_model_file_options(const char* path, char* out, int cap) {
+    ES_REQUIRE(path && out && cap > 0, "es_model_file_options: bad args");
+    FILE* fp = fopen(path, "rb");
+    ES_REQUIRE(fp, "es_model_file_options: cannot open %s", path);
+    ModelHeader h{};
+    char opt[ES_MODEL_OPT_BYTES];
+    const bool ok = fread(&h, sizeof(h), 1, fp) == 1 && !memcmp(h.magic, ES_MODEL_MAGIC, 8) && fread(opt, 1, ES_MODEL_OPT_BYTES, fp) == ES_MODEL_OPT_BYTES;
+    fclose(fp);
+    ES_REQUIRE(ok, "es_model_file_options: %s is not a model file of this format", path);
+    opt[ES_MODEL_OPT_BYTES - 1] = 0;
+    strncpy(out, opt, (size_t)cap - 1);
+    out[cap - 1] = 0;
+    return 0;
+}
+
 extern "C" void es_model_free(es_model* m) {
     if (!m) return;
     if (m->plan) es_plan_destroy(m->plan);
@@ -377,6 +410,18 @@ static es_model* model_load_impl(const char* path, FILE* fp, es_model* m) {
     // the header is untrusted input: bound every count before it sizes an allocation
     if (h.n_buffers == 0 || h.n_buffers > ES_MAX_BUFFERS || h.n_ops == 0 || h.n_ops > ES_MAX_OPS || h.n_regions > ES_MAX_REGIONS)
         return fail("implausible header counts");
+    {
+        char opt[ES_MODEL_OPT_BYTES], cur[ES_MODEL_OPT_BYTES];
+        if (fread(opt, 1, ES_MODEL_OPT_BYTES, fp) != ES_MODEL_OPT_BYTES) return fail("truncated route options");
+        opt[ES_MODEL_OPT_BYTES - 1] = 0;
+        memset(cur, 0, sizeof(cur));
+        es_options_string(cur, ES_MODEL_OPT_BYTES);
+        if (strcmp(opt, cur)) {
+            es_set_error("es_model_load(%s): written under route options '%s', this process runs '%s' (es_vol_set_option / es_rows_set_kernel_family): "
+                         "the replay would cut its sums elsewhere", path, opt, cur);
+            return nullptr;
+        }
+    }
     m->sizes.resize(h.n_buffers);
     std::vector<bool> scratch(h.n_buffers);
     size_t free_b = 0, total_b = 0, need = 0;

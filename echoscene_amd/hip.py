@@ -136,6 +136,11 @@ EXPORTS = {
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_linear_rows_multi_f32': (C.c_int, [C.POINTER(C.POINTER(LinearArgs)), C.c_int, C.c_void_p]),
     'es_rows_set_kernel_family': (C.c_int, [C.c_int]),
+    'es_rows_get_kernel_family': (C.c_int, []),
+    'es_vol_set_option': (C.c_int, [C.c_char_p, C.c_int]),
+    'es_vol_options': (C.c_int, [C.c_char_p, C.c_int]),
+    'es_options_string': (C.c_int, [C.c_char_p, C.c_int]),
+    'es_model_file_options': (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     'es_linear_rows_slices': (C.c_int, [C.POINTER(LinearArgs), C.POINTER(C.c_int)]),
     'es_linear_rows_auto_slices': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),

@@ -16,6 +16,21 @@ from .hip import ConvArgs, GNArgs, LNArgs, AttnArgs, GegluArgs, ToClArgs, StemAr
 from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn)
 
 
+# Planner constants of the volume path (round 5: module constants, not environment switches -- they decide which products a plan
+# holds and which tensors exist, i.e. the bits; tests / A-B tools set the attributes).
+VOL_FOLD_FFO = True        # FeedForward output + proj_out as ONE K-concatenated product (round 4: -11 launches per step)
+VOL_GN_F16 = True          # a ResBlock's conv1 -> GroupNorm -> conv2 intermediate written once, as f16, with the conv's row-group sums
+VOL_GN_RG_ANY = False      # tests: ask every producing conv for the row-group sums, whatever route it takes
+
+
+def _gn_rg():
+    """the library's route option `gn_rg` (es_vol_set_option): GroupNorm statistics from the producing conv's row-group sums"""
+    buf = C.create_string_buffer(512)
+    hip.lib().es_vol_options(buf, 512)
+    opts = dict(kv.split('=') for kv in buf.value.decode().strip(';').split(';'))
+    return int(opts.get('gn_rg', '1')) != 0
+
+
 class PackedConv:
     """f16 [Npad][taps][Cin32] image of a conv / linear weight + fp32 bias on the device."""
 
@@ -155,7 +170,7 @@ class UNet3DWeights:
                 # FeedForward output + proj_out as ONE K-concatenated product (round 4): with t3 = ff2(gg) + t2 (attention.py:243-245)
                 # and out = proj_out(t3) + x_in (:385-396),  out = (Wp W2) gg + Wp t2 + (Wp b2 + bp) + x_in -- the kernel's second
                 # contraction phase (a2 / w2) carries the t2 term; the [M, C] tensor t3 and one HBM-bound launch per block disappear
-                if os.environ.get('ES_VOL_FOLD_FFO', '1') != '0':
+                if VOL_FOLD_FFO:
                     W2, b2 = sd[tb + '.ff.net.2.weight'].double(), sd[tb + '.ff.net.2.bias'].double()
                     Wp, bp = sd[name + '.proj_out.weight'].flatten(1).double(), sd[name + '.proj_out.bias'].double()
                     d['ffo'] = PackedConv((Wp @ W2).float(), None, device)
@@ -266,7 +281,7 @@ class VolBuilderMixin:
         """The conv op of this plan that writes the fp32 tensor x and would form its row-group sums in its own epilogue
         (es_conv_emits_gn_stats), or None: x comes from elsewhere (stem output, another plan), the shapes do not allow it, or the
         conv takes a route behind which the sums would cost a pass over the output -- what the GroupNorm's statistics pass costs."""
-        if os.environ.get('ES_GN_RG', '1') == '0' or V % 64 or x is None:
+        if not _gn_rg() or V % 64 or x is None:
             return None
         ent = getattr(self, '_conv_of', {}).get(x.data_ptr())
         if ent is None or ent[1] != M or ent[2] != Cx:
@@ -274,8 +289,8 @@ class VolBuilderMixin:
         op = self.ops[ent[0]]
         if op.kind != hip.OP_CONV or op.u.conv.out_f32 != x.data_ptr():
             return None
-        # (ES_GN_RG_ANY=1, tests: ask whatever the route -- the sums then come from k_rowgroup_stats behind the conv)
-        if os.environ.get('ES_GN_RG_ANY', '0') != '1':
+        # (VOL_GN_RG_ANY, tests: ask whatever the route -- the sums then come from k_rowgroup_stats behind the conv)
+        if not VOL_GN_RG_ANY:
             q = ConvArgs.from_buffer_copy(op.u.conv)
             if q.O_hint > q.O:
                 # a deterministic shard takes the decision of the WHOLE problem: where the unsharded run reduces row-group sums
@@ -319,7 +334,7 @@ class VolBuilderMixin:
         idx = self.conv(a_f16, pc, O, dims, rowvec=rowvec, out_f16=h16)
         op = self.ops[idx]
         L = hip.lib()
-        if V % 64 == 0 and os.environ.get('ES_GN_RG', '1') != '0' and os.environ.get('ES_GN_F16', '1') != '0':
+        if V % 64 == 0 and _gn_rg() and VOL_GN_F16:
             whole = ConvArgs.from_buffer_copy(op.u.conv)
             if whole.O_hint > whole.O:
                 whole.O, whole.O_hint = whole.O_hint, 0

@@ -147,6 +147,17 @@ int es_linear_rows_multi_f32(const es_linear_args* const* args, int n, es_stream
  * products with the same K slices; the order of additions inside a slice differs, so results agree to rounding, not bit for bit.
  * For A/B tools and tests -- set it before plans are captured. */
 int es_rows_set_kernel_family(int family);
+int es_rows_get_kernel_family(void);
+
+/* Route options of the volume path (round 5).  Everything that decides where an fp32 sum is cut or which kernel family multiplies --
+ * i.e. the bits of the results -- is a process-wide option with a constant default; the library reads NO environment variable for
+ * them (until round 4 they were getenv switches: two ranks, or a saving and a replaying process, with different environments silently
+ * disagreed).  Names: conv_tile (128: force 128-row tiles), conv_force256, conv_ws, conv_wssplit, conv_wss_target, conv_deep,
+ * conv_tinysplit, gn_rg.  es_model_save records es_options_string() in the file; es_model_load refuses a file written under other values. */
+int es_vol_set_option(const char* name, int value);
+int es_vol_options(char* out, int cap);                 /* "name=value;..." of the volume-path options; returns the length needed */
+int es_options_string(char* out, int cap);              /* + "rows_family=..." : every numerics-affecting option of the library */
+int es_model_file_options(const char* path, char* out, int cap);   /* the options string recorded in a model file (no device needed) */
 /* number of slices the launch will run for `args` (and the rounded kb_per_slice) -- the planner sizes the slab buffer with it */
 int es_linear_rows_slices(const es_linear_args* args, int* kb_per_slice);
 /* the library's default kb_per_slice for a [*, K] x [K, N] product whose slices must be multiples of kalign_cols columns

@@ -17,6 +17,29 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'slow: full-width CPU oracle cases (tens of seconds)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _route_options_of_this_test_process():
+    """The library reads no environment variable for its numerics-affecting route options (round 5).  A test that wants another route
+    re-runs tests in a subprocess with ES_TEST_VOL_OPTIONS="name=value,..." -- a variable of THIS harness, applied here through the
+    explicit API (es_vol_set_option) before any plan is built."""
+    spec = os.environ.get('ES_TEST_VOL_OPTIONS', '')
+    if spec:
+        from echoscene_amd import hip
+        for kv in spec.split(','):
+            k, v = kv.split('=')
+            hip.check(hip.lib().es_vol_set_option(k.encode(), int(v)), 'es_vol_set_option')
+    yield
+
+
+def route_options():
+    """the library's current route options as a dict"""
+    import ctypes
+    from echoscene_amd import hip
+    buf = ctypes.create_string_buffer(1024)
+    hip.lib().es_options_string(buf, 1024)
+    return dict(kv.split('=') for kv in buf.value.decode().strip(';').split(';'))
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + '.npz'))
     return {k: torch.from_numpy(np.asarray(d[k])) for k in d.files}

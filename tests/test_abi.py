@@ -177,3 +177,47 @@ def test_conv_route_query_for_groupnorm_sums_is_host_only():
     assert L.es_conv_emits_gn_stats(C.byref(args(4096, (2, 4, 4), 64, 224))) == 0         # 32 voxels per object
     bad = args(32, (16, 16, 16), 100, 224)                                                # Cin not a multiple of 32
     assert L.es_conv_emits_gn_stats(C.byref(bad)) == -1 and b'Cin' in L.es_last_error()
+
+
+def test_route_options_are_explicit_and_recorded(L, tmp_path):
+    """VERDICT r4 #6 / ADVICE r4: everything that decides where an fp32 sum is cut is a process-wide OPTION with a constant default,
+    set only through the API -- the library reads no environment variable for it -- and the options string is what es_model_save writes
+    behind the header of a model file (es_model_load compares it with the loading process's)."""
+    import ctypes as C
+    import os
+    import re
+    buf = C.create_string_buffer(1024)
+    assert L.es_options_string(buf, 1024) > 0
+    s = buf.value.decode()
+    opts = dict(kv.split('=') for kv in s.strip(';').split(';'))
+    assert opts == {'rows_family': '1', 'conv_tile': '0', 'conv_force256': '0', 'conv_ws': '1', 'conv_wssplit': '1', 'conv_wss_target': '256',
+                    'conv_deep': '1', 'conv_tinysplit': '1', 'gn_rg': '1'}, opts
+    # set / read back / restore; unknown names are errors
+    assert L.es_vol_set_option(b'conv_wss_target', 512) == 0
+    L.es_options_string(buf, 1024)
+    assert 'conv_wss_target=512;' in buf.value.decode()
+    assert L.es_vol_set_option(b'conv_wss_target', 256) == 0
+    assert L.es_vol_set_option(b'no_such_option', 1) != 0
+    # the environment is not consulted: the old switch names change nothing
+    for name in ('ES_CONV_WSSPLIT', 'ES_CONV_TINYSPLIT', 'ES_CONV_WSS_TARGET', 'ES_CONV_DEEP', 'ES_GN_RG', 'ES_CONV_WS', 'ES_CONV_TILE', 'ES_CONV_FORCE256'):
+        os.environ[name] = '0'
+    try:
+        L.es_options_string(buf, 1024)
+        assert buf.value.decode() == s
+    finally:
+        for name in ('ES_CONV_WSSPLIT', 'ES_CONV_TINYSPLIT', 'ES_CONV_WSS_TARGET', 'ES_CONV_DEEP', 'ES_GN_RG', 'ES_CONV_WS', 'ES_CONV_TILE', 'ES_CONV_FORCE256'):
+            del os.environ[name]
+    # no getenv of a numerics-affecting switch is left in the sources: the remaining ones are listed as timing-only / debugging
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {'ES_CONV_N16', 'ES_CONV_LINWS', 'ES_LIN_RING', 'ES_DEBUG_SYNC', 'ES_ROWS_FUSE', 'ES_ROWS_PREFETCH', 'ES_ROWS_NT2', 'ES_ROWS_U1', 'ES_ROWS_DBG'}
+    found = set()
+    for f in os.listdir(os.path.join(here, 'echoscene_amd', 'csrc')):
+        if f.endswith(('.hip', '.h')):
+            found |= set(re.findall(r'getenv\("(\w+)"\)', open(os.path.join(here, 'echoscene_amd', 'csrc', f)).read()))
+    assert found <= allowed, found - allowed
+    # a model file carries the string right behind its 32-byte header (format 'ESMODEL2'): es_model_file_options reads it back
+    path = str(tmp_path / 'fake.esmodel')
+    with open(path, 'wb') as fp:
+        fp.write(b'ESMODEL2' + bytes(24) + s.encode().ljust(512, b'\0'))
+    out = C.create_string_buffer(1024)
+    assert L.es_model_file_options(path.encode(), out, 1024) == 0 and out.value.decode() == s

@@ -474,6 +474,19 @@ def test_model_files_replayed_by_a_c_host(tmp_path):
     x_py = lden.sample(oe, triples, noise, n_steps=30).cpu()
     f_lay = str(tmp_path / 'layout.esm')
     lden.save_model(f_lay, oe, triples)
+    # round 5: the file records the route options it was built under (es_model_load refuses a file written under other values)
+    import ctypes
+    from conftest import route_options
+    from echoscene_amd import hip
+    rec = ctypes.create_string_buffer(1024)
+    assert hip.lib().es_model_file_options(f_lay.encode(), rec, 1024) == 0
+    assert dict(kv.split('=') for kv in rec.value.decode().strip(';').split(';')) == route_options()
+    hip.check(hip.lib().es_vol_set_option(b'conv_wss_target', 512), 'es_vol_set_option')
+    try:
+        assert not hip.lib().es_model_load(f_lay.encode()), 'a model file written under other route options must be refused'
+        assert b'route options' in hip.lib().es_last_error()
+    finally:
+        hip.check(hip.lib().es_vol_set_option(b'conv_wss_target', 256), 'es_vol_set_option')
     x_c = run_c('layout', f_lay, noise.reshape(noise.shape[0], -1), 30, (O, 8))
     assert torch.equal(x_c, x_py), (x_c - x_py).abs().max()
     # shape loop

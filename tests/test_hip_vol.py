@@ -498,6 +498,67 @@ def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world, O):
     assert torch.equal(z, z_ref), 'max abs diff %.3e' % (z - z_ref).abs().max().item()
 
 
+def _run_shards(shards, uc, triples, noise1, nst, dev):
+    for sh in shards:
+        st = sh._plan_for(uc, triples)
+        st['x'].copy_(noise1.to(dev).expand(st['hi'] - st['lo'], 3, 16, 16, 16))
+        sh._cur, sh._use_graph = st, True
+    for i in range(nst):
+        codes = torch.cat([sh.codes_local(i)[:sh._cur['hi'] - sh._cur['lo']].clone() for sh in shards], 0)
+        for sh in shards:
+            sh.step(i, codes)
+    return torch.cat([sh.latents_local() for sh in shards], 0)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_tuned_object_shards_vs_unsharded_run(dev, world):
+    """``ShapeDenoiser(deterministic=False)`` -- the mode the strong-scaling figures quote: every rank picks its K
+    splits / tiles from its LOCAL object count -- had no numeric test.  O = 32 at the shipped widths over 2 and 8 shards on one
+    GPU, 2 DDIM steps (the decomposition of ``test_object_shards_equal_unsharded_bitwise``): equal to the unsharded run up to the
+    fp32 summation order of fp16-operand products -- stated bar allclose(2e-2, 2e-2), the measured maximum is printed."""
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    O, mc, ctx = 32, 224, 1280
+    objs, triples = synth.synthetic_graph(O, seed=6)
+    uc = _rnd((O, 1, ctx), 52)
+    noise1 = synth.shape_noise(seed=7)
+    p = escfg.shape_unet_params(mc)
+    p['context_dim'] = ctx
+    df = DiffusionUNet(p)
+    synth.seeded_fill_(df, prefix='unet3d_full.')
+    mpar = escfg.shape_df_conf().model.params
+    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev).sample(uc, triples, noise1, n_steps=2)
+    shards = [ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, rank=r, world=world, deterministic=False) for r in range(world)]
+    z = _run_shards(shards, uc, triples, noise1, 2, dev)
+    d = (z - z_ref).abs().max().item()
+    rms = ((z - z_ref).pow(2).mean().sqrt() / z_ref.pow(2).mean().sqrt()).item()
+    print('tuned shards, world %d, O = 32, 2 DDIM steps vs the unsharded run: max abs diff %.3e (|z| max %.2f), rel rms %.3e'
+          % (world, d, z_ref.abs().max().item(), rms))
+    assert torch.allclose(z, z_ref, atol=2e-2, rtol=2e-2), d
+
+
+def test_tuned_object_shards_vs_reference_trajectory_O16(dev):
+    """The tuned shard mode against the REFERENCE: ``shape_traj_full_O16`` (two steps of the reference's own DDIMSampler at
+    model_channels 224, 16 objects) stepped as 8 tuned shards of 2 objects -- the kernel routes of a few-objects-per-GPU rank
+    (64-row tiles, K-short linear launches, local split-K factors).  Bar: the product path's fp16-operand tolerance."""
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    g = load_golden('shape_traj_full_O16')
+    df = DiffusionUNet(escfg.shape_unet_params(224))
+    synth.seeded_fill_(df, prefix='unet3d_full.')
+    mpar = escfg.shape_df_conf().model.params
+    noise1 = synth.shape_noise(seed=7)
+    world = 8
+    for k in (1, 2):
+        shards = [ShapeDenoiser(df, mpar, ddim_steps=100, device=dev, rank=r, world=world, deterministic=False) for r in range(world)]
+        z = _run_shards(shards, g['uc_s'], g['triples'], noise1, k, dev).cpu()
+        mx = (z - g['z_steps'][k - 1]).abs().max().item()
+        print('tuned shards (8 x 2 objects), %d DDIM step(s) vs the reference trajectory: max abs err %.2e' % (k, mx))
+        assert torch.allclose(z, g['z_steps'][k - 1], atol=2e-2, rtol=2e-2), (k, mx)
+        del shards
+        torch.cuda.empty_cache()
+
+
 # ---- SURVEY.md section 8(f) rank 2: 'concat'-conditioned shape denoiser (sdfusion-txt2shape_concat_mp.yaml) ----
 def _shape_concat(dev, mc, prefix, S):
     from echoscene_amd.model.unet import DiffusionUNet
@@ -559,9 +620,9 @@ def test_conv_ws_at_production_tile_counts(dev, O, dims, Cin, N, skipC):
     D, H, W = dims
     V = D * H * W
     if O * V < 256 * 256:
-        import os
-        if os.environ.get('ES_CONV_FORCE256') != '1':
-            pytest.skip('needs ES_CONV_FORCE256=1 to reach the 256-row kernels at this size (run by test_conv_alternate_kernels)')
+        from conftest import route_options
+        if route_options().get('conv_force256') != '1':
+            pytest.skip('needs the route option conv_force256 = 1 to reach the 256-row kernels at this size (run by test_conv_alternate_kernels)')
     x = _rnd((O, Cin) + dims, 1).half().float()
     wt = (_rnd((N, Cin, 3, 3, 3), 2) / np.sqrt(Cin * 27)).half().float()
     bias = _rnd((N,), 3)
@@ -623,7 +684,8 @@ def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
     from echoscene_amd.plan import Builder, View
     from echoscene_amd.plan_vol import PackedConv
     from echoscene_amd import hip
-    monkeypatch.setenv('ES_GN_RG_ANY', '1')
+    from echoscene_amd import plan_vol
+    monkeypatch.setattr(plan_vol, 'VOL_GN_RG_ANY', True)
     for O, dims, Cin, N, epi in [(17, (16, 16, 16), 32, 224, 1), (2, (4, 8, 8), 64, 448, 0)]:
         D, H, W = dims
         V = D * H * W
@@ -637,7 +699,7 @@ def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
         oa, ob = b.buf(O * V, N, zero=True), b.buf(O * V, N, zero=True)
         ia = b.conv(xcl, PackedConv(wa, ba, dev), O, dims, rowvec=View(b.dev(rv)), out_f32=oa)
         ib = b.conv(xcl, PackedConv(wb, None, dev), O, dims, res=oa, out_f32=ob)
-        if not any(k.startswith('ES_CONV_') for k in os.environ):     # (the A/B switches of test_conv_alternate_kernels re-route)
+        if not os.environ.get('ES_TEST_VOL_OPTIONS'):     # (the route options of test_conv_alternate_kernels re-route)
             import ctypes
             assert hip.lib().es_conv_emits_gn_stats(ctypes.byref(b.ops[ia].u.conv)) == epi
         ga, be = 1 + 0.1 * _rnd((2 * N,), 6), 0.1 * _rnd((2 * N,), 7)
@@ -654,22 +716,24 @@ def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
         cat = torch.cat([oa.view(O, V, N), ob.view(O, V, N)], 2).permute(0, 2, 1).reshape(O, 2 * N, D, H, W).cpu()
         ref = F.silu(F.group_norm(cat, 32, ga, be, 1e-5))
         assert _rel(y, _cl(ref)) < 2e-3
-        monkeypatch.setenv('ES_GN_RG', '0')              # (read by the planner at build time: this GroupNorm passes over the tensors)
+        hip.check(hip.lib().es_vol_set_option(b'gn_rg', 0), 'es_vol_set_option')     # (read by the planner at build time: this GroupNorm passes over the tensors)
         b2 = Builder(dev)
         y2 = b2.buf(O * V, 2 * N, dtype=torch.float16, zero=True)
         i2 = b2.groupnorm(oa, N, ob, N, O, V, b2.dev(ga), b2.dev(be), 1e-5, True, y2)
         assert not b2.ops[i2].u.gn.stats1
         b2.finish().run()
         torch.cuda.synchronize()
-        monkeypatch.delenv('ES_GN_RG')
+        hip.check(hip.lib().es_vol_set_option(b'gn_rg', 1), 'es_vol_set_option')
         assert (y.float() - y2.float()).abs().max() <= 2e-3 * max(1.0, float(y2.float().abs().max()))
 
 
-@pytest.mark.parametrize('env', [{'ES_CONV_WS': '0'}, {'ES_CONV_TILE': '128'}, {'ES_CONV_FORCE256': '1'}, {'ES_CONV_WSSPLIT': '0'}, {'ES_CONV_LINWS': '0'}])
+@pytest.mark.parametrize('env', [{'ES_TEST_VOL_OPTIONS': 'conv_ws=0'}, {'ES_TEST_VOL_OPTIONS': 'conv_tile=128'}, {'ES_TEST_VOL_OPTIONS': 'conv_force256=1'},
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_wssplit=0'}, {'ES_CONV_LINWS': '0'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
     128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
-    (the switches are read once per process).  ES_CONV_FORCE256 routes EVERY conv of those tests (ragged, strided, up-sampled,
+    (route options are process-wide: tests/conftest.py applies ES_TEST_VOL_OPTIONS through es_vol_set_option; ES_CONV_LINWS is a
+    timing-only environment switch).  conv_force256 routes EVERY conv of those tests (ragged, strided, up-sampled,
     1x1, fused skip, GEGLU) through the 256-row producer/consumer kernels, which otherwise only see launches with >= 256
     tiles."""
     import os

@@ -145,3 +145,35 @@ def test_more_ranks_than_objects_does_not_deadlock(tmp_path):
     z3 = torch.load(out)
     z1 = sharded_ddim_loop(_ToyShard(2, 0, 1), 2, 3, 1)
     assert torch.equal(z3, z1)
+
+
+def _worker_uneven8(rank, world, port, out, O, steps):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from echoscene_amd.parallel import sharded_ddim_loop, partition
+    lo, hi, blk = partition(O, world, rank)
+    z = sharded_ddim_loop(_ToyShard(O, rank, world), O, steps, world)
+    torch.save(dict(z=z, lo=lo, hi=hi), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_8_uneven_partition_with_partial_and_empty_shards(tmp_path):
+    """the 8-rank decomposition the driver's SCALE run uses, on an object count the ranks do not divide -- O = 26 over
+    8 ranks is 6 full blocks of 4, one PARTIAL block of 2 and one EMPTY shard.  Every rank (the empty one too) must return the full
+    result of the 1-rank run, bit for bit."""
+    from echoscene_amd.parallel import sharded_ddim_loop, partition
+    O, world, steps = 26, 8, 3
+    shares = [partition(O, world, r)[:2] for r in range(world)]
+    assert [hi - lo for lo, hi in shares] == [4, 4, 4, 4, 4, 4, 2, 0]
+    out = str(tmp_path / 'z%d.pt')
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_uneven8, args=(world, port, out, O, steps), nprocs=world, join=True)
+    z1 = sharded_ddim_loop(_ToyShard(O, 0, 1), O, steps, 1)
+    for r in range(world):
+        got = torch.load(out % r)
+        assert (got['lo'], got['hi']) == shares[r]
+        assert torch.equal(got['z'], z1), r
