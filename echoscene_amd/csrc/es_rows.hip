@@ -589,6 +589,51 @@ extern "C" int es_pack_linear_f32_dev(const float* d_w, int N, int K, float* d_o
     return 0;
 }
 
+// fp64 product for the planners' weight folds (to_out . to_v, proj_out . ff2, W . beta ...) when the model's parameters already live
+// on the GPU: C[N, M] = A[N, K] B[K, M], every element a left fold over k = 0..K-1 of fma(a, b, acc) -- one fixed order whatever the
+// shape or the launch, so two processes (object shards) fold bit-identical weights; a BLAS call gives no such promise.
+// 64x64 tile per workgroup, 4x4 outputs per thread, 16-deep LDS panels.
+__global__ __launch_bounds__(256) void k_matmul_f64(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ Cm, int N, int K, int M) {
+    __shared__ double sa[16][64 + 1], sb[16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, kk = e & 15;                      // A panel: 64 rows x 16 k (k fastest in memory)
+            sa[kk][r] = (i0 + r < N && k0 + kk < K) ? A[(long)(i0 + r) * K + k0 + kk] : 0.0;
+            const int kb = e >> 6, c = e & 63;                      // B panel: 16 k x 64 columns
+            sb[kb][c] = (k0 + kb < K && j0 + c < M) ? B[(long)(k0 + kb) * M + j0 + c] : 0.0;
+        }
+        __syncthreads();
+        const int kn = K - k0 < 16 ? K - k0 : 16;                   // (the zero padding is never added: the fold stops at K)
+        for (int kk = 0; kk < kn; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = sa[kk][ty * 4 + u]; b[u] = sb[kk][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+            if (i < N && j < M) Cm[(long)i * M + j] = acc[u][v];
+        }
+}
+
+extern "C" int es_matmul_f64(const double* d_a, const double* d_b, double* d_c, int N, int K, int M, es_stream stream) {
+    ES_REQUIRE(d_a && d_b && d_c && N > 0 && K > 0 && M > 0, "es_matmul_f64: N=%d K=%d M=%d", N, K, M);
+    hipLaunchKernelGGL(k_matmul_f64, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, d_a, d_b, d_c, N, K, M);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // GEGLU variant: W[2*Nh, K] = [value rows | gate rows]  ->  rows interleaved per 16-row tile as 8 value + 8 gate,
 // then packed as usual.  h_bias (2*Nh, may be NULL) is permuted into h_bias_out the same way.
 extern "C" int es_pack_linear_geglu_f32(const float* w, const float* h_bias, int Nh, int K, float* out, float* h_bias_out) {

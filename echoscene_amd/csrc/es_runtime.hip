@@ -255,10 +255,10 @@ extern "C" int es_op_pointer_offsets(int kind, size_t* out, int cap) {
         case ES_OP_COPY: v = {ES_PTR(copy.dst), ES_PTR(copy.src)}; break;
         case ES_OP_CONV: case ES_OP_CONV_F32:
             v = {ES_PTR(conv.a), ES_PTR(conv.w), ES_PTR(conv.a2), ES_PTR(conv.w2), ES_PTR(conv.bias), ES_PTR(conv.rowvec), ES_PTR(conv.res),
-                 ES_PTR(conv.out_f32), ES_PTR(conv.out_f16), ES_PTR(conv.workspace), ES_PTR(conv.gn_stats_out)};
+                 ES_PTR(conv.out_f32), ES_PTR(conv.out_f16), ES_PTR(conv.workspace), ES_PTR(conv.gn_stats_out), ES_PTR(conv.gn_part_out)};
             break;
         case ES_OP_GN:
-            v = {ES_PTR(gn.x1), ES_PTR(gn.x2), ES_PTR(gn.gamma), ES_PTR(gn.beta), ES_PTR(gn.stats), ES_PTR(gn.y_f16), ES_PTR(gn.raw_f16), ES_PTR(gn.stats1), ES_PTR(gn.stats2)};
+            v = {ES_PTR(gn.x1), ES_PTR(gn.x2), ES_PTR(gn.gamma), ES_PTR(gn.beta), ES_PTR(gn.stats), ES_PTR(gn.y_f16), ES_PTR(gn.raw_f16), ES_PTR(gn.stats1), ES_PTR(gn.stats2), ES_PTR(gn.part_in)};
             break;
         case ES_OP_LN: v = {ES_PTR(ln.x), ES_PTR(ln.gamma), ES_PTR(ln.beta), ES_PTR(ln.y_f16)}; break;
         case ES_OP_ATTN: case ES_OP_ATTN_F32: v = {ES_PTR(attn.qkv), ES_PTR(attn.out_f16)}; break;

@@ -1992,6 +1992,87 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(const es_conv_args a
     }
 }
 
+// The split-K reduction above fused with the statistics pass of the GroupNorm that reads the tensor next (es_conv_args.gn_part_out):
+// the workgroup / thread layout and the summation order of k_gn_partial (one workgroup per (object, voxel tile); lane = 4 channels,
+// 4 voxel rows in flight; per-lane sums over its rows top to bottom, the 4 row lanes combined pairwise, channels -> group left to
+// right), with the element formed here instead of loaded -- slab sum in slab order + bias + rowvec + res, as k_conv_splitk_reduce --
+// and stored on the way.  One launch instead of two, and the same bits as the two.
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce_gn(const es_conv_args a, long M, int V, int S, int vt) {
+    __shared__ float ssum4[4][2048], ssq4[4][2048];
+    float* ssum = ssum4[0];
+    float* ssq = ssq4[0];
+    const int o = blockIdx.y, tile = blockIdx.x, C = a.N;
+    const int v0 = tile * vt;
+    const int nv = min(vt, V - v0);
+    const int c4n = C >> 2;
+    const int cx = threadIdx.x & 63, vy = threadIdx.x >> 6;
+    const long MN = M * a.N;
+    auto elem = [&](int c, int v) -> f4 {
+        const long m = (long)o * V + v0 + v;
+        const float* p = (const float*)a.workspace + m * a.N + c;
+        f4 x = *(const f4*)p;
+        int z = 1;
+        for (; z + 3 < S; z += 4) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN),
+                     t2 = *(const f4*)(p + (long)(z + 2) * MN), t3 = *(const f4*)(p + (long)(z + 3) * MN);
+            x += t0; x += t1; x += t2; x += t3;
+        }
+        if (z + 2 < S) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN), t2 = *(const f4*)(p + (long)(z + 2) * MN);
+            x += t0; x += t1; x += t2;
+        } else if (z + 1 < S) {
+            const f4 t0 = *(const f4*)(p + (long)z * MN), t1 = *(const f4*)(p + (long)(z + 1) * MN);
+            x += t0; x += t1;
+        } else if (z < S) {
+            x += *(const f4*)(p + (long)z * MN);
+        }
+        if (a.bias) x += *(const f4*)&a.bias[c];
+        if (a.rowvec) x += *(const f4*)&a.rowvec[(long)o * a.rowvec_ld + c];
+        if (a.res) x += *(const f4*)&a.res[m * a.out_ld + c];
+        *(f4*)&a.out_f32[m * a.out_ld + c] = x;
+        if (a.out_f16) {
+            h4 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+            *(h4*)((_Float16*)a.out_f16 + m * a.out_ld + c) = hv;
+        }
+        return x;
+    };
+    for (int c4 = cx; c4 < c4n; c4 += 64) {
+        const int c = c4 * 4;
+        f4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+        if (nv == vt && (vt & 15) == 0) {
+            for (int v = vy; v < vt; v += 16) {
+                const f4 x0 = elem(c, v), x1 = elem(c, v + 4), x2 = elem(c, v + 8), x3 = elem(c, v + 12);
+                s += x0; q += x0 * x0; s += x1; q += x1 * x1; s += x2; q += x2 * x2; s += x3; q += x3 * x3;
+            }
+        } else {
+            for (int v = vy; v < nv; v += 4) { const f4 x = elem(c, v); s += x; q += x * x; }
+        }
+        *(f4*)&ssum4[vy][c] = s;
+        *(f4*)&ssq4[vy][c] = q;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        ssum[c] = (ssum4[0][c] + ssum4[1][c]) + (ssum4[2][c] + ssum4[3][c]);
+        ssq[c] = (ssq4[0][c] + ssq4[1][c]) + (ssq4[2][c] + ssq4[3][c]);
+    }
+    __syncthreads();
+    const int gs = C / a.gn_part_groups;
+    if (threadIdx.x < a.gn_part_groups) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < gs; ++k) { s += ssum[threadIdx.x * gs + k]; q += ssq[threadIdx.x * gs + k]; }
+        float* dst = a.gn_part_out + (((long)o * gridDim.x + tile) * a.gn_part_groups + threadIdx.x) * 2;
+        dst[0] = s; dst[1] = q;
+    }
+}
+
+// voxel-tile size of the GroupNorm statistics pass by workgroup count: small problems (few objects per GPU when sharded) get smaller
+// tiles; Oh = the object count of the WHOLE problem (O_hint) so that a shard tiles like the unsharded run
+static inline int gn_voxel_tile(long Oh, int V) {
+    int vt = GN_VT;
+    while (vt > 8 && Oh * ((V + vt - 1) / vt) < 512) vt >>= 1;
+    return vt;
+}
+
 // Row-group sums of es_conv_args.gn_stats_out for the routes whose epilogue does not form them (64- / 128-row tiles, k_linear_ws,
 // split K): one thread per (64-row group, column quad), the summation order of conv_epilogue<STATS_> -- the even rows of the group
 // top to bottom, the odd rows top to bottom, then the two halves -- so that every route leaves the same bits.
@@ -2235,6 +2316,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
                     if (a->out_f16) c.out_f16 = (char*)a->out_f16 + o0 * V * a->out_ld * 2;
                 }
                 c.gn_stats_out = nullptr;                  // (the planes are laid out for the whole tensor: one pass below)
+                c.gn_part_out = nullptr;                   // (never requested: es_conv_emits_gn_part() == 0 for a chunked launch)
                 if (int rc = conv_dispatch(&c, stream, nullptr)) return rc;
             }
             if (a->gn_stats_out) {
@@ -2392,7 +2474,10 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     // k_rowgroup_stats over the finished output
     const bool epi_stats = route256 && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
                            (a->D * a->H * a->W) % 64 == 0;
-    if (emits) { *emits = epi_stats ? 1 : 0; return 0; }
+    // (bit 1) a split launch can form the next GroupNorm's per-tile partial sums in its reduction kernel (gn_part_out)
+    const bool part_ok = S > 1 && !deep && a->out_f32 && !ncdhw && a->N % 4 == 0 && a->N <= 2048 && a->out_ld == a->N && a->gn_part_groups > 0 &&
+                         a->gn_part_groups <= 64 && a->N % a->gn_part_groups == 0;
+    if (emits) { *emits = (epi_stats ? 1 : 0) | (part_ok ? 2 : 0); return 0; }
     {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
@@ -2457,7 +2542,12 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     if (S > 1) {
         const long n4 = M * (a->N / 4);
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
+        if (a->gn_part_out && part_ok) {
+            const int V = a->D * a->H * a->W;
+            const int vt = gn_voxel_tile(a->O_hint > a->O ? a->O_hint : a->O, V);
+            hipLaunchKernelGGL(k_conv_splitk_reduce_gn, dim3((V + vt - 1) / vt, a->O), dim3(256), 0, st, *a, M, V, S, vt);
+        } else
+            hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
     }
     if (want_stats && !stats_done) {
         ES_REQUIRE(a->out_f32, "es_conv_mfma_f16: this launch's route forms gn_stats_out by a pass over the fp32 output: out_f32 must be given "
@@ -2477,7 +2567,12 @@ extern "C" int es_conv_mfma_f16(const es_conv_args* a, es_stream stream) { retur
 // not, -1 on invalid arguments.  Host-only: launches nothing.
 extern "C" int es_conv_emits_gn_stats(const es_conv_args* a) {
     int e = 0;
-    return conv_dispatch(a, nullptr, &e) == 0 ? e : -1;
+    return conv_dispatch(a, nullptr, &e) == 0 ? (e & 1) : -1;
+}
+
+extern "C" int es_conv_emits_gn_part(const es_conv_args* a) {
+    int e = 0;
+    return conv_dispatch(a, nullptr, &e) == 0 ? ((e >> 1) & 1) : -1;
 }
 
 extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
@@ -2487,14 +2582,15 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     ES_REQUIRE(a->stats != nullptr, "es_groupnorm_vol: stats scratch missing");
     // voxel-tile sizes by workgroup count: small problems (few objects per GPU when sharded) get smaller tiles
     const long Oh = a->O_hint > a->O ? a->O_hint : a->O;       // tile sizes from the whole problem when this launch is a shard
-    int vt = GN_VT;
-    while (vt > 8 && Oh * ((a->V + vt - 1) / vt) < 512) vt >>= 1;
+    const int vt = gn_voxel_tile(Oh, a->V);
     const int ntiles = (a->V + vt - 1) / vt;
     float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats
     const bool from_rg = a->stats1 && (!a->x2 || a->stats2) && a->V % 64 == 0 && (a->x1_is_f16 || vo("gn_rg") != 0);
     ES_REQUIRE(!a->x1_is_f16 || (from_rg && !a->x2 && !a->raw_f16),
                "es_groupnorm_vol: an f16 source needs the producer's row-group sums (stats1), one source, no raw copy");
-    if (!from_rg) hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
+    ES_REQUIRE(!a->part_in || (!from_rg && !a->x2), "es_groupnorm_vol: part_in needs one source and no row-group sums");
+    if (a->part_in) part = (float*)a->part_in;
+    else if (!from_rg) hipLaunchKernelGGL(k_gn_partial, dim3(ntiles, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, vt);
     int vpb = 32;
     while (vpb > 8 && (long)a->O * ((a->V + vpb - 1) / vpb) < 512) vpb >>= 1;
     while (vpb < 1024 && (long)a->O * ((a->V + vpb - 1) / vpb) > 16384) vpb <<= 1;     // (64^3 volumes: fewer, larger blocks)

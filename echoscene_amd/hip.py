@@ -58,14 +58,14 @@ class ConvArgs(C.Structure):
                 ('a2', C.c_void_p), ('w2', C.c_void_p), ('Cin2', C.c_int32), ('bias', C.c_void_p),
                 ('rowvec', C.c_void_p), ('rowvec_ld', C.c_int32), ('res', C.c_void_p), ('out_f32', C.c_void_p), ('out_f16', C.c_void_p),
                 ('workspace', C.c_void_p), ('splitk', C.c_int32), ('out_ld', C.c_int32), ('O_hint', C.c_int32),
-                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p)]
+                ('epilogue', C.c_int32), ('gn_stats_out', C.c_void_p), ('gn_part_out', C.c_void_p), ('gn_part_groups', C.c_int32)]
 
 
 class GNArgs(C.Structure):
     _fields_ = [('x1', C.c_void_p), ('C1', C.c_int32), ('x2', C.c_void_p), ('C2', C.c_int32), ('O', C.c_int32),
                 ('V', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float), ('gamma', C.c_void_p),
                 ('beta', C.c_void_p), ('silu', C.c_int32), ('stats', C.c_void_p), ('y_f16', C.c_void_p),
-                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p), ('x1_is_f16', C.c_int32), ('y_is_f32', C.c_int32)]
+                ('raw_f16', C.c_void_p), ('O_hint', C.c_int32), ('stats1', C.c_void_p), ('stats2', C.c_void_p), ('x1_is_f16', C.c_int32), ('y_is_f32', C.c_int32), ('part_in', C.c_void_p)]
 
 
 class LNArgs(C.Structure):
@@ -132,6 +132,7 @@ EXPORTS = {
     'es_pack_linear_f32_size': (C.c_size_t, [C.c_int, C.c_int]),
     'es_pack_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_linear_f32_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'es_matmul_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_linear_geglu_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'es_linear_rows_f32': (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
     'es_linear_rows_multi_f32': (C.c_int, [C.POINTER(C.POINTER(LinearArgs)), C.c_int, C.c_void_p]),
@@ -150,6 +151,7 @@ EXPORTS = {
                                      C.c_void_p]),
     'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'es_conv_emits_gn_stats': (C.c_int, [C.POINTER(ConvArgs)]),
+    'es_conv_emits_gn_part': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_conv_f16_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -210,7 +212,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 7:
+        if L.es_abi_version() != 8:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

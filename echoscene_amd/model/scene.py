@@ -270,14 +270,17 @@ class _SceneModel(nn.Module):
         dev = _hip_device(_dev(self))
         if self._setup_w is None:
             # packed GCN weights + the three embedding tables the glue reads; dropped by invalidate()
-            sd = {k: v.detach().cpu() for k, v in nn.Module.state_dict(self).items()
+            from ..plan import own
+            # (parameters that already live on the device are read in place: samplers.state_dict_for)
+            here = lambda v: v.detach() if (v.is_cuda and v.device == dev) else v.detach().cpu()
+            sd = {k: here(v) for k, v in nn.Module.state_dict(self).items()
                   if k.startswith(('gconv_net_ec.', 'gconv_net_manipulation.', 'obj_embeddings_ec.', 'pred_embeddings_ec.',
                                    'pred_embeddings_man_dc.'))}
             # (the embedding tables live on the device: the lookups below are device-side row gathers, the CLIP features are
             #  never copied to the host -- VERDICT r2 #9)
             pool = self.gconv_net_ec.gconvs[0].pooling          # 'avg' (every shipped args.json) or 'sum'
             self._setup_w = (GCNWeights(sd, 'gconv_net_ec', dev, pool), GCNWeights(sd, 'gconv_net_manipulation', dev, pool),
-                             {k: sd[k + '.weight'].float().to(dev) for k in ('obj_embeddings_ec', 'pred_embeddings_ec',
+                             {k: own(sd[k + '.weight'], dev) for k in ('obj_embeddings_ec', 'pred_embeddings_ec',
                                                                              'pred_embeddings_man_dc')})
         w_ec, w_man, tabs = self._setup_w
         sd = {k + '.weight': v for k, v in tabs.items()}

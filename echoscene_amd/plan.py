@@ -144,6 +144,32 @@ def norm_segs(views, gamma, beta, eps, silu, C=None, groups=32):
     return out
 
 
+def own(t, device, dtype=torch.float32):
+    """Contiguous ``dtype`` copy of t on ``device`` that the plan OWNS.  The weight planners read a model's parameters in place when
+    the model already sits on the GPU (samplers.state_dict_for): whatever a plan keeps must not alias a live parameter."""
+    r = t.detach().to(device=device, dtype=dtype).contiguous()
+    return r.clone() if r.data_ptr() == t.data_ptr() else r
+
+
+def mm64(A, B):
+    """A @ B in fp64 for the weight folds.  Host tensors: torch.  Device tensors: the library's es_matmul_f64 -- a fixed left fold
+    over k per element, so that every process (object shards fold their own copy) derives bit-identical weights; a BLAS call on the
+    GPU promises no summation order.  A vector B gives a vector."""
+    A = A.detach().double()
+    B = B.detach().double()
+    if not A.is_cuda:
+        return A @ B.to(A.device)
+    vec = B.dim() == 1
+    Bm = (B.unsqueeze(1) if vec else B).to(A.device).contiguous()
+    A = A.contiguous()
+    assert A.dim() == 2 and Bm.dim() == 2 and A.shape[1] == Bm.shape[0], (A.shape, B.shape)
+    with torch.cuda.device(A.device):
+        out = torch.empty(A.shape[0], Bm.shape[1], dtype=torch.float64, device=A.device)
+        hip.check(hip.lib().es_matmul_f64(hip.ptr(A), hip.ptr(Bm), hip.ptr(out), A.shape[0], A.shape[1], Bm.shape[1], hip.current_stream()),
+                  'es_matmul_f64')
+    return out[:, 0] if vec else out
+
+
 class PackedLinear:
     """Device image of one (possibly fused) linear layer in MFMA fragment order.
     ``geglu=True``: W = [value rows | gate rows] of a GEGLU projection; rows are interleaved per 16-row tile so
@@ -168,7 +194,7 @@ class PackedLinear:
                 out = torch.empty(n, dtype=torch.float32, device=device)
                 hip.check(L.es_pack_linear_f32_dev(hip.ptr(Wd), self.N, self.K, hip.ptr(out), hip.current_stream()), 'es_pack_linear_f32_dev')
             self.w = out
-            self.b = None if b is None else b.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.b = None if b is None else own(b, device)
             self.weight_bytes = self.N * self.K * 4
             self.nbatch = 1
             return
@@ -217,8 +243,8 @@ def fold_affine(W, b, gamma, beta):
     product directly (no SiLU in between) moves into the weights (fp64 fold) -- the kernels then neither load nor apply it
     (round 5: the norm prologue of 32 launches per layout step lost a third of its loads)."""
     Wd = W.detach().double()
-    g, be = gamma.detach().double(), beta.detach().double()
-    bb = (b.detach().double() if b is not None else torch.zeros(W.shape[0], dtype=torch.float64)) + Wd @ be
+    g, be = gamma.detach().double().to(Wd.device), beta.detach().double().to(Wd.device)
+    bb = (b.detach().double().to(Wd.device) if b is not None else torch.zeros(W.shape[0], dtype=torch.float64, device=Wd.device)) + mm64(Wd, be)
     return (Wd * g[None, :]).float(), bb.float()
 
 
@@ -815,7 +841,7 @@ class UNet1DWeights:
         self.in_ch, self.out_ch = net.in_channels, net.out_channels
         self.concat = bool(getattr(net, 'concat', False))
         self.heads = net.num_heads
-        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        dv = lambda k: own(sd[k], device)
         P = lambda w, bname: PackedLinear(centre_tap(sd[w]), sd[bname] if bname else None, device)
         self.te0 = P('time_embed.0.weight', 'time_embed.0.bias')
         self.te2 = P('time_embed.2.weight', 'time_embed.2.bias')
@@ -863,7 +889,7 @@ class UNet1DWeights:
                 bv = sd[name + '.qkv.bias'].double()[vrows]
                 Wp = centre_tap(sd[name + '.proj_out.weight']).double()
                 d['gn'] = (None, None)               # (affine folded into the product)
-                d['av'] = PackedLinear(*fold_affine(Wp @ Wv, Wp @ bv + sd[name + '.proj_out.bias'].double(),
+                d['av'] = PackedLinear(*fold_affine(mm64(Wp, Wv), mm64(Wp, bv) + sd[name + '.proj_out.bias'].double(),
                                                     sd[name + '.norm.weight'], sd[name + '.norm.bias']), device)
             elif kind == 'attn':
                 tb = name + '.transformer_blocks.0'
@@ -875,22 +901,21 @@ class UNet1DWeights:
                 d['ln3'] = (None, None)
                 # one token, one key: softmax == 1, so attention(x) = to_out(to_v(.)) exactly
                 # ... and the two linears fold into one matrix (fp64): to_out . to_v
-                d['vo1'] = PackedLinear(*fold_affine(sd[tb + '.attn1.to_out.0.weight'].double() @ sd[tb + '.attn1.to_v.weight'].double(),
+                d['vo1'] = PackedLinear(*fold_affine(mm64(sd[tb + '.attn1.to_out.0.weight'], sd[tb + '.attn1.to_v.weight']),
                                                      sd[tb + '.attn1.to_out.0.bias'], sd[tb + '.norm1.weight'], sd[tb + '.norm1.bias']), device)
-                d['o2'] = (sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_out.0.bias'])
                 d['ff1'] = PackedLinear(*fold_affine(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'],
                                                      sd[tb + '.norm3.weight'], sd[tb + '.norm3.bias']), device, geglu=True)
                 # x_out = proj_out(ff2(g) + b2 + t2) + x_in is linear in (g, t2): ONE op over the K-concatenation [g | t2] with
                 # [Wpo.Wff2 | Wpo] (folded in fp64) -- one dependent launch less per transformer block
                 Wpo = centre_tap(sd[name + '.proj_out.weight']).double()
                 Wf2 = sd[tb + '.ff.net.2.weight'].double()
-                d['ff2po'] = PackedLinear(torch.cat([Wpo @ Wf2, Wpo], 1).float(),
-                                          (Wpo @ sd[tb + '.ff.net.2.bias'].double() + sd[name + '.proj_out.bias'].double()).float(),
+                d['ff2po'] = PackedLinear(torch.cat([mm64(Wpo, Wf2), Wpo], 1).float(),
+                                          (mm64(Wpo, sd[tb + '.ff.net.2.bias']) + sd[name + '.proj_out.bias'].double()).float(),
                                           device)
                 # cross-attention with ONE key: out = to_out2(to_v2(ctx)) -- linear in ctx, so the two matrices fold into one
                 # [C x ctx_dim] matrix per block (fp64): all blocks' vectors are ONE product per step
                 self.ca[name] = (len(ca_v), it[1])
-                ca_v.append((sd[tb + '.attn2.to_out.0.weight'].double() @ sd[tb + '.attn2.to_v.weight'].double()).float())
+                ca_v.append(mm64(sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_v.weight']).float())
                 ca_b.append(sd[tb + '.attn2.to_out.0.bias'])
             elif kind == 'down':
                 d['conv'] = P(name + '.op.weight', name + '.op.bias')

@@ -13,13 +13,14 @@ import torch
 
 from . import hip
 from .hip import ConvArgs, GNArgs, LNArgs, AttnArgs, GegluArgs, ToClArgs, StemArgs, Op
-from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn)
+from .plan import (Builder, PackedLinear, GCNWeights, View, seg, emit_gcn, own, mm64)
 
 
 # Planner constants of the volume path (round 5: module constants, not environment switches -- they decide which products a plan
 # holds and which tensors exist, i.e. the bits; tests / A-B tools set the attributes).
 VOL_FOLD_FFO = True        # FeedForward output + proj_out as ONE K-concatenated product (round 4: -11 launches per step)
 VOL_GN_F16 = True          # a ResBlock's conv1 -> GroupNorm -> conv2 intermediate written once, as f16, with the conv's row-group sums
+VOL_GN_PART_FUSED = True     # a split-K conv's reduction kernel also forms the next GroupNorm's partial sums (same bits, one launch less)
 VOL_GN_RG_ANY = False      # tests: ask every producing conv for the row-group sums, whatever route it takes
 
 
@@ -71,7 +72,7 @@ class PackedConv:
             hip.check(L.es_pack_conv_f16(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())),
                       'es_pack_conv_f16')
         self.w = out.to(device)
-        self.b = None if b is None else b.detach().float().contiguous().to(device)
+        self.b = None if b is None else own(b, device)
         self.weight_bytes = self.N * cin * self.taps * 2
         self.cin_true = cin
 
@@ -92,7 +93,7 @@ class PackedConv32:
         out = torch.empty(L.es_pack_conv_f32_size(self.N, cin, self.taps), dtype=torch.float32)
         hip.check(L.es_pack_conv_f32(C.c_void_p(W.data_ptr()), self.N, cin, self.taps, C.c_void_p(out.data_ptr())), 'es_pack_conv_f32')
         self.w = out.to(device)
-        self.b = None if b is None else b.detach().float().contiguous().to(device)
+        self.b = None if b is None else own(b, device)
         self.weight_bytes = self.N * cin * self.taps * 4
         self.cin_true = cin
 
@@ -107,7 +108,7 @@ class UNet3DWeights:
         self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
         self.heads = net.num_heads
         self.concat = bool(getattr(net, 'concat', False))
-        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        dv = lambda k: own(sd[k], device)
         PL = lambda w, b: PackedLinear(sd[w], sd[b] if b else None, device)
         PC = lambda w, b: PackedConv(sd[w], sd[b] if b else None, device)
         self.te0 = PL('time_embed.0.weight', 'time_embed.0.bias')
@@ -173,12 +174,12 @@ class UNet3DWeights:
                 if VOL_FOLD_FFO:
                     W2, b2 = sd[tb + '.ff.net.2.weight'].double(), sd[tb + '.ff.net.2.bias'].double()
                     Wp, bp = sd[name + '.proj_out.weight'].flatten(1).double(), sd[name + '.proj_out.bias'].double()
-                    d['ffo'] = PackedConv((Wp @ W2).float(), None, device)
+                    d['ffo'] = PackedConv(mm64(Wp, W2).float(), None, device)
                     d['po'] = PackedConv(Wp.float(), None, device)
-                    d['ffo_bias'] = (Wp @ b2 + bp).float().contiguous().to(device)
+                    d['ffo_bias'] = (mm64(Wp, b2) + bp).float().contiguous().to(device)
                 # cross-attention with one key: to_out2(to_v2(ctx)) folded into one matrix per block (fp64)
                 self.ca[name] = (len(ca_v), it[1])
-                ca_v.append((sd[tb + '.attn2.to_out.0.weight'].double() @ sd[tb + '.attn2.to_v.weight'].double()).float())
+                ca_v.append(mm64(sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_v.weight']).float())
                 ca_b.append(sd[tb + '.attn2.to_out.0.bias'])
             elif kind == 'down':
                 d['conv'] = PC(name + '.op.weight', name + '.op.bias')
@@ -387,6 +388,22 @@ class VolBuilderMixin:
         if p1 is not None and (x2 is None or p2 is not None):
             a.stats1 = self._rowgroup_stats(p1, x1, C1, O * V).data_ptr()
             a.stats2 = self._rowgroup_stats(p2, x2, C2, O * V).data_ptr() if x2 is not None else None
+        elif x2 is None and VOL_GN_PART_FUSED:
+            # x1 written by a split-K conv of this plan: its reduction kernel leaves this GroupNorm's per-tile partial sums
+            # (es_conv_args.gn_part_out; k_gn_partial's own order, the same bits) and the statistics launch is dropped
+            ent = getattr(self, '_conv_of', {}).get(x1.data_ptr())
+            if ent is not None and ent[1] == O * V and ent[2] == C1:
+                op = self.ops[ent[0]]
+                cv = op.u.conv
+                if op.kind == hip.OP_CONV and cv.out_f32 == x1.data_ptr() and not cv.gn_part_out and not cv.gn_stats_out:
+                    cv.gn_part_groups = groups
+                    if hip.lib().es_conv_emits_gn_part(C.byref(cv)) == 1:
+                        pb = self.buf(O * ((V + 7) // 8) * groups * 2, scratch=True)
+                        cv.gn_part_out = pb.data_ptr()
+                        a.part_in = pb.data_ptr()
+                        self.keep.append(pb)
+                    else:
+                        cv.gn_part_groups = 0
         self.keep += [gamma, beta]
         return self._push(hip.OP_GN, 'gn', a)
 
@@ -724,23 +741,22 @@ def _vq_groups(C):
 
 class VQWeights:
     def __init__(self, sd, device):
-        dv = lambda k: sd[k].detach().float().contiguous().to(device)
+        dv = lambda k: own(sd[k], device)
         PC = lambda w, b: PackedConv(sd[w], sd[b] if b else None, device)
         E = sd['quantize.embedding.weight'].detach().double()
         Wp = sd['post_quant_conv.weight'].detach().double().flatten(1)          # [3,3]
-        self.codebook = E.float().contiguous().to(device)
-        self.lut = (E @ Wp.t() + sd['post_quant_conv.bias'].double()).float().contiguous().to(device)
+        self.codebook = own(E, device)
+        self.lut = (mm64(E, Wp.t()) + sd['post_quant_conv.bias'].double()).float().contiguous().to(device)
         self.n_embed = E.shape[0]
         if E.shape[1] != 3:
             raise NotImplementedError('embed_dim != 3')
         d = {k[len('decoder.'):]: v for k, v in sd.items() if k.startswith('decoder.')}
-        self.d = d
         self.conv_in = PackedConv(d['conv_in.weight'], d['conv_in.bias'], device)
 
         def res(p):
-            r = dict(gn1=(d[p + '.norm1.weight'].float().to(device), d[p + '.norm1.bias'].float().to(device)),
+            r = dict(gn1=(own(d[p + '.norm1.weight'], device), own(d[p + '.norm1.bias'], device)),
                      conv1=PackedConv(d[p + '.conv1.weight'], d[p + '.conv1.bias'], device),
-                     gn2=(d[p + '.norm2.weight'].float().to(device), d[p + '.norm2.bias'].float().to(device)),
+                     gn2=(own(d[p + '.norm2.weight'], device), own(d[p + '.norm2.bias'], device)),
                      conv2=PackedConv(d[p + '.conv2.weight'], d[p + '.conv2.bias'], device))
             r['cin'], r['cout'] = d[p + '.conv1.weight'].shape[1], d[p + '.conv1.weight'].shape[0]
             if (p + '.nin_shortcut.weight') in d:
@@ -752,7 +768,7 @@ class VQWeights:
         p = 'mid.attn_1'
         Cc = d[p + '.q.weight'].shape[0]
         self.attn = dict(
-            C=Cc, gn=(d[p + '.norm.weight'].float().to(device), d[p + '.norm.bias'].float().to(device)),
+            C=Cc, gn=(own(d[p + '.norm.weight'], device), own(d[p + '.norm.bias'], device)),
             qkv=PackedConv(torch.cat([d[p + '.q.weight'].flatten(1), d[p + '.k.weight'].flatten(1),
                                       d[p + '.v.weight'].flatten(1)], 0),
                            torch.cat([d[p + '.q.bias'], d[p + '.k.bias'], d[p + '.v.bias']], 0), device),
@@ -768,7 +784,7 @@ class VQWeights:
             if (f'up.{lvl}.upsample.conv.weight') in d:
                 up = PackedConv(d[f'up.{lvl}.upsample.conv.weight'], d[f'up.{lvl}.upsample.conv.bias'], device)
             self.levels.append((blocks, up))
-        self.out_gn = (d['norm_out.weight'].float().to(device), d['norm_out.bias'].float().to(device))
+        self.out_gn = (own(d['norm_out.weight'], device), own(d['norm_out.bias'], device))
         self.conv_out = PackedConv(d['conv_out.weight'], d['conv_out.bias'], device)
 
 

@@ -16,8 +16,18 @@ def _cap(n_triples):
     return max(32, (int(n_triples) + 31) // 32 * 32)
 
 
+def state_dict_for(module, device=None):
+    """The module's state dict as the weight planners read it.  Entries that already live on ``device`` (a GPU) stay there: the
+    fp64 folds and the weight re-layouts then run on the GPU from the parameters in place -- a model moved with ``.cuda()`` used to be
+    downloaded tensor by tensor (1867 copies), folded on the host and uploaded again (1300 copies), 1.5 s of a process's first scene
+    call.  Everything else comes to the host.  The planners never keep an entry itself (plan.own)."""
+    dev = None if device is None else torch.device(device)
+    on_dev = lambda v: dev is not None and dev.type == 'cuda' and v.is_cuda and (dev.index is None or v.device.index == dev.index)
+    return {k: (v.detach() if on_dev(v) else v.detach().cpu()) for k, v in module.state_dict().items()}
+
+
 def _cpu_sd(module):
-    return {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    return state_dict_for(module, None)
 
 
 def gcn_forward(sd, prefix, obj, pred, triples, device=None, weights=None, pooling='avg'):
@@ -43,7 +53,7 @@ class LayoutDenoiser:
     def __init__(self, net, diffusion_kwargs, device=None):
         self.device = device or torch.device('cuda')
         self.net = net
-        self.w = UNet1DWeights(_cpu_sd(net), net, self.device)
+        self.w = UNet1DWeights(state_dict_for(net, self.device), net, self.device)
         dk = dict(diffusion_kwargs)
         if dk.get('model_mean_type', 'eps') != 'eps' or dk.get('model_var_type', 'fixedsmall') != 'fixedsmall':
             raise NotImplementedError('only eps-prediction / fixedsmall is on the sampling path')
@@ -157,7 +167,7 @@ class ShapeDenoiser:
         self.df = df
         net = df.diffusion_net
         self.net = net
-        sd = {k[len('diffusion_net.'):]: v for k, v in _cpu_sd(df).items()}
+        sd = {k[len('diffusion_net.'):]: v for k, v in state_dict_for(df, self.device).items()}
         self.w = UNet3DWeights(sd, net, self.device, precision)
         mp = dict(model_params or {})
         self.ddim_eta = float(ddim_eta)
@@ -435,7 +445,7 @@ class VQDecoder:
 
     def __init__(self, vqvae, device=None, chunk=8):
         self.device = device or torch.device('cuda')
-        self.w = VQWeights(_cpu_sd(vqvae), self.device)
+        self.w = VQWeights(state_dict_for(vqvae, self.device), self.device)
         self.chunk = chunk
         self._plans = {}
 

@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 7
+#define ES_ABI_VERSION 8
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -136,6 +136,9 @@ size_t es_pack_linear_f32_size(int N, int K);
 int es_pack_linear_f32(const float* h_w, int N, int K, float* h_out);
 /* the same image from a weight already on the device (what the Python host uses: the host loop is a strided gather) */
 int es_pack_linear_f32_dev(const float* d_w, int N, int K, float* d_out, es_stream stream);
+/* C[N, M] = A[N, K] B[K, M] in fp64 on the device, every element a left fold over k of fma(a, b, acc): the planners' weight folds
+ * (plan.py mm64) when the model's parameters already live on the GPU -- a fixed summation order, so every process folds the same bits */
+int es_matmul_f64(const double* d_a, const double* d_b, double* d_c, int N, int K, int M, es_stream stream);
 /* GEGLU projection W[2*Nh,K] (value rows | gate rows): interleave per 16-row tile, then pack (ES_ACT_GEGLU) */
 int es_pack_linear_geglu_f32(const float* h_w, const float* h_bias, int Nh, int K, float* h_out, float* h_bias_out);
 
@@ -257,12 +260,22 @@ typedef struct es_conv_args {
                                  rows top to bottom, then the two halves): the same bits whichever route ran.
                                  Requires voxels per object % 64 == 0, channels-last output; out_f32 may be NULL (f16-only output)
                                  when es_conv_emits_gn_stats() == 1: the sums are formed from the fp32 values before rounding     */
+    float* gn_part_out;       /* NULL, or the per-(object, voxel tile, group) partial sums [O][ntiles][gn_part_groups][2] that the
+                                 statistics pass of the NEXT GroupNorm over this tensor alone (es_gn_args.part_in) would form: when
+                                 the launch is split over K (es_conv_emits_gn_part() == 1) its reduction kernel -- which touches
+                                 every output element anyway -- forms them from the values it stores, in that pass's own
+                                 summation order (the same bits), and the GroupNorm runs its apply kernel only.  Ignored
+                                 (nothing written) when es_conv_emits_gn_part() == 0: leave part_in NULL then             */
+    int32_t gn_part_groups;   /* groups of that GroupNorm (N % groups == 0)                                                 */
 } es_conv_args;
 enum { ES_EPI_NONE = 0, ES_EPI_GEGLU = 1 };
 int es_conv_mfma_f16(const es_conv_args* args, es_stream stream);
 /* host-only: 1 when es_conv_mfma_f16(args) would form gn_stats_out inside its own epilogue, 0 when it would need the extra pass,
  * -1 on invalid arguments (es_last_error()).  Launches nothing. */
 int es_conv_emits_gn_stats(const es_conv_args* args);
+/* host-only: 1 when es_conv_mfma_f16(args) would write gn_part_out (a split-K launch with a channels-last fp32 output), else 0;
+ * -1 on invalid arguments.  Launches nothing. */
+int es_conv_emits_gn_part(const es_conv_args* args);
 /* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
  * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
  * block per K step.  h_out holds uint16 bit patterns. */
@@ -293,6 +306,8 @@ typedef struct es_gn_args {
                                         written once, as the operand precision the next contraction reads anyway, openai_model_3d.py:
                                         294-314).  Requires stats1 (the statistics are the conv's sums over its fp32 values), no x2   */
     int32_t y_is_f32;                /* 1: y_f16 / raw_f16 point at FP32 tensors (the fp32-operand validation route, es_conv_f32)       */
+    const float* part_in;            /* NULL, or the partial sums the producing conv's split-K reduction left (es_conv_args.gn_part_out,
+                                        same O / O_hint / V / groups, one source): the statistics pass is skipped             */
 } es_gn_args;
 /* GroupNorm32 (+SiLU) over channels-last volumes: ldm_diffusion_util.py:222-239, eps 1e-5 in
  * ResBlocks, 1e-6 in SpatialTransformer3D (attention.py:77-78). Two kernels: stats (a pass over x, or a reduction of

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(L):
     for name in sorted(declared):
         assert hasattr(raw, name), 'libechoscene_hip.so lacks %s' % name
     assert declared == set(hip.EXPORTS), 'ctypes table and header disagree: %s' % (declared ^ set(hip.EXPORTS))
-    assert L.es_abi_version() == 7
+    assert L.es_abi_version() == 8
 
 
 def test_struct_sizes_match_header(L, tmp_path):
@@ -177,6 +177,17 @@ def test_conv_route_query_for_groupnorm_sums_is_host_only():
     assert L.es_conv_emits_gn_stats(C.byref(args(4096, (2, 4, 4), 64, 224))) == 0         # 32 voxels per object
     bad = args(32, (16, 16, 16), 100, 224)                                                # Cin not a multiple of 32
     assert L.es_conv_emits_gn_stats(C.byref(bad)) == -1 and b'Cin' in L.es_last_error()
+    # the other way a producer helps the next GroupNorm: a launch split over K forms that GroupNorm's per-tile partial sums in its
+    # reduction kernel (gn_part_out) -- exactly the launches above that are too small for the epilogue sums
+    def part(O, dims, cin, n, **kw):
+        a = args(O, dims, cin, n, **kw)
+        a.gn_part_groups = 32
+        return a
+    assert L.es_conv_emits_gn_part(C.byref(part(32, (16, 16, 16), 224, 224))) == 0
+    assert L.es_conv_emits_gn_part(C.byref(part(4, (16, 16, 16), 224, 224))) == 1
+    assert L.es_conv_emits_gn_part(C.byref(part(32, (16, 4, 4), 672, 672))) == 1
+    assert L.es_conv_emits_gn_part(C.byref(args(4, (16, 16, 16), 224, 224))) == 0           # no group count given
+    assert L.es_conv_emits_gn_part(C.byref(bad)) == -1
 
 
 def test_route_options_are_explicit_and_recorded(L, tmp_path):

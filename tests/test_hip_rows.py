@@ -242,6 +242,49 @@ def test_layout_loop_tiny_100_steps_vs_reference_golden(dev, use_graph):
     assert torch.equal(x, x2), 'sampling must be deterministic for fixed noise'
 
 
+@pytest.mark.parametrize('shape', [(672, 672, 2688), (100, 37, 70), (5, 3, 1), (1, 1000, 1)])
+def test_fold_product_on_the_device(dev, shape):
+    """plan.mm64 on device tensors (es_matmul_f64: a fixed left fold over k per element) against the host fp64 product, a vector
+    right-hand side included; two calls leave the same bits."""
+    from echoscene_amd.plan import mm64
+    N, K, M = shape
+    rs = np.random.RandomState(N + K + M)
+    A = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32))
+    B = torch.from_numpy(rs.standard_normal((K, M)).astype(np.float32))
+    ref = A.double() @ B.double()
+    got = mm64(A.to(dev), B.to(dev))
+    got2 = mm64(A.to(dev), B.to(dev))
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float64 and got.is_cuda and torch.equal(got, got2)
+    assert float((got.cpu() - ref).abs().max()) <= 1e-12 * max(1.0, float(ref.abs().max()))
+    if M == 1:
+        v = mm64(A.to(dev), B[:, 0].to(dev))
+        assert v.shape == (N,) and torch.equal(v, got[:, 0])
+
+
+def test_layout_denoiser_from_a_model_on_the_gpu(dev):
+    """The planners read a model's parameters IN PLACE when it already sits on the GPU (samplers.state_dict_for: fp64 folds and
+    re-layouts on the device, no download / upload of every tensor): same golden, and the plan owns everything it keeps -- zeroing
+    the module's parameters afterwards changes nothing."""
+    from echoscene_amd.model.unet import UNet1DModel
+    from echoscene_amd.samplers import LayoutDenoiser
+    g = load_golden('unet1d_full')
+    kw = dict(escfg.layout_denoiser_kwargs(512))
+    kw['concat_dim'] = kw['crossattn_dim'] = 1280
+    net = UNet1DModel(**kw)
+    synth.seeded_fill_(net, prefix='unet1d_full.')
+    net.to(dev)
+    den = LayoutDenoiser(net, escfg.layout_diffusion_kwargs(1000), dev)
+    eps = den.eps(g['box8'], g['obj_embed8'], g['triples8'], iteration=999 - 617)
+    _close(eps, g['eps8'], 1e-4)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.zero_()
+    torch.cuda.synchronize()
+    eps2 = den.eps(g['box8'], g['obj_embed8'], g['triples8'], iteration=999 - 617)
+    assert torch.equal(eps, eps2)
+
+
 def test_unet1d_full_vs_reference_golden(dev):
     """Full-width layout denoiser (config/full_mp.yaml) at O=8 and O=32 (BASELINE configs[1] size)."""
     g = load_golden('unet1d_full')

@@ -287,13 +287,15 @@ def test_shape_stem(dev):
     assert _rel(out, ref) < 1e-5
 
 
-def _shape(dev, mc, ctx, prefix, S, precision='fp16'):
+def _shape(dev, mc, ctx, prefix, S, precision='fp16', on_gpu=False):
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     p = escfg.shape_unet_params(mc)
     p['context_dim'] = ctx
     df = DiffusionUNet(p)
     synth.seeded_fill_(df, prefix=prefix)
+    if on_gpu:
+        df.to(dev)
     return ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=S, device=dev, precision=precision)
 
 
@@ -338,6 +340,23 @@ def test_unet3d_tiny_eps_vs_reference_golden(dev):
     e = _rel(eps, g['eps'])
     print('unet3d tiny: fp16-MFMA eps vs fp32 reference golden: rel err %.3e' % e)
     assert e < 2e-2
+
+
+def test_shape_denoiser_from_a_model_on_the_gpu(dev):
+    """samplers.state_dict_for: parameters that already live on the GPU are folded (fp64, es_matmul_f64) and re-laid out there; same
+    golden as the host route, and the plan keeps no alias of a parameter."""
+    g = load_golden('unet3d_tiny')
+    den = _shape(dev, 32, 64, 'unet3d_tiny.', 100, on_gpu=True)
+    it = int(np.nonzero(den.sched.timesteps == int(g['t'][0]))[0][0])
+    eps = den.eps(g['x'], g['uc_s'], g['triples'], iteration=it).clone()
+    assert _rel(eps, g['eps']) < 2e-2
+    host = _shape(dev, 32, 64, 'unet3d_tiny.', 100).eps(g['x'], g['uc_s'], g['triples'], iteration=it)
+    assert _rel(eps, host) < 1e-4                      # (fp64 folds in another summation order: a weight may round the other way)
+    with torch.no_grad():
+        for p_ in den.df.parameters():
+            p_.zero_()
+    torch.cuda.synchronize()
+    assert torch.equal(den.eps(g['x'], g['uc_s'], g['triples'], iteration=it), eps)
 
 
 @pytest.mark.parametrize('use_graph', [False, True])
@@ -725,6 +744,49 @@ def test_conv_rowgroup_stats_feed_groupnorm(dev, monkeypatch):
         torch.cuda.synchronize()
         hip.check(hip.lib().es_vol_set_option(b'gn_rg', 1), 'es_vol_set_option')
         assert (y.float() - y2.float()).abs().max() <= 2e-3 * max(1.0, float(y2.float().abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('O,dims,Cin,N,taps,res', [(4, (16, 16, 16), 224, 224, 27, True), (4, (16, 4, 4), 672, 672, 27, False),
+                                                  (3, (16, 8, 8), 448, 448, 27, True), (2, (16, 4, 4), 672, 672, 27, True)])
+def test_splitk_reduction_leaves_the_next_groupnorm_partials(dev, monkeypatch, O, dims, Cin, N, taps, res):
+    """es_conv_args.gn_part_out: a conv launch split over K forms, in its reduction kernel, the per-tile partial sums of the
+    GroupNorm that reads its output next; that GroupNorm then runs its apply kernel only.  The fused kernel repeats the statistics
+    pass's summation order: conv output and GroupNorm output are BIT-identical to the plan with the two separate launches."""
+    import ctypes
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    from echoscene_amd import hip, plan_vol
+    if os.environ.get('ES_TEST_VOL_OPTIONS'):
+        pytest.skip('route options re-route the launch')
+    D, H, W = dims
+    V = D * H * W
+    k = 3 if taps == 27 else 1
+    x = _rnd((O, Cin) + dims, 1)
+    w = (_rnd((N, Cin, k, k, k), 2) / np.sqrt(Cin * taps)).half().float()
+    bias, rv, r0 = 0.3 * _rnd((N,), 4), 0.5 * _rnd((O, N), 5), _rnd((O * V, N), 8)
+    ga, be = 1 + 0.1 * _rnd((N,), 6), 0.1 * _rnd((N,), 7)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(plan_vol, 'VOL_GN_PART_FUSED', fused)
+        b = Builder(dev)
+        xcl = b.dev(_cl(x), torch.float16)
+        o32 = b.buf(O * V, N, zero=True)
+        ic = b.conv(xcl, PackedConv(w, bias, dev), O, dims, rowvec=View(b.dev(rv)), res=b.dev(r0) if res else None, out_f32=o32)
+        y = b.buf(O * V, N, dtype=torch.float16, zero=True)
+        ig = b.groupnorm(o32, N, None, 0, O, V, b.dev(ga), b.dev(be), 1e-5, True, y)
+        cv, gn = b.ops[ic].u.conv, b.ops[ig].u.gn
+        if fused:
+            assert hip.lib().es_conv_emits_gn_part(ctypes.byref(cv)) == 1, 'this launch is expected to split K'
+            assert cv.gn_part_out and gn.part_in == cv.gn_part_out and cv.gn_part_groups == 32
+        else:
+            assert not cv.gn_part_out and not gn.part_in
+        b.finish().run()
+        torch.cuda.synchronize()
+        outs.append((o32.clone(), y.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    cl = outs[0][0].view(O, V, N).permute(0, 2, 1).reshape(O, N, D, H, W).cpu()
+    assert _rel(outs[0][1], _cl(F.silu(F.group_norm(cl, 32, ga, be, 1e-5)))) < 2e-3
 
 
 @pytest.mark.parametrize('env', [{'ES_TEST_VOL_OPTIONS': 'conv_ws=0'}, {'ES_TEST_VOL_OPTIONS': 'conv_tile=128'}, {'ES_TEST_VOL_OPTIONS': 'conv_force256=1'},

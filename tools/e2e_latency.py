@@ -12,6 +12,7 @@ from model.SGDiff import SGDiff
 ap = argparse.ArgumentParser()
 ap.add_argument('--nodes', type=int, default=32)
 ap.add_argument('--concat', action='store_true')
+ap.add_argument('--prewarm', type=float, default=0.0, help='experiment: reserve this many GB in the caching allocator first (timed, reported)')
 ap.add_argument('--profile-first', action='store_true', help='cProfile of the first call (weight re-layouts, plan build, graph capture): top functions')
 a = ap.parse_args()
 opt = escfg.default_diff_opt('cuda', concat=a.concat)
@@ -27,6 +28,12 @@ O = a.nodes
 objs, triples = synth.synthetic_graph(O, seed=9)
 tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
 args = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
+if a.prewarm > 0:
+    t0 = time.perf_counter()
+    blk = torch.empty(int(a.prewarm * (1 << 30)), dtype=torch.uint8, device='cuda')
+    del blk
+    torch.cuda.synchronize()
+    print('prewarm %.1f GB: %.3f s' % (a.prewarm, time.perf_counter() - t0), flush=True)
 for i in range(3):
     torch.cuda.synchronize()
     prof = None
@@ -42,6 +49,7 @@ for i in range(3):
         import pstats
         prof.disable()
         pstats.Stats(prof).sort_stats('tottime').print_stats(18)
+        pstats.Stats(prof).sort_stats('cumulative').print_stats('echoscene_amd|model/', 45)
     print('call %d: %.3f s  (shapes %s, finite %s)' % (i, dt, tuple(d['shapes'].shape), bool(torch.isfinite(d['shapes']).all())), flush=True)
 
 # ---- breakdown (each part synchronised) ----
