@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--nodes', type=int, default=32)
 ap.add_argument('--concat', action='store_true')
 ap.add_argument('--prewarm', type=float, default=0.0, help='experiment: reserve this many GB in the caching allocator first (timed, reported)')
+ap.add_argument('--host-weights', action='store_true', help='A/B: read the parameters through the host as before round 5')
 ap.add_argument('--profile-first', action='store_true', help='cProfile of the first call (weight re-layouts, plan build, graph capture): top functions')
 a = ap.parse_args()
 opt = escfg.default_diff_opt('cuda', concat=a.concat)
@@ -28,6 +29,9 @@ O = a.nodes
 objs, triples = synth.synthetic_graph(O, seed=9)
 tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
 args = (objs.cuda(), triples.cuda(), tf.cuda(), rf.cuda())
+if a.host_weights:          # A/B: the round-4 route -- every parameter downloaded, folded on the host, uploaded again
+    from echoscene_amd import samplers as _smp
+    _smp.state_dict_for = lambda module, device=None: {k: v.detach().cpu() for k, v in module.state_dict().items()}
 if a.prewarm > 0:
     t0 = time.perf_counter()
     blk = torch.empty(int(a.prewarm * (1 << 30)), dtype=torch.uint8, device='cuda')

@@ -1,11 +1,12 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/s9
+OUT=$GRAFT_REPO_ROOT/gpurun_out/s11
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_hip_rows.py tests/test_hip_vol.py -m gpu -x -q -k "fold_product or from_a_model or splitk_reduction" 2>&1 | tail -5
-python tools/e2e_latency.py --profile-first > $OUT/e2e_first.txt 2>&1
-grep -E "^call|loop|decode|GCN|new graph" $OUT/e2e_first.txt
-python tools/e2e_latency.py --prewarm 12 > $OUT/e2e_prewarm.txt 2>&1
-grep -E "^call|prewarm" $OUT/e2e_prewarm.txt
-python -c "import torch; print(torch.cuda.memory_reserved())" 
+# page the image in first (torch, its code objects, our library): every measurement below is a NEW process on a warm file cache
+timeout 300 python tools/e2e_latency.py --nodes 8 > $OUT/warmup.txt 2>&1; grep -E "^call" $OUT/warmup.txt
+for v in plain host prewarm plain2 host2; do
+  case $v in plain|plain2) F="";; host|host2) F="--host-weights";; prewarm) F="--prewarm 12";; esac
+  timeout 200 python tools/e2e_latency.py $F > $OUT/e2e_$v.txt 2>&1
+  echo "== $v"; grep -E "^call|prewarm" $OUT/e2e_$v.txt
+done
