@@ -139,6 +139,15 @@ def pmc_traffic(kernel):
         return None
 
 
+def route_options_string():
+    """the library's route options (es_options_string: what a model file records) -- the run's kernel routes, for the record"""
+    import ctypes
+    from echoscene_amd import hip
+    buf = ctypes.create_string_buffer(1024)
+    hip.lib().es_options_string(buf, 1024)
+    return buf.value.decode()
+
+
 def pmc_traffic_source():
     """file + git blob id of the committed counter summary ``roofline.traffic`` is read from (so that a stale file is visible:
     the id changes whenever the passes are re-collected), or null"""
@@ -632,6 +641,9 @@ def main():
                                           else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
                                                 '[O,64] codes every DDIM step over RCCL)' % world)),
                            'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': (not a.tuned) if sh_world > 1 else None,
+                           'deterministic': not a.tuned,       # ShapeDenoiser(deterministic=...): bit-exact object shards (the default since round 4; --tuned flips it)
+                           'step_graph': os.environ.get('ES_STEP_GRAPH', '0') == '1',      # sharded DDIM step captured as ONE graph (opt-in)
+                           'route_options': route_options_string(),
                            'loops': ('one hipGraph per full step, layout step as a parallel branch '
                                                                               '(%.3f ms per step); layout / shape below: each loop alone' % (fused_ms / a.steps))
                            if fused_ms is not None else ('layout step as a parallel branch of the sharded main graph' if fused_sharded else 'two HIP streams'), 'layout': lay,

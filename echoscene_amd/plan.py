@@ -566,6 +566,17 @@ class Plan:
     def run(self):
         hip.check(hip.lib().es_plan_run(C.c_void_p(self.handle), hip.current_stream()), 'es_plan_run')
 
+    def poison_scratch(self):
+        """Verification of the ``scratch=True`` claim (model files store such buffers without their contents and the loader
+        zero-fills them): overwrite every scratch buffer with NaN bit patterns.  A plan whose results after this differ from before
+        -- or are not finite -- reads a byte no op of it wrote.  Returns the number of bytes poisoned."""
+        n = 0
+        for t in self.keep:
+            if isinstance(t, torch.Tensor) and t.data_ptr() in self.scratch and t.numel():
+                t.view(torch.uint8).fill_(0xFF)          # 0xFFFFFFFF / 0xFFFF: a NaN in fp32 and fp16, -1 in the integer types
+                n += t.numel() * t.element_size()
+        return n
+
     def sample(self, step, first_step, n_steps, use_graph=True):
         hip.check(hip.lib().es_sampler_run(C.c_void_p(self.handle), C.c_void_p(step.data_ptr()), first_step,
                                            n_steps, 1 if use_graph else 0, hip.current_stream()), 'es_sampler_run')

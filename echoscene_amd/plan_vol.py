@@ -352,6 +352,10 @@ class VolBuilderMixin:
                 return h16
         h32 = self.buf(M, pc.N, scratch=True)
         op.u.conv.out_f32, op.u.conv.out_f16 = h32.data_ptr(), None
+        # the f16 tensor is not used on this route: release it (it was M x N x 2 bytes of HBM held for nothing)
+        self.scratch.discard(h16.data_ptr())
+        self.keep[:] = [t for t in self.keep if t is not h16]
+        del h16
         if not hasattr(self, '_conv_of'):
             self._conv_of = {}
         self._conv_of[h32.data_ptr()] = (idx, M, pc.N)

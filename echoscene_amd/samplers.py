@@ -305,7 +305,12 @@ class ShapeDenoiser:
         from .plan import save_model
         assert self.world == 1 and not self.force_exchange
         st = self._plan_for(uc, triples, c)
-        return save_model(st['plan'], path, dict(x=st['x'], step=st['step'], coef=self.coef))
+        regions = dict(x=st['x'], step=st['step'], coef=self.coef)
+        if st.get('snoise') is not None:
+            # ddim_eta != 0: the per-step draws [S, objects x latent] are an INPUT of the loop -- a named region the host fills before
+            # es_shape_sample (es_model_region(m, "step_noise")); the file stores whatever the table holds now
+            regions['step_noise'] = st['snoise']
+        return save_model(st['plan'], path, regions)
 
     def step_graph(self, group=None):
         """ONE graph per DDIM step of the sharded loop ("RCCL on a dedicated stream, or direct peer
@@ -381,7 +386,15 @@ class ShapeDenoiser:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
         st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
         if st.get('snoise') is not None:
-            if step_noise is None:
+            if step_noise is None and self.world > 1:
+                # one table for the WHOLE scene from this rank's generator, then this rank's objects: ranks seeded alike (as they
+                # must be for noise1) draw what the unsharded run draws -- a local normal_() gave every world size its own noise
+                per = st['snoise'].shape[1] // max(st['hi'] - st['lo'], 1) if st['hi'] > st['lo'] else 0
+                if per:
+                    full = torch.randn(self.S, st['O'], per, device=self.device)
+                    st['snoise'].copy_(full[:, st['lo']:st['hi']].reshape(self.S, -1))
+                    del full
+            elif step_noise is None:
                 st['snoise'].normal_()
             else:
                 sn = step_noise.to(self.device).float()[:, st['lo']:st['hi']]

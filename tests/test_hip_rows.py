@@ -240,6 +240,10 @@ def test_layout_loop_tiny_100_steps_vs_reference_golden(dev, use_graph):
     _close(x, g['x_final'], 2e-4)
     x2 = den.sample(g['obj_embed'], g['triples'], noise, use_graph=use_graph)
     assert torch.equal(x, x2), 'sampling must be deterministic for fixed noise'
+    # the plan's scratch claim (model files store such buffers empty): poisoned with NaN patterns, the loop gives the same bits
+    assert den._last['plan'].poison_scratch() > 0
+    x3 = den.sample(g['obj_embed'], g['triples'], noise, use_graph=use_graph)
+    assert torch.equal(x, x3), 'an op reads scratch bytes that no op of the plan wrote'
 
 
 @pytest.mark.parametrize('shape', [(672, 672, 2688), (100, 37, 70), (5, 3, 1), (1, 1000, 1)])

@@ -35,6 +35,9 @@ def test_vqvae_decode_vs_reference_golden(tag):
     assert e < 2e-2
     ea = abs(sdf.double().abs().sum().item() - g['sdf_abs'].item()) / g['sdf_abs'].item()
     assert ea < 5e-3
+    for st in dec._plans.values():                     # scratch claim of the decode plans: NaN-poisoned, same bits
+        assert st['plan'].poison_scratch() > 0
+    assert torch.equal(dec.decode_no_quant(g['z']), sdf)
 
 
 @pytest.mark.parametrize('typ,concat,gold', [('echolayout', False, None), ('echoscene', False, None), ('echoscene', True, None),

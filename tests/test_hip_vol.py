@@ -369,6 +369,10 @@ def test_ddim_tiny_loop_vs_reference_golden(dev, use_graph):
     assert e < 2e-2
     z2 = den.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), use_graph=use_graph)
     assert torch.equal(z, z2)
+    # scratch claim of the plan (activations, split-K slabs, statistics are stored empty in model files): NaN-poisoned, same bits
+    assert den._plan_for(g['uc_s'], g['triples'], None)['plan'].poison_scratch() > 0
+    z3 = den.sample(g['uc_s'], g['triples'], synth.shape_noise(seed=7), use_graph=use_graph)
+    assert torch.equal(z, z3), 'an op reads scratch bytes that no op of the plan wrote'
 
 
 def test_ddim_loop_with_eta_vs_reference_golden(dev):
@@ -391,6 +395,37 @@ def test_ddim_loop_with_eta_vs_reference_golden(dev):
     assert e < 2e-2
     z2 = den.sample(g['ddim_uc_s'], g['ddim_triples'], synth.shape_noise(seed=7), step_noise=step_noise)
     assert torch.equal(z, z2)
+    # the model file of a stochastic loop names its draws: region "step_noise" [S, objects x latent] is an input the host fills
+    import ctypes as C, tempfile
+    from echoscene_amd import hip
+    L = hip.lib()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'eta.esm')
+        den.save_model(path, g['ddim_uc_s'], g['ddim_triples'])
+        m = L.es_model_load(path.encode())
+        assert m, L.es_last_error()
+        try:
+            reg = {}
+            for name in (b'x', b'step_noise'):
+                ptr, nb = C.c_void_p(), C.c_size_t()
+                hip.check(L.es_model_region(C.c_void_p(m), name, C.byref(ptr), C.byref(nb)), 'es_model_region')
+                reg[name] = (ptr.value, nb.value)
+            O_ = step_noise.shape[1]
+            assert reg[b'step_noise'][1] == step_noise.numel() * 4 and reg[b'x'][1] == O_ * 3 * 16 ** 3 * 4
+            sn = step_noise.to(dev).float().reshape(4, -1).contiguous()
+            x0 = synth.shape_noise(seed=7).to(dev).float().expand(O_, 3, 16, 16, 16).contiguous()
+            hipc = C.CDLL(os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'libamdhip64.so'))
+            hipc.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            torch.cuda.synchronize()
+            assert hipc.hipMemcpy(reg[b'step_noise'][0], sn.data_ptr(), reg[b'step_noise'][1], 3) == 0
+            assert hipc.hipMemcpy(reg[b'x'][0], x0.data_ptr(), reg[b'x'][1], 3) == 0
+            hip.check(L.es_model_run(C.c_void_p(m), 0, 4, hip.current_stream()), 'es_model_run')
+            torch.cuda.synchronize()
+            zf = torch.empty_like(x0)
+            assert hipc.hipMemcpy(zf.data_ptr(), reg[b'x'][0], reg[b'x'][1], 3) == 0
+            assert torch.equal(zf.cpu(), z.cpu()), 'the loaded model replays the stochastic loop bit for bit'
+        finally:
+            L.es_model_free(C.c_void_p(m))
     z0 = _shape(dev, 32, 64, 'unet3d_tiny.', 4).sample(g['ddim_uc_s'], g['ddim_triples'], synth.shape_noise(seed=7))
     assert _rel(z0, load_golden('ddim_tiny')['z_final']) < 2e-2
 
