@@ -414,15 +414,19 @@ def test_ddim_loop_with_eta_vs_reference_golden(dev):
             assert reg[b'step_noise'][1] == step_noise.numel() * 4 and reg[b'x'][1] == O_ * 3 * 16 ** 3 * 4
             sn = step_noise.to(dev).float().reshape(4, -1).contiguous()
             x0 = synth.shape_noise(seed=7).to(dev).float().expand(O_, 3, 16, 16, 16).contiguous()
-            hipc = C.CDLL(os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'libamdhip64.so'))
-            hipc.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            torch.cuda.synchronize()
-            assert hipc.hipMemcpy(reg[b'step_noise'][0], sn.data_ptr(), reg[b'step_noise'][1], 3) == 0
-            assert hipc.hipMemcpy(reg[b'x'][0], x0.data_ptr(), reg[b'x'][1], 3) == 0
+            from echoscene_amd.plan import Builder
+
+            def dcopy(dst, src, nbytes):               # device-to-device copy through the library (raw pointers: ES_OP_COPY)
+                bb = Builder(dev)
+                bb.copy(dst, src, nbytes)
+                bb.finish().run()
+                torch.cuda.synchronize()
+            dcopy(reg[b'step_noise'][0], sn.data_ptr(), reg[b'step_noise'][1])
+            dcopy(reg[b'x'][0], x0.data_ptr(), reg[b'x'][1])
             hip.check(L.es_model_run(C.c_void_p(m), 0, 4, hip.current_stream()), 'es_model_run')
             torch.cuda.synchronize()
             zf = torch.empty_like(x0)
-            assert hipc.hipMemcpy(zf.data_ptr(), reg[b'x'][0], reg[b'x'][1], 3) == 0
+            dcopy(zf.data_ptr(), reg[b'x'][0], reg[b'x'][1])
             assert torch.equal(zf.cpu(), z.cpu()), 'the loaded model replays the stochastic loop bit for bit'
         finally:
             L.es_model_free(C.c_void_p(m))
