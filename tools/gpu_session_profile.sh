@@ -19,6 +19,8 @@ for SET in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 timeout 600 python tools/microbench_rows.py cold 2>&1 | grep "^cold" > $OUT/rows_microbench.txt
 timeout 600 python tools/conv_launch_table.py 2>&1 | grep -v amdgpu > $OUT/conv_launch_table.txt
+timeout 600 python tools/aux_launch_table.py 2>&1 | grep -v amdgpu > $OUT/aux_launch_table.txt
+timeout 300 python tools/layout_op_times.py 2>&1 | grep -v amdgpu > $OUT/layout_op_times.txt
 # keep the merge small: the kernel traces of the PMC passes are not needed
 find $OUT -path "*pmc_*" -name "*kernel_trace.csv" -delete
 find $OUT -name "*kernel_trace.csv" -size +6M -delete
