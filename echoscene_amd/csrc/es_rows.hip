@@ -20,6 +20,14 @@
 //     that lands in B-operand registers (streamed once per workgroup, no LDS round trip), issued before the staging;
 //   * exact fp32 on the matrix pipe: v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain); the k-blocks of a slice are
 //     dealt to the 8 waves (NWAVE) and reduced through LDS in a fixed order (deterministic, no float atomics).
+// Round 5: the product launches run on k_rows_x (es_rows_x.h; family 1, the default) -- the same decomposition, slabs, K cuts and
+// fixed-order reductions, but no staging tile: a wave loads its A fragments straight into MFMA operand registers and applies the
+// slab sum / ReLU / GroupNorm / LayerNorm prologue there (lane swaps instead of LDS), every load of a workgroup is issued
+// unconditionally behind ONE 64-byte per-slice descriptor (zero-record buffer descriptors gate what does not exist), slices are cut at
+// SEGMENT boundaries (a workgroup never multiplies two segments), and a ninth wave pulls the NEXT launch's weights into this XCD's
+// L2.  Measured by wave stamps (profiles/r05_rows_stamps_*.txt): these kernels are bound by the number of dependent VALU
+// instructions in front of the first MFMA (~5 clocks each at one wave per SIMD), not by bytes.  The kernel below (k_linear_rows,
+// family 0) remains for the CSR pooling launch, the tables built once per schedule and A/B timing (es_rows_set_kernel_family).
 #include "es_common.h"
 #include <cstdlib>
 #include <mutex>
