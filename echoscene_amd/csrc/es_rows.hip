@@ -142,6 +142,40 @@ __device__ __forceinline__ void stage_chunk(const es_linear_args& a, float* x, i
                 }
                 for (int c4 = cl; c4 < w4; c4 += LPR) {
                     f4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (!wavg && nslab == 1) {
+                        // The sampling path's pooling ('avg' / 'sum', one slab).  Round 5: the scene node's row (~2*O entries) was a chain
+                        // of 8 batches x 2 dependent round trips (index pairs, then rows) = 4 us of this launch's 7.8 (wave stamps).  Now
+                        // 12 entries per batch (16 spill), and the index pairs of batch b + 1 are requested BEHIND the rows of batch b (loads
+                        // retire in order: the additions of batch b wait for its rows only) -- one round trip per 12 entries.  Same
+                        // entries, added in the same (stored == the reference's scatter_add) order: the same bits.
+                        constexpr int EB = 12;
+                        int off[EB];
+#pragma unroll
+                        for (int u = 0; u < EB; ++u) {
+                            const int ee = min(e0 + u, e1 - 1);
+                            off[u] = e0 < e1 ? sg.ent_row[ee] * sg.ld + sg.ent_off[ee] : 0;
+                        }
+                        for (int e = e0; e < e1; e += EB) {
+                            f4 t[EB];
+#pragma unroll
+                            for (int u = 0; u < EB; ++u) t[u] = *(const f4*)(base + off[u] + 4 * c4);
+                            if (e + EB < e1) {
+#pragma unroll
+                                for (int u = 0; u < EB; ++u) {
+                                    const int ee = min(e + EB + u, e1 - 1);
+                                    off[u] = sg.ent_row[ee] * sg.ld + sg.ent_off[ee];     // (the row loads above have been issued: their address registers are free)
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < EB; ++u) {
+                                if (relu_in) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) t[u][q] = fmaxf(t[u][q], 0.f);
+                                }
+                                if (e + u < e1) v += t[u];
+                            }
+                        }
+                    } else
                     // stored order == scatter_add order of the reference.  Entries are fetched 8 at a time (index pairs,
                     // then rows) and added in order (the scene node has ~2*O incident edges).
                     for (int e = e0; e < e1; e += 8) {
@@ -894,7 +928,7 @@ void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
     memset(&P, 0, sizeof(P));
     P.wpack = a.wpack; P.bias = a.bias; P.res = a.res; P.res2 = a.res2; P.out = a.out;
     P.res_step = a.res_step; P.res_step_stride = a.res_step_stride;
-    P.M = a.M; P.N = a.N; P.K = a.K; P.nkb_total = a.K / 16; P.S = xp.S | (((32768 + xp.S - 1) / xp.S) << 16); P.Jw = xp.Jw; P.act = a.act;
+    P.M = a.M; P.N = a.N; P.inv_k = 1.0f / (float)a.K; P.nkb_total = a.K / 16; P.S = xp.S | (((32768 + xp.S - 1) / xp.S) << 16); P.Jw = xp.Jw; P.act = a.act;
     P.res_ld = a.res_ld; P.res_nslab = a.res_nslab > 1 ? a.res_nslab : 1; P.res_sstr = a.res_slab_stride;
     P.res2_ld = a.res2_ld; P.res2_nslab = a.res2_nslab > 1 ? a.res2_nslab : 1; P.res2_sstr = a.res2_slab_stride;
     P.out_ld = a.out_ld; P.out_sstr = a.out_slab_stride;

@@ -37,7 +37,7 @@ struct XProb {                                    // 128 + 6 * 64 = 512 bytes
     int32_t res_ld, res_nslab, res_sstr, res2_ld;
     int32_t res2_nslab, res2_sstr, out_ld, out_sstr;
     int32_t wg0, ny, xw, fw;
-    int32_t act, res_step_stride, Jw, K;
+    int32_t act, res_step_stride, Jw; float inv_k;       // inv_k = 1.0f / K formed on the host (IEEE division: the bits the device division gave)
     XSlice sl[XMAXS];
 };
 // What the NEXT rows launch of the plan will read of its weight image (single-problem launches): the extra wave of this launch pulls
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
     const XProb& PP = L.p[pi];
     struct XHdr { const float* wpack; const float* bias; const float* res; const float* res2; float* out; const int32_t* res_step;
                   int32_t M, N, nkb_total, S, res_ld, res_nslab, res_sstr, res2_ld, res2_nslab, res2_sstr, out_ld, out_sstr, wg0, ny, xw, fw,
-                          act, res_step_stride, Jw, K; };
+                          act, res_step_stride, Jw; float inv_k; };
     static_assert(sizeof(XHdr) == 128 && sizeof(XProb) == 128 + XMAXS * 64, "k_rows_x: descriptor layout");
     const XHdr P = *(const XHdr*)&PP;                      // by VALUE: the whole header in two wide scalar loads, here
     // tiles of a problem = (column tile, slice) pairs along blockIdx.x, slice fastest, from wg0 on; a problem with fewer row tiles than
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
 
     // (4) prologue in registers
     f4 a[NB];
+    const float relu_lo = (SL.flags & 16) ? 0.f : -INFINITY;
 #pragma unroll
     for (int v = 0; v < NB; ++v) {
         const int j = v % JW, sl = v / JW;
@@ -218,10 +219,9 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         f4 y = av[v][0];                                       // (blocks / slabs that do not exist are zeros: x + 0 = x)
 #pragma unroll
         for (int u = 1; u < NS; ++u) y += av[v][u];
-        if (SL.flags & 16) {
+        // ReLU on the slab sum without a branch per block: max(y, 0) or max(y, -inf)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
-        }
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], relu_lo);
         a[v] = y;
     }
     if (PROC == 1 && (SL.flags & 2)) {
@@ -278,16 +278,16 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < NKG; ++w) tot += lnx[w * 16 + i16];
-        const float inv_k = 1.0f / (float)P.K;
+        const float inv_k = P.inv_k;
         const float mean = tot * inv_k;
         float sq = 0.f;
 #pragma unroll
         for (int v = 0; v < NB; ++v) {
             const int j = v % JW, sl = v / JW;
-            if (j < Jw && j < nj && sl < S) {
+            // (a block that does not exist holds zeros: against a zero "mean" it adds exact zeros -- a scalar select, no branch)
+            const float mv = (j < Jw && j < nj && sl < S) ? mean : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mean; sq += d * d; }
-            }
+            for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mv; sq += d * d; }
         }
         sq = quad_sum(sq);
         if (q == 0) lnx[NKG * 16 + wave * 16 + i16] = sq;
@@ -323,18 +323,21 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
     const bool ok_res = geglu ? (ok_e && nl < 8) : ok_e;
     float e_res = 0.f, e_res2 = 0.f, e_bias = 0.f;
     float rr1[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rr2[XMAXS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (first) {                                          // (a branch is harmless here: the loads the prologue waited for are behind us)
+    {
+        // no branches here either (round 5, from the ISA: twelve `if (u < nslab) load` were ~130 instructions in front of the MFMAs):
+        // slabs that do not exist and workgroups of the other slices load through descriptors without records
         const float* rp = P.res;
         // (the step counter through the scalar cache: a vector load here would wait for every load issued above)
-        if (P.res_step) rp += (long)(*(const __attribute__((address_space(4))) int32_t*)(unsigned long)P.res_step) * P.res_step_stride;
+        if (first && P.res_step) rp += (long)(*(const __attribute__((address_space(4))) int32_t*)(unsigned long)P.res_step) * P.res_step_stride;
         const unsigned ro1 = ok_res ? ((unsigned)m_e * (unsigned)P.res_ld + (unsigned)nres) * 4u : XOOB;
         const unsigned ro2 = ok_res ? ((unsigned)m_e * (unsigned)P.res2_ld + (unsigned)nres) * 4u : XOOB;
+        const int n1 = first ? P.res_nslab : 0, n2 = first ? P.res2_nslab : 0;
 #pragma unroll
         for (int u = 0; u < XMAXS; ++u) {
-            if (u < P.res_nslab) rr1[u] = x_ld1(x_rsrc_if(rp, true), ro1, (unsigned)(u * P.res_sstr) * 4u);
-            if (u < P.res2_nslab) rr2[u] = x_ld1(x_rsrc_if(P.res2, true), ro2, (unsigned)(u * P.res2_sstr) * 4u);
+            rr1[u] = x_ld1(x_rsrc_if(rp, u < n1), ro1, (unsigned)(u * P.res_sstr) * 4u);
+            rr2[u] = x_ld1(x_rsrc_if(P.res2, u < n2), ro2, (unsigned)(u * P.res2_sstr) * 4u);
         }
-        e_bias = x_ld1(x_rsrc_if(P.bias, true), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
+        e_bias = x_ld1(x_rsrc_if(P.bias, first), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
     }
     ES_RSTAMP(3);
 

@@ -74,8 +74,10 @@ def rects_overlap(a, b):
         return False
     pa, pb = getattr(a, 'pitch', 0), getattr(b, 'pitch', 0)
     if pa and pa == pb and a.width <= pa and b.width <= pa:
-        ca, cb = a[0] % pa, (b[0] - (a[0] - a[0] % pa)) % pa             # column offsets relative to a common row start
-        if ca + a.width <= pa and cb + b.width <= pa and (ca + a.width <= cb or cb + b.width <= ca):
+        # only the DIFFERENCE of the two starts is meaningful (the matrix base need not be pitch-aligned: taking each address modulo
+        # the pitch made this check depend on where the allocator put the buffer): b's columns start d bytes right of a's, cyclically
+        d = (b[0] - a[0]) % pa
+        if d >= a.width and d + b.width <= pa:
             return False
     return True
 
