@@ -543,16 +543,21 @@ def main():
     lay_reps, shp_reps = [r[1] / a.steps for r in regions], [r[2] / a.steps for r in regions]
     if fused is not None:
         # per-loop figures for the record (outside the timed region): each loop alone on the idle GPU, `reps` times each
+        # (the layout loop: 20 untimed steps first, then up to 400 timed ones -- 50 steps right behind a shape loop measured the first
+        #  replays of its graph on a GPU still clocked for the matrix work: 0.786 ms where `--workload layout` measures 0.666)
         nn = min(a.steps, 50)
+        nl = max(1, min(max(a.steps, 1) * 4, 400, den.T - 20))
         lay_reps, shp_reps = [], []
         for _ in range(reps):
             reset_state()
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record(); st['plan'].sample(st['step'], 0, nn, use_graph=use_graph)
-            e[1].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
-            e[2].record(); torch.cuda.synchronize()
-            lay_reps.append(e[0].elapsed_time(e[1]) / nn)
-            shp_reps.append(e[1].elapsed_time(e[2]) / nn)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            st['plan'].sample(st['step'], 0, 20, use_graph=use_graph)
+            e[0].record(); st['plan'].sample(st['step'], 20, nl, use_graph=use_graph)
+            e[1].record()
+            e[2].record(); ss['plan'].sample(ss['step'], 0, nn, use_graph=use_graph)
+            e[3].record(); torch.cuda.synchronize()
+            lay_reps.append(e[0].elapsed_time(e[1]) / nl)
+            shp_reps.append(e[2].elapsed_time(e[3]) / nn)
         solo = (_stats(lay_reps)['median'] * a.steps, _stats(shp_reps)['median'] * a.steps)
     if fused_sharded:
         # the layout steps ran inside the sharded main graphs; for the record (outside the timed region): the layout loop alone
