@@ -565,14 +565,15 @@ __global__ void k_row_select(const es_rowsel_args a) {
 // Box de-normalisation after the layout loop (helpers/util.py:542-568): [-1,1] -> [min,max] for sizes and
 // translations (in place, stats = {min_lhw[3], max_lhw[3], min_xyz[3], max_xyz[3], min_angle, max_angle}) and
 // (sin, cos) -> arctan2 in degrees-or-radians (scale).
+// ncol = 7: also the angle column (descale_box_params(angle=True), helpers/util.py:553-555: stats[12], stats[13]).
 __global__ void k_box_postprocess(float* boxes, int ld, const float* sincos, float* angle_out, const float* stats,
-                                  int O, float angle_scale) {
+                                  int O, float angle_scale, int ncol) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= O) return;
     if (boxes) {
-        for (int c = 0; c < 6; ++c) {
-            const float lo = stats[c < 3 ? c : 3 + c], hi = stats[c < 3 ? 3 + c : 6 + c];
+        for (int c = 0; c < ncol; ++c) {
+            const float lo = stats[c < 3 ? c : c < 6 ? 3 + c : 12], hi = stats[c < 3 ? 3 + c : c < 6 ? 6 + c : 13];
             float v = boxes[(long)i * ld + c];
             v = (v + 1.0f) / 2.0f;
             boxes[(long)i * ld + c] = v * (hi - lo) + lo;
@@ -1245,7 +1246,15 @@ extern "C" int es_box_postprocess(float* boxes, int ld, const float* sincos, flo
                                   int O, float angle_scale, es_stream stream) {
     ES_REQUIRE(O > 0 && (!boxes || (stats && ld >= 6)), "es_box_postprocess: bad args");
     hipLaunchKernelGGL(k_box_postprocess, dim3((O + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, ld, sincos,
-                       angle_out, stats, O, angle_scale);
+                       angle_out, stats, O, angle_scale, 6);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int es_box_descale(float* boxes, int ld, int ncol, const float* stats, int O, es_stream stream) {
+    ES_REQUIRE(O > 0 && boxes && stats && (ncol == 6 || ncol == 7) && ld >= ncol, "es_box_descale: bad args (ncol=%d, ld=%d)", ncol, ld);
+    hipLaunchKernelGGL(k_box_postprocess, dim3((O + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, ld, (const float*)nullptr,
+                       (float*)nullptr, stats, O, 1.0f, ncol);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

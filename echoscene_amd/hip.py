@@ -149,6 +149,7 @@ EXPORTS = {
     'es_ddim_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),
     'es_box_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
                                      C.c_void_p]),
+    'es_box_descale': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'es_conv_emits_gn_stats': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_conv_emits_gn_part': (C.c_int, [C.POINTER(ConvArgs)]),

@@ -126,16 +126,51 @@ def seg(view, mode=hip.SEG_DIRECT, idx=None, ent_row=None, ent_off=None, step=No
     return s
 
 
-def norm_segs(views, gamma, beta, eps, silu, C=None, groups=32):
+def rows_gn_in_registers(C, groups=32):
+    """True when the rows kernels' GroupNorm prologue takes ``groups`` groups over C channels: it reduces a group inside one wave with
+    power-of-two lane strides (es_rows_x.h), i.e. group sizes 4, 8, 16, 32 -- the shipped layout denoisers' 512 / 1024 channels."""
+    gs = C // groups
+    return C % groups == 0 and 4 <= gs <= 32 and gs & (gs - 1) == 0
+
+
+def norm_segs(views, gamma, beta, eps, silu, C=None, groups=32, b=None, M=None):
     """segments of GroupNorm32(+SiLU) over the channel concatenation of ``views`` (th.cat([h, hs.pop()]) followed by
-    normalization(ch), openai_model_3d.py / denoise_net.py ResBlock.in_layers): groups never straddle a source."""
+    normalization(ch), openai_model_3d.py / denoise_net.py ResBlock.in_layers): groups never straddle a source.
+
+    Any other group size (GroupNorm32(32, channels) takes every channels % 32 == 0, ldm_diffusion_util.py:222-239; e.g.
+    model_channels = 384: groups of 12, or the 36-channel groups of a 768 + 384 concatenation): the norm is its own launch in front
+    of the product -- the channels-last GroupNorm of the volume path over M rows of ONE voxel each, fp32 in / fp32 out
+    (es_groupnorm_vol: sums in fp32, statistics in double) -- and the product reads the normalised rows as a plain segment.  The
+    sources must then be whole matrices (``Builder.allow_split`` off: emit_unet1d_step decides that for the whole plan)."""
     C = sum(v.width for v in views) if C is None else C
     gs = C // groups
-    if C % groups or gs < 4 or gs > 32 or gs & (gs - 1):
-        # the rows kernel's GroupNorm prologue reduces a group inside one wave with power-of-two strides (es_rows.hip); the shipped
-        # layout denoisers have 512 / 1024 channels (group size 16 / 32).  Said here, at plan build, not at the first launch.
-        raise ValueError('GroupNorm32 over %d channels: group size %d is not a power of two in 4..32 -- the rows path supports '
-                         'model_channels in {128, 256, 512, 1024} (reference: any multiple of 32)' % (C, gs))
+    if C % groups:
+        raise ValueError('GroupNorm32 over %d channels: not a multiple of %d groups' % (C, groups))
+    if not rows_gn_in_registers(C, groups) or any(v.width % gs for v in views):
+        if b is None or M is None:
+            raise ValueError('GroupNorm32 over %d channels: group size %d needs the separate-launch route (pass the builder)' % (C, gs))
+        assert 1 <= len(views) <= 2 and C <= 2048 and groups <= 64, (len(views), C, groups)
+        for v in views:
+            assert v.nslab <= 1 and v.col == 0 and v.row == 0 and v.ld == v.width and v.width % 8 == 0, \
+                'the separate GroupNorm launch reads whole fp32 matrices (allow_split off)'
+        from .hip import GNArgs
+        if gamma is None:                            # the affine is folded into the product's weights (fold_affine): unit scale, no shift
+            gamma, beta = b.dev(torch.ones(C)), b.dev(torch.zeros(C))
+        y = b.buf(M, C, scratch=True)
+        a = GNArgs()
+        a.x1, a.C1 = views[0].ptr, views[0].width
+        a.x2, a.C2 = (views[1].ptr, views[1].width) if len(views) > 1 else (None, 0)
+        a.O, a.V, a.groups, a.eps = M, 1, groups, eps
+        a.gamma, a.beta, a.silu = gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0
+        st = getattr(b, '_gn_stats', None)           # (Builder.groupnorm's scratch: one for all GroupNorms of a plan, same stream)
+        need = M * groups * 2 + M * groups * 2
+        if st is None or st.numel() < need:
+            st = b._gn_stats = b.buf(need, scratch=True)
+        a.stats = st.data_ptr()
+        a.y_f16, a.y_is_f32 = y.data_ptr(), 1
+        b.keep += [gamma, beta, y] + [v.t for v in views]
+        b._push(hip.OP_GN, 'gn', a)
+        return [seg(View(y))]
     out, off = [], 0
     for v in views:
         assert v.width % gs == 0 and off % gs == 0
@@ -467,7 +502,7 @@ class Builder:
         """The op emitted LAST (a rows product, or the last member of a fused group of two) takes the next independent op of
         ``rider`` onto its launch: the rider's op is appended right behind it and the pair is marked for one grid.  Problems of one
         launch must be independent -- the rider's chain only reads its own earlier ops and inputs of the step."""
-        if rider is None or self.use_lanes or not ROWS_RIDE:
+        if rider is None or self.use_lanes or not ROWS_RIDE or not self.allow_split:
             return False
         i = len(self.ops) - 1
         host = self.ops[i]
@@ -866,6 +901,9 @@ class UNet1DWeights:
         names += [(f'middle_block.{j}', it) for j, it in enumerate(mid)]
         names += [(f'output_blocks.{i}.{j}', it) for i, blk in enumerate(out) for j, it in enumerate(blk)]
         self.items = {}
+        # channel counts the trunk's GroupNorms run over (ResBlock in / out layers, attention / transformer input norms, the output norm)
+        self.gn_channels = sorted({c for _, it in names for c in (it[1:3] if it[0] == 'res' else it[1:2] if it[0] == 'attn' else ())}
+                                  | {self.mc})
         emb_w, emb_b, self.emb_slices, off = [], [], {}, 0
         ca_v, ca_b, self.ca = [], [], {}
         for name, it in names:
@@ -974,6 +1012,10 @@ def emit_unet1d_step(b, w, g, x, obj_embed_dev, temb, step, eps_out, tables=None
     # tables only, not the GCN output, and rides on the launches of the GCN chain (Rider / Builder.ride) -- conv_in on the box
     # embedding's launch (both read x_t), then one product per net1 / net2 output launch of the GCN layers.
     box = {}
+    if not all(rows_gn_in_registers(c) for c in w.gn_channels):
+        # a GroupNorm of the trunk has a group size the rows kernels do not reduce in registers (model_channels = 384: groups of
+        # 12): those norms are separate launches over whole matrices (norm_segs) -- no K-split slab outputs, nothing rides
+        b.allow_split = False
     rider = Rider(_trunk(b, w, O, x, emb_all, emb_ld, box, eps_out))
     if w.enable_t_emb and tables is not None:
         # the time slot of the node vectors = row *step of the t_lin table, broadcast: an IDENTITY product over a step-indexed segment
@@ -1038,15 +1080,15 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
                 cin, cout = it[1], it[2]
                 assert cin == hC
                 eo, _ = w.emb_slices[name]
-                skip_early = 'skip' in d and ROWS_SKIP_EARLY
+                skip_early = 'skip' in d and ROWS_SKIP_EARLY and b.allow_split      # (not behind a separate GroupNorm launch)
                 if skip_early:
                     yield 'CTX'                  # (this variant fuses conv1 with the skip projection itself: nothing rides from here on)
-                h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin), d['conv1'], O,
+                h1 = b.linear(norm_segs(h_segs, d['gn1'][0], d['gn1'][1], 1e-5, True, C=cin, b=b, M=O), d['conv1'], O,
                               res=(View(emb_all[0], col=eo, ld=0, width=cout, step=emb_all[1], step_stride=emb_all[0].shape[1])
                                    if isinstance(emb_all, tuple) else View(emb_all, col=eo, ld=emb_ld, width=cout)), fuse_next=skip_early)
                 if not skip_early:
                     yield
-                gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout)
+                gn2 = norm_segs([h1], d['gn2'][0], d['gn2'][1], 1e-5, True, C=cout, b=b, M=O)
                 if skip_early:
                     # skip_connection(x) depends only on the block input: it rides on conv1's launch as a second, independent problem
                     # (one grid), and conv2 shrinks from K = cout + cin to K = cout with the projection as its (slab) residual
@@ -1069,13 +1111,13 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
             elif kind == 'attn' and w.concat:
                 C = it[1]
                 xin = h_segs[0]
-                o = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-5, False, C=C), d['av'], O, res=xin)
+                o = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-5, False, C=C, b=b, M=O), d['av'], O, res=xin)
                 yield
                 h_segs, hC = [o], C
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
-                t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C), d['proj_in'], O, split=ln_kbps(C))
+                t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C, b=b, M=O), d['proj_in'], O, split=ln_kbps(C))
                 yield
                 yield 'CTX'                      # the next product adds the cross-attention vector of the GCN output
                 cavo = box['cavo']
@@ -1119,9 +1161,9 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
     # eps: a slab tensor too when the caller takes it as a View (eps_out None: the DDPM update sums the slabs) -- two workgroups
     # multiplying the whole K range were the slowest launch of the trunk's tail
     if eps_out is None:
-        b.tags['eps'] = b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O)
+        b.tags['eps'] = b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC, b=b, M=O), w.out_conv, O)
     else:
-        b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC), w.out_conv, O, View(eps_out))
+        b.linear(norm_segs(h_segs, w.out_gn[0], w.out_gn[1], 1e-5, True, C=hC, b=b, M=O), w.out_conv, O, View(eps_out))
         b.tags['eps'] = View(eps_out)
     yield
 

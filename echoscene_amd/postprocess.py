@@ -9,17 +9,17 @@ from . import hip
 
 
 def descale_box_params(normed_box_params, file=None, angle=False, stats=None):
-    """[-1,1] -> dataset units for sizes (cols 0:3) and translations (cols 3:6), in place on a CUDA tensor."""
+    """[-1,1] -> dataset units for sizes (cols 0:3) and translations (cols 3:6), in place on a CUDA tensor; ``angle=True``: also
+    column 6, a normalised angle, to [stats[12], stats[13]] (helpers/util.py:553-555)."""
     assert file is not None or stats is not None
-    if angle:
-        raise NotImplementedError('angle=True (7-column boxes) is not used by the sampling path')
+    ncol = 7 if angle else 6
     st = np.loadtxt(file) if stats is None else np.asarray(stats)
     x = normed_box_params
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] >= 6 and x.stride(1) == 1):
-        raise ValueError('descale_box_params: expects a float32 CUDA tensor [O, >=6]')
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] >= ncol and x.stride(1) == 1):
+        raise ValueError('descale_box_params: expects a float32 CUDA tensor [O, >=%d]' % ncol)
     std = torch.tensor(st, dtype=torch.float32, device=x.device)
-    hip.check(hip.lib().es_box_postprocess(C.c_void_p(x.data_ptr()), x.stride(0), None, None, C.c_void_p(std.data_ptr()),
-                                           x.shape[0], 1.0, hip.current_stream()), 'es_box_postprocess')
+    hip.check(hip.lib().es_box_descale(C.c_void_p(x.data_ptr()), x.stride(0), ncol, C.c_void_p(std.data_ptr()), x.shape[0],
+                                       hip.current_stream()), 'es_box_descale')
     return x
 
 

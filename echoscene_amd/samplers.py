@@ -55,10 +55,10 @@ class LayoutDenoiser:
         self.net = net
         self.w = UNet1DWeights(state_dict_for(net, self.device), net, self.device)
         dk = dict(diffusion_kwargs)
-        if dk.get('model_mean_type', 'eps') != 'eps' or dk.get('model_var_type', 'fixedsmall') != 'fixedsmall':
-            raise NotImplementedError('only eps-prediction / fixedsmall is on the sampling path')
+        # every parameterisation GaussianDiffusion can sample with is a coefficient table of the same update op (schedules.py)
         self.sched = LayoutSchedule(dk.get('time_num', 1000), dk.get('beta_start', 1e-4), dk.get('beta_end', 0.02),
-                                    dk.get('schedule_type', 'linear'))
+                                    dk.get('schedule_type', 'linear'), dk.get('model_mean_type', 'eps'),
+                                    dk.get('model_var_type', 'fixedsmall'))
         self.T = self.sched.time_num
         self.temb = timestep_embedding_table(self.sched.timesteps, net.model_channels).to(self.device)
         self.coef = self.sched.coef.to(self.device)

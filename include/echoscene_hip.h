@@ -201,6 +201,9 @@ int es_ddpm_update(const es_update_args* args, es_stream stream);
  * angle_out[O] = atan2(sin, cos) * angle_scale).  Either half may be skipped with NULL pointers. */
 int es_box_postprocess(float* boxes, int ld, const float* sincos, float* angle_out, const float* stats,
                        int O, float angle_scale, es_stream stream);
+/* descale_box_params alone, with its ``angle`` flag (helpers/util.py:542-557): ncol = 6 -> sizes | translations (the call above),
+ * ncol = 7 -> also column 6, a normalised angle, back to [stats[12], stats[13]] (angle=True, :553-555).  In place. */
+int es_box_descale(float* boxes, int ld, int ncol, const float* stats, int O, es_stream stream);
 int es_ddim_update(const es_update_args* args, es_stream stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -397,13 +397,29 @@ def unet3d_forward(sd, x, obj_embed, triples, timesteps, context=None, heads=8,
 
 
 # --------------------------------------------------------------------------------------
-# a9-a11  DDPM tables + ancestral sampling loop   diffusion_ddpm.py:38-41,133-162,220-345
+# a9-a11  DDPM tables + ancestral sampling loop   diffusion_ddpm.py:38-84,133-162,220-345
 # --------------------------------------------------------------------------------------
-def ddpm_tables(beta_start=1e-4, beta_end=0.02, time_num=1000):
+def get_betas(schedule_type, b_start, b_end, time_num):
+    """get_betas (diffusion_ddpm.py:38-84).  'cosine' fails in the reference with UnboundLocalError (the table is computed but never
+    bound, diffusion_ddpm.py:59-84): restated as that failure."""
+    if schedule_type == 'linear':
+        return np.linspace(b_start, b_end, time_num)
+    if schedule_type in ('warm0.1', 'warm0.2', 'warm0.5'):
+        frac = {'warm0.1': 0.1, 'warm0.2': 0.2, 'warm0.5': 0.5}[schedule_type]
+        betas = b_end * np.ones(time_num, dtype=np.float64)
+        warmup_time = int(time_num * frac)
+        betas[:warmup_time] = np.linspace(b_start, b_end, warmup_time, dtype=np.float64)
+        return betas
+    if schedule_type == 'cosine':
+        raise UnboundLocalError('betas')
+    raise NotImplementedError(schedule_type)
+
+
+def ddpm_tables(beta_start=1e-4, beta_end=0.02, time_num=1000, schedule_type='linear'):
     """Coefficient tables exactly as GaussianDiffusion.__init__ builds them: betas/cumprod in
     fp64 numpy, cast to fp32, *then* the derived tables in fp32 torch (the order of the casts
     matters for bit-parity)."""
-    betas64 = np.linspace(beta_start, beta_end, time_num).astype(np.float64)
+    betas64 = get_betas(schedule_type, beta_start, beta_end, time_num).astype(np.float64)
     alphas64 = 1. - betas64
     ac = torch.from_numpy(np.cumprod(alphas64, axis=0)).float()
     ac_prev = torch.from_numpy(np.append(1., ac[:-1])).float()
@@ -411,6 +427,8 @@ def ddpm_tables(beta_start=1e-4, beta_end=0.02, time_num=1000):
     alphas = torch.from_numpy(alphas64).float()
     post_var = betas * (1. - ac_prev) / (1. - ac)
     return {
+        'betas': betas,
+        'posterior_variance': post_var,
         'sqrt_recip_alphas_cumprod': torch.sqrt(1. / ac).float(),
         'sqrt_recipm1_alphas_cumprod': torch.sqrt(1. / ac - 1).float(),
         'posterior_mean_coef1': betas * torch.sqrt(ac_prev) / (1. - ac),
@@ -419,32 +437,46 @@ def ddpm_tables(beta_start=1e-4, beta_end=0.02, time_num=1000):
     }
 
 
-def ddpm_step(tab, x, eps, t, noise, clip_denoised=False):
-    """p_mean_variance + p_sample_sg, eps-prediction, 'fixedsmall'; ``clip_denoised``: the predicted x0 clamped to [-1, 1]
-    (diffusion_ddpm.py:220-264 with :243-244, 266-271, 204-217, 296-309; the shipped sampling call passes False)."""
-    x0 = tab['sqrt_recip_alphas_cumprod'][t] * x - tab['sqrt_recipm1_alphas_cumprod'][t] * eps
+def ddpm_step(tab, x, out, t, noise, clip_denoised=False, model_mean_type='eps', model_var_type='fixedsmall'):
+    """p_mean_variance + p_sample_sg (diffusion_ddpm.py:220-264, 266-271, 204-217, 296-309).  ``out`` is the network's output: the
+    noise ('eps', the shipped configs) or x_0 itself ('x0', :246-254); the log-variance is the clipped posterior's ('fixedsmall') or
+    log(cat[posterior_variance[1:2], betas[1:]]) ('fixedlarge', :224-235); ``clip_denoised``: the predicted x0 clamped to [-1, 1]
+    (:243-244; the shipped sampling call passes False)."""
+    if model_mean_type == 'eps':
+        x0 = tab['sqrt_recip_alphas_cumprod'][t] * x - tab['sqrt_recipm1_alphas_cumprod'][t] * out
+    elif model_mean_type == 'x0':
+        x0 = out
+    else:
+        raise NotImplementedError(model_mean_type)
     if clip_denoised:
         x0 = torch.clamp(x0, -1.0, 1.0)
     mean = tab['posterior_mean_coef1'][t] * x0 + tab['posterior_mean_coef2'][t] * x
-    logvar = tab['posterior_log_variance_clipped'][t] * torch.ones_like(x)
+    if model_var_type == 'fixedsmall':
+        lv = tab['posterior_log_variance_clipped']
+    elif model_var_type == 'fixedlarge':
+        lv = torch.log(torch.cat([tab['posterior_variance'][1:2], tab['betas'][1:]]))
+    else:
+        raise NotImplementedError(model_var_type)
+    logvar = lv[t] * torch.ones_like(x)
     nonzero = 1.0 - float(t == 0)
     return mean + nonzero * torch.exp(0.5 * logvar) * noise
 
 
 def layout_sample_loop(sd, obj_embed, triples, noise, time_num=1000, n_steps=None,
-                       beta_start=1e-4, beta_end=0.02, heads=8, enable_t_emb=True, trace=None, clip_denoised=False):
+                       beta_start=1e-4, beta_end=0.02, heads=8, enable_t_emb=True, trace=None, clip_denoised=False,
+                       schedule_type='linear', model_mean_type='eps', model_var_type='fixedsmall'):
     """p_sample_loop_sg (diffusion_ddpm.py:330-345) with injected noise:
     noise[0] = x_T, noise[1+i] = draw of iteration i.  ``n_steps`` < time_num runs only the
     first n_steps iterations (t = time_num-1 ... time_num-n_steps) -- used for short goldens."""
-    tab = ddpm_tables(beta_start, beta_end, time_num)
+    tab = ddpm_tables(beta_start, beta_end, time_num, schedule_type)
     O = obj_embed.shape[0]
     x = noise[0].clone()
     n_steps = time_num if n_steps is None else n_steps
     for i in range(n_steps):
         t = time_num - 1 - i
         t_ = torch.full((O,), t, dtype=torch.int64)
-        eps = unet1d_forward(sd, x, obj_embed, triples, t_, heads, enable_t_emb)
-        x = ddpm_step(tab, x, eps, t, noise[1 + i], clip_denoised)
+        out = unet1d_forward(sd, x, obj_embed, triples, t_, heads, enable_t_emb)
+        x = ddpm_step(tab, x, out, t, noise[1 + i], clip_denoised, model_mean_type, model_var_type)
         if trace is not None:
             trace.append(x.clone())
     return x
@@ -611,14 +643,17 @@ def rel_s(sd, feat):
 # --------------------------------------------------------------------------------------
 # (f3) post-path box helpers   helpers/util.py:542-557 (descale_box_params), :559-568
 # --------------------------------------------------------------------------------------
-def descale_box_params(boxes, stats):
+def descale_box_params(boxes, stats, angle=False):
     stats = torch.as_tensor(stats, dtype=boxes.dtype)
-    min_lhw, max_lhw, min_xyz, max_xyz = stats[:3], stats[3:6], stats[6:9], stats[9:12]
+    min_lhw, max_lhw, min_xyz, max_xyz, min_angle, max_angle = stats[:3], stats[3:6], stats[6:9], stats[9:12], stats[12:13], stats[13:]
     out = boxes.clone()
     out[:, :3] = (out[:, :3] + 1) / 2
     out[:, :3] = out[:, :3] * (max_lhw - min_lhw) + min_lhw
     out[:, 3:6] = (out[:, 3:6] + 1) / 2
     out[:, 3:6] = out[:, 3:6] * (max_xyz - min_xyz) + min_xyz
+    if angle:                                                       # helpers/util.py:553-555
+        out[:, 6:7] = (out[:, 6:7] + 1) / 2
+        out[:, 6:7] = out[:, 6:7] * (max_angle - min_angle) + min_angle
     return out
 
 

@@ -141,12 +141,13 @@ def case_unet1d_tiny():
     save('unet1d_tiny', box=box, obj_embed=oe, triples=triples, t=t, eps=eps.squeeze(-1))
 
 
-def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=False, clip_denoised=False):
+def _layout_loop(net, kw, O, seed_graph, time_num, n_steps, noise, force_traj=False, clip_denoised=False, **diffusion_overrides):
     """Runs the reference's own DiffusionPoint / GaussianDiffusion.p_sample_loop_sg with an
     injected noise_fn; optionally truncated to the first n_steps iterations."""
     from model.networks.diffusion_layout.diffusion_ddpm import DiffusionPoint
     cfg = escfg.AttrDict(angle_dim=2)
     dkw = dict(escfg.layout_diffusion_kwargs(time_num))
+    dkw.update(diffusion_overrides)
     df = DiffusionPoint(denoise_net=net, config=cfg, **dkw)
     objs, triples = synth.synthetic_graph(O, seed=seed_graph)
     oe = rnd((O, 640), 100 + seed_graph)
@@ -479,7 +480,9 @@ def case_box_post():
     np.savetxt(f, stats)
     out = descale_box_params(boxes.clone(), file=f)
     ang = postprocess_sincos2arctan(sc)
-    save('box_post', boxes=boxes, sincos=sc, stats=torch.from_numpy(stats), boxes_out=out, angle=ang)
+    boxes7 = torch.from_numpy(rs.uniform(-1.2, 1.2, (33, 7)).astype(np.float32))         # angle=True: 7-column boxes
+    out7 = descale_box_params(boxes7.clone(), file=f, angle=True)
+    save('box_post', boxes=boxes, sincos=sc, stats=torch.from_numpy(stats), boxes_out=out, angle=ang, boxes7=boxes7, boxes7_out=out7)
 
 
 def case_nomp():
@@ -768,6 +771,52 @@ def case_sampler_options():
     save('sampler_options_tiny', **out)
 
 
+def case_unet1d_mc384():
+    """VERDICT r4 "missing #3": GroupNorm32(32, channels) takes every channels % 32 == 0 (ldm_diffusion_util.py:222-239).  A layout
+    denoiser with model_channels = 384 has GroupNorm groups of 12 and 24 channels (and 36 behind the skip concatenations) -- none a
+    power of two.  Reference modules, seeded weights, both conditioning families: eps at one timestep (O = 8), and 3 ancestral
+    steps of a 100-step schedule through the reference's loop."""
+    for tag, concat in (('crossattn', False), ('concat', True)):
+        net, kw = _unet1d(384, 128, concat=concat)
+        fill(net, 'unet1d_mc384_%s.' % tag)
+        objs, triples = synth.synthetic_graph(8, seed=31)
+        box = rnd((8, 8), 311)
+        oe = rnd((8, 640), 312)
+        t = torch.full((8,), 437, dtype=torch.int64)
+        with torch.no_grad():
+            eps = net(box, oe, triples, t)
+        noise = synth.layout_noise(8, 8, 100, seed=11)
+        oe2, tri2, x, traj, _ = _layout_loop(net, kw, 8, 32, 100, 3, noise)
+        save('unet1d_mc384_' + tag, box=box, obj_embed=oe, triples=triples, t=t, eps=eps.squeeze(-1), loop_obj_embed=oe2,
+             loop_triples=tri2, loop_x3=x)
+
+
+def case_sampler_variants():
+    """The parameterisations GaussianDiffusion can sample with beyond the shipped 'linear' / 'eps' / 'fixedsmall' (VERDICT r4 "missing
+    #4"): the warm-up beta schedules of get_betas (diffusion_ddpm.py:38-58), x0-prediction (:246-254) and the 'fixedlarge' variance
+    (:224-235).  All 100 steps at tiny width through the reference's own gen_samples_sg, injected noise; the 'cosine' branch of
+    get_betas is recorded as what it does in the reference: it raises."""
+    net, kw = _unet1d(128, 128)
+    fill(net, 'unet1d_tiny.')
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    out = {}
+    for tag, ov in (('warm01_large', dict(schedule_type='warm0.1', model_var_type='fixedlarge')),
+                    ('warm05_x0', dict(schedule_type='warm0.5', model_mean_type='x0')),
+                    ('warm02_x0_large_clip', dict(schedule_type='warm0.2', model_mean_type='x0', model_var_type='fixedlarge'))):
+        oe, triples, x, _, tabs = _layout_loop(net, kw, 8, 3, 100, 100, noise, clip_denoised=tag.endswith('clip'), **ov)
+        out['x_final_' + tag] = x
+        out.update(obj_embed=oe, triples=triples)
+    from model.networks.diffusion_layout.diffusion_ddpm import get_betas
+    for st in ('warm0.1', 'warm0.2', 'warm0.5'):
+        out['betas_' + st.replace('.', '')] = torch.from_numpy(get_betas(st, 1e-4, 0.02, 1000))
+    try:
+        get_betas('cosine', 1e-4, 0.02, 1000)
+        out['cosine_raises'] = torch.zeros(1)
+    except UnboundLocalError:
+        out['cosine_raises'] = torch.ones(1)
+    save('sampler_variants_tiny', **out)
+
+
 def case_temb():
     """a8: the reference's timestep_embedding (ldm_diffusion_util.py:174-194) for both schedules: t = 999..0 at dim 512
     (layout) and the 100 DDIM timesteps at dim 224 (shape) -- pins the product's host tables bit for bit."""
@@ -955,7 +1004,7 @@ def case_gcn_pooling():
                  cfg=np.array([din, dp, 3, H, 1, 1, dout, code]))
 
 
-CASES = dict(gcn_pooling=case_gcn_pooling, sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
+CASES = dict(unet1d_mc384=case_unet1d_mc384, sampler_variants=case_sampler_variants, gcn_pooling=case_gcn_pooling, sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
              scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,

@@ -236,6 +236,13 @@ def test_box_postprocess_matches_reference_helpers():
     r = descale_box_params(b, stats=stats)
     assert r.data_ptr() == b.data_ptr()
     assert torch.allclose(b.cpu(), orc.descale_box_params(boxes, stats), atol=1e-6, rtol=1e-6)
+    g = load_golden('box_post')                                     # the reference's own outputs, incl. angle=True (7 columns)
+    b6 = g['boxes'].cuda()
+    descale_box_params(b6, stats=g['stats'].numpy())
+    assert torch.allclose(b6.cpu(), g['boxes_out'], atol=1e-6, rtol=1e-6)
+    b7 = g['boxes7'].cuda()
+    assert descale_box_params(b7, stats=g['stats'].numpy(), angle=True).data_ptr() == b7.data_ptr()
+    assert torch.allclose(b7.cpu(), g['boxes7_out'], atol=1e-6, rtol=1e-6)
     a = postprocess_sincos2arctan(sc.cuda())
     assert tuple(a.shape) == (33, 1)
     assert torch.allclose(a.cpu(), orc.sincos2arctan(sc), atol=2e-6)

@@ -83,10 +83,14 @@ def test_ddpm_tables_bit_exact():
     g = load_golden('ddpm_tables_1000')
     tab = orc.ddpm_tables(1e-4, 0.02, 1000)
     for k, v in tab.items():
+        if k in ('betas', 'posterior_variance'):        # (inputs of the 'fixedlarge' variance; pinned through sampler_variants_tiny)
+            continue
         assert torch.equal(v, g[k]), k
     g100 = load_golden('layout_loop_tiny')
     tab = orc.ddpm_tables(1e-4, 0.02, 100)
     for k, v in tab.items():
+        if k in ('betas', 'posterior_variance'):
+            continue
         assert torch.equal(v, g100['tab100_' + k]), k
 
 
@@ -163,6 +167,69 @@ def test_sampler_options_clip_denoised_and_ddim_eta():
                               for k in range(4)])
     z = orc.shape_sample_loop(dsd, g['ddim_uc_s'], g['ddim_triples'], synth.shape_noise(seed=7), S=4, eta=0.7, step_noise=step_noise)
     _close(z, g['ddim_z_final_eta07'], 2e-4)
+
+
+@pytest.mark.parametrize('tag,concat', [('crossattn', False), ('concat', True)])
+def test_unet1d_model_channels_384(tag, concat):
+    """GroupNorm32 groups that are not a power of two (model_channels = 384: 12 / 24 / 36 channels per group; reference: any
+    channels % 32 == 0, ldm_diffusion_util.py:222-239): the oracle against the reference's eps and 3 loop steps."""
+    g = load_golden('unet1d_mc384_' + tag)
+    kw = dict(escfg.layout_denoiser_kwargs(384, concat=concat))
+    kw['concat_dim'] = kw['crossattn_dim'] = 128
+    sd = seeded_state_dict(UNet1DModel(**kw), 'unet1d_mc384_%s.' % tag)
+    eps = orc.unet1d_forward(sd, g['box'], g['obj_embed'], g['triples'], g['t'])      # (the family is read off the input conv's width)
+    _close(eps, g['eps'], 5e-5)
+    if not concat:                                     # (one loop keeps the CPU suite short; the HIP test runs both)
+        x = orc.layout_sample_loop(sd, g['loop_obj_embed'], g['loop_triples'], synth.layout_noise(8, 8, 100, seed=11), time_num=100,
+                                   n_steps=3)
+        _close(x, g['loop_x3'], 1e-4)
+
+
+def test_sampler_variants_schedules_x0_prediction_fixedlarge():
+    """The other parameterisations GaussianDiffusion samples with (get_betas warm-up schedules diffusion_ddpm.py:38-58, x0-prediction
+    :246-254, 'fixedlarge' :224-235): goldens from the reference's own gen_samples_sg (make_golden.py case_sampler_variants).  The
+    oracle restates the branches; the product expresses all of them as ONE coefficient table of the same update op
+    (schedules.LayoutSchedule) -- both are checked: the oracle loop against the reference's results, the product's table against the
+    oracle's step on random data, bit for bit."""
+    import numpy as np
+    from echoscene_amd.schedules import LayoutSchedule, layout_betas
+    g = load_golden('sampler_variants_tiny')
+    for st in ('warm0.1', 'warm0.2', 'warm0.5'):
+        ref = g['betas_' + st.replace('.', '')].double().numpy()
+        assert np.array_equal(orc.get_betas(st, 1e-4, 0.02, 1000), ref) and np.array_equal(layout_betas(st, 1e-4, 0.02, 1000), ref)
+    assert float(g['cosine_raises']) == 1.0
+    for fn in (orc.get_betas, layout_betas):
+        with pytest.raises(UnboundLocalError):
+            fn('cosine', 1e-4, 0.02, 1000)
+        with pytest.raises(NotImplementedError):
+            fn('quadratic', 1e-4, 0.02, 1000)
+    sd = _unet1d_sd(128, 128, 'unet1d_tiny.')
+    noise = synth.layout_noise(8, 8, 100, seed=7)
+    plain = load_golden('layout_loop_tiny')['x_final']
+    cases = (('warm01_large', dict(schedule_type='warm0.1', model_var_type='fixedlarge'), False),
+             ('warm05_x0', dict(schedule_type='warm0.5', model_mean_type='x0'), False),
+             ('warm02_x0_large_clip', dict(schedule_type='warm0.2', model_mean_type='x0', model_var_type='fixedlarge'), True))
+    for tag, kw, clip in cases:
+        x = orc.layout_sample_loop(sd, g['obj_embed'], g['triples'], noise, time_num=100, clip_denoised=clip, **kw)
+        _close(x, g['x_final_' + tag], 1e-4)
+        assert (x - plain).abs().max() > 1e-3
+        # the product's table: x0 = c0 x - c1 out; mean = c2 x0 + c3 x; x' = mean + c4 noise (k_ddpm_update, no contraction)
+        sch = LayoutSchedule(100, 1e-4, 0.02, **kw)
+        tab = orc.ddpm_tables(1e-4, 0.02, 100, kw['schedule_type'])
+        rs = np.random.RandomState(5)
+        for t in (99, 57, 10, 1, 0):
+            xx, out, nz = (torch.from_numpy(rs.standard_normal((8, 8)).astype('float32')) for _ in range(3))
+            want = orc.ddpm_step(tab, xx, out, t, nz, clip, kw.get('model_mean_type', 'eps'), kw.get('model_var_type', 'fixedsmall'))
+            c = sch.coef[99 - t]
+            x0 = c[0] * xx - c[1] * out
+            if clip:
+                x0 = torch.clamp(x0, -1.0, 1.0)
+            got = (c[2] * x0 + c[3] * xx) + c[4] * nz
+            assert torch.equal(got, want), (tag, t)
+    with pytest.raises(NotImplementedError):
+        LayoutSchedule(100, model_var_type='learned')
+    with pytest.raises(NotImplementedError):
+        LayoutSchedule(100, model_mean_type='v')
 
 
 def _unet3d_sd(mc, ctx, prefix):
@@ -354,4 +421,6 @@ def test_box_postprocess_helpers_vs_reference():
     g = load_golden('box_post')
     out = orc.descale_box_params(g['boxes'].clone(), g['stats'].numpy())
     _close(torch.as_tensor(out), g['boxes_out'], 1e-6)
+    out7 = orc.descale_box_params(g['boxes7'].clone(), g['stats'].numpy(), angle=True)         # helpers/util.py:553-555
+    _close(torch.as_tensor(out7), g['boxes7_out'], 1e-6)
     _close(torch.as_tensor(orc.sincos2arctan(g['sincos'])).reshape(-1, 1), g['angle'], 1e-6)
