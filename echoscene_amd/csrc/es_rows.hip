@@ -762,7 +762,7 @@ static thread_local const es_linear_args* g_rows_next = nullptr;
 void es_rows_hint_next(const es_linear_args* next) { g_rows_next = next; }
 
 namespace {
-struct RowsPrep { es_linear_args a; int S, kbps, nsmax, proc, nb; bool has_ln, csr, gepi; };
+struct RowsPrep { es_linear_args a; int S, kbps, nsmax, proc, nb; bool has_ln, csr, gepi, lnattn; };
 
 // validation + normalisation of one problem (op-level prologue -> segments; slice choice)
 int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
@@ -799,7 +799,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
             koff += a.seg[s].width;
         }
     }
-    bool has_ln = false;
+    bool has_ln = false, lnattn = false;
     {
         int koff = 0;
         for (int s = 0; s < a.nseg; ++s) {
@@ -813,6 +813,14 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
                 ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && (sg.gamma != nullptr) == (sg.beta != nullptr) && sg.width <= 1024,
                            "es_linear_rows_f32: LayerNorm prologue needs ONE direct segment of width <= 1024 (gamma AND beta, or neither: affine folded into the weights)");
                 has_ln = true;
+            } else if (sg.pro == ES_PRO_LN_ATTN) {
+                // LayerNorm over a row formed from [t0 | u], two vectors and the cross-attention vector (echoscene_hip.h, es_seg.pro)
+                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta && sg.width <= 512 && sg.width % 16 == 0 &&
+                           sg.gs >= sg.width && sg.gs % 4 == 0 && a.res && a.res2 && a.res_nslab <= 1 && a.res2_nslab <= 1 &&
+                           a.res_ld % 4 == 0 && a.res2_ld % 4 == 0 && !a.res_step,
+                           "es_linear_rows_f32: ES_PRO_LN_ATTN needs ONE direct segment of width <= 512, both vectors, u at gs >= width columns, "
+                           "and plain res (output) / res2 (cross-attention vector) matrices");
+                has_ln = true; lnattn = true;
             } else if (sg.pro == ES_PRO_GEGLU) {
                 ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT, "es_linear_rows_f32: GEGLU prologue needs one direct segment");
             } else {
@@ -825,7 +833,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
     const int nb = a.nbatch > 1 ? a.nbatch : 1;
     ES_REQUIRE(nb == 1 || (a.nseg == 1 && a.seg[0].mode == ES_SEG_DIRECT && a.seg[0].pro == ES_PRO_NONE && !a.res && !a.res2),
                "es_linear_rows_f32: batched launch supports one direct segment, no prologue, no residuals");
-    ES_REQUIRE(a.act != ES_ACT_GEGLU || (a.N % 16 == 0 && !a.res2), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
+    ES_REQUIRE(a.act != ES_ACT_GEGLU || (a.N % 16 == 0 && (!a.res2 || lnattn)), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
     int kbps = 0;
     const int S = es_linear_rows_slices(&a, &kbps);
     ES_REQUIRE(S >= 1, "es_linear_rows_f32: segment-aligned slices need segment widths that are multiples of 16");
@@ -844,7 +852,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
         csr = csr || a.seg[s].mode == ES_SEG_CSRMEAN || a.seg[s].mode == ES_SEG_CSRSUM || a.seg[s].mode == ES_SEG_CSRWAVG;
     }
     out->a = a; out->S = S; out->kbps = kbps; out->nsmax = nsmax; out->proc = proc; out->nb = nb;
-    out->has_ln = has_ln; out->csr = csr; out->gepi = a.act == ES_ACT_GEGLU;
+    out->has_ln = has_ln; out->csr = csr; out->gepi = a.act == ES_ACT_GEGLU; out->lnattn = lnattn;
     return 0;
 }
 
@@ -863,7 +871,7 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
     for (int s = 0; s < a.nseg; ++s) {
         const es_seg& sg = a.seg[s];
         if (sg.mode != ES_SEG_DIRECT && sg.mode != ES_SEG_GATHER) return false;
-        if (sg.pro != ES_PRO_NONE && sg.pro != ES_PRO_GN && sg.pro != ES_PRO_GN_SILU && sg.pro != ES_PRO_LN) return false;
+        if (sg.pro != ES_PRO_NONE && sg.pro != ES_PRO_GN && sg.pro != ES_PRO_GN_SILU && sg.pro != ES_PRO_LN && sg.pro != ES_PRO_LN_ATTN) return false;
         if (sg.step || sg.nslab > 6 || sg.width % 16) return false;
         if ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) && sg.gs < 4) return false;
         koff += sg.width;
@@ -909,6 +917,7 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
     if (gs32 && (Jw & 1)) ++Jw;
     xp->uniform = true;
     for (int i = 0; i + 1 < S; ++i) xp->uniform = xp->uniform && (xp->cut[i + 1] - xp->cut[i] == xp->cut[1] - xp->cut[0]);
+    if (p.lnattn && S != 1) return false;
     if (p.has_ln) {
         if (S > 2 || S * Jw > 4 || p.nsmax > 2) return false;
         if (S == 2 && xp->cut[2] - xp->cut[1] != xp->cut[1] - xp->cut[0]) return false;
@@ -932,6 +941,7 @@ void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
     P.M = a.M; P.N = a.N; P.inv_k = 1.0f / (float)a.K; P.nkb_total = a.K / 16; P.S = xp.S | (((32768 + xp.S - 1) / xp.S) << 16); P.Jw = xp.Jw; P.act = a.act;
     P.res_ld = a.res_ld; P.res_nslab = a.res_nslab > 1 ? a.res_nslab : 1; P.res_sstr = a.res_slab_stride;
     P.res2_ld = a.res2_ld; P.res2_nslab = a.res2_nslab > 1 ? a.res2_nslab : 1; P.res2_sstr = a.res2_slab_stride;
+    if (pr.lnattn) P.res_nslab = P.res2_nslab = 0;        // res: the formed row's output, res2: an operand of the prologue -- the epilogue adds neither
     P.out_ld = a.out_ld; P.out_sstr = a.out_slab_stride;
     int segc0[3] = {0, 0, 0};
     for (int s = 1; s < a.nseg; ++s) segc0[s] = segc0[s - 1] + a.seg[s - 1].width;
@@ -939,7 +949,7 @@ void x_fill(XProb& P, const RowsPrep& pr, const XPlan& xp) {
         const es_seg& sg = a.seg[xp.segof[i]];
         XSlice& d = P.sl[i];
         const int col = xp.cut[i] * 16 - segc0[xp.segof[i]];          // first column of the slice inside its segment
-        const bool ln = sg.pro == ES_PRO_LN;
+        const bool ln = sg.pro == ES_PRO_LN || sg.pro == ES_PRO_LN_ATTN;
         d.a = sg.ptr + (ln ? 0 : col);
         d.idx = sg.mode == ES_SEG_GATHER ? sg.idx : nullptr;
         d.gamma = sg.gamma ? sg.gamma + (ln ? 0 : col) : nullptr;
@@ -964,7 +974,7 @@ XPre x_prefetch_of_next() {
     XPlan xp;
     if (!x_plan(pr, &xp)) return pf;
     const int nct = (pr.a.N + 15) / 16;
-    const int nt = (pr.has_ln && pr.gepi && xp.S == 1 && nct % 2 == 0) ? 2 : 1;
+    const int nt = (pr.has_ln && pr.gepi && xp.S == 1 && nct % 2 == 0 && !pr.lnattn) ? 2 : 1;
     pf.w = (const char*)pr.a.wpack;
     pf.gx = nct / nt * xp.S;
     pf.smagic = xp.S | (((32768 + xp.S - 1) / xp.S) << 16);
@@ -1012,9 +1022,10 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
     if (has_ln) {
         if (n != 1 || gather) return -1;
         const RowsPrep& p0 = pr[0];
-        const bool nt2 = p0.gepi && xp[0].S == 1 && ((p0.a.N + 15) / 16) % 2 == 0;
+        const bool nt2 = p0.gepi && xp[0].S == 1 && ((p0.a.N + 15) / 16) % 2 == 0 && !p0.lnattn;
         nt = nt2 ? 2 : 1;
-        if (xp[0].S == 2) fn = (const void*)k_rows_x<2, 2, 2, 2, 1, true, 1>;
+        if (p0.lnattn) fn = (const void*)k_rows_x<4, 2, 3, 1, 1, true, 1>;
+        else if (xp[0].S == 2) fn = (const void*)k_rows_x<2, 2, 2, 2, 1, true, 1>;
         else fn = nt2 ? (const void*)k_rows_x<4, 2, 2, 1, 2, true, 1> : (const void*)k_rows_x<4, 2, 2, 1, 1, true, 1>;
     } else {
         if (cls < 0) return -1;
@@ -1126,6 +1137,9 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
             }
         }
     }
+    for (int i = 0; i < n; ++i)
+        ES_REQUIRE(!pr[i].lnattn, "es_linear_rows_f32: ES_PRO_LN_ATTN runs on the register-operand kernel only (K=%d, %d slabs, kernel family %d): "
+                                  "ask es_linear_rows_takes_ln_attn() at plan build", pr[i].a.K, pr[i].nsmax, g_rows_family);
     // k_linear_rows cuts K uniformly: segment-aligned cuts must coincide with that (every segment but the last a multiple of the slice)
     for (int i = 0; i < n; ++i) {
         const es_linear_args& a = pr[i].a;
@@ -1201,6 +1215,17 @@ int rows_launch(const RowsPrep* pr, int n, es_stream stream) {
     return 0;
 }
 }  // namespace
+
+// 1 when es_linear_rows_f32(a) with an ES_PRO_LN_ATTN segment would run (the register-operand kernel takes it), 0 when not (the planner
+// then keeps the self-attention product as its own launch), -1 on invalid arguments.  Host-only: launches nothing.
+extern "C" int es_linear_rows_takes_ln_attn(const es_linear_args* a) {
+    RowsPrep pr;
+    if (rows_prepare(a, &pr)) return -1;
+    if (!pr.lnattn || g_rows_family != 1) return 0;
+    RowsLaunch L;
+    memset(&L, 0, sizeof(L));
+    return x_launch(&pr, 0, nullptr, L, 0, 0) == -2 ? 1 : 0;
+}
 
 extern "C" int es_rows_get_kernel_family(void) { return g_rows_family; }
 

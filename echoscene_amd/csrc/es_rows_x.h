@@ -92,14 +92,19 @@ __device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 
 // JW: bound of the k-blocks per wave and slice; NS: bound of the slab counts; PROC 0: raw / ReLU'd operands, 1: + GroupNorm(+SiLU),
-// 2: LayerNorm over the row (SLN = slices the row is cut into: the statistics need all of them); NT: column tiles per workgroup;
+// 2: LayerNorm over the row (SLN = slices the row is cut into: the statistics need all of them); 3: LayerNorm over a row that is
+// FORMED here (ES_PRO_LN_ATTN, the one-token self-attention of a transformer block folded into its input projection, plan.py: the
+// producer wrote [t0 | u] with u = t0 W1^T through folded weights; the row is x = rstd(t0) (u - mean(t0) c) + b + t0 + cav, i.e.
+// attn1(LayerNorm1(t0)) + t0 + attn2 -- a dependent launch less per block; c / b arrive as the slice's gamma / beta vectors, cav as
+// the launch's res2, and the workgroups of column tile 0 publish x through the launch's res pointer); NT: column tiles per workgroup;
 // NP: problems the launch may carry (1: single-problem launches read a 3x smaller argument block and skip the problem lookup).
 // GATHER: rows may be gathered through an index (a dependent round trip in front of the A loads: its own variants).
 template <int JW, int NS, int PROC, int SLN, int NT, bool GEGLU_EPI, int NP, bool GATHER = false>
 __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
     __shared__ __attribute__((aligned(16))) float red[NT * NKG * 256];
-    __shared__ float lnx[PROC == 2 ? 2 * NKG * 16 : 1];
+    __shared__ float lnx[PROC >= 2 ? 2 * NKG * 16 : 1];
     static_assert(PROC == 2 || SLN == 1, "k_rows_x: only LayerNorm reads foreign slices");
+    static_assert(PROC != 3 || NT == 1, "k_rows_x: the formed-row variant has one column tile per workgroup (register budget)");
 #ifdef ES_STAMP
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     st_[0] = __builtin_amdgcn_s_memrealtime();
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < (PROC == 2 ? 3 : 1); ++i) __syncthreads();
+        for (int i = 0; i < (PROC == 3 ? 5 : PROC == 2 ? 3 : 1); ++i) __syncthreads();
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink));
         return;
     }
@@ -199,7 +204,23 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
             av[v][u] = x_ld4(rA, (sl < S ? voff : XOOB) + vj[j], so + (unsigned)u * sstr4);
         }
     }
-    const bool aff = PROC >= 1 && SL.gamma != nullptr;     // NULL: the affine of the norm is folded into the weights (host)
+    // PROC 3: the other operands of the formed row -- u at the same rows, SL.gs columns behind t0 in the producer's output (same
+    // slabs); the cross-attention vector (the launch's res2: plain rows, one slab); c and b come through the gamma / beta loads below
+    f4 uv[PROC == 3 ? JW : 1][NS], cv[PROC == 3 ? JW : 1];
+    if (PROC == 3) {
+        const unsigned uo = (unsigned)SL.gs * 4u;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const __amdgpu_buffer_rsrc_t rA = x_rsrc_if(SL.a, u < SL.nslab);
+#pragma unroll
+            for (int j = 0; j < JW; ++j) uv[j][u] = x_ld4(rA, voff + uo + vj[j], (unsigned)u * sstr4);
+        }
+        const __amdgpu_buffer_rsrc_t rC = x_rsrc(P.res2);
+        const unsigned co = ((unsigned)mc * (unsigned)P.res2_ld + colw) * 4u;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) cv[j] = x_ld4(rC, co + vj[j], 0);
+    }
+    const bool aff = PROC >= 1 && PROC != 3 && SL.gamma != nullptr;     // NULL: the affine of the norm is folded into the weights (host)
     if (PROC >= 1) {
         const __amdgpu_buffer_rsrc_t rG = x_rsrc_if(SL.gamma, (SL.flags & (2 | 8)) != 0), rB = x_rsrc_if(SL.beta, (SL.flags & (2 | 8)) != 0);
         const unsigned go = colw * 4u, gso = PROC == 2 ? (unsigned)(slice * SL.nkb) * 64u : 0u;
@@ -207,6 +228,9 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         for (int j = 0; j < JW; ++j) { gav[j] = x_ld4(rG, go + vj[j], gso); bev[j] = x_ld4(rB, go + vj[j], gso); }
     }
 
+    // (PROC 3, from the ISA: with 44 loads per lane the scheduler started summing the first slabs -- behind vmcnt waits -- before it had
+    //  issued the rest; nothing may move across this point, so every load is in flight before the first wait, as in the other variants)
+    if (PROC == 3) __builtin_amdgcn_sched_barrier(0);
     ES_RSTAMP(2);
 
     // (4) prologue in registers
@@ -267,7 +291,48 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
 #pragma unroll
         for (int j = 0; j < JW; ++j) if (j < Jw && j < nj) a[j] = o[j];      // (a[] stayed raw for the partner block of a 32-channel group)
     }
-    if (PROC == 2) {
+    if (PROC == 3) {
+        // statistics of the t0 row (LayerNorm 1 of the block: its affine sits in u's weights), exactly as the LayerNorm below forms them
+        float sm = 0.f;
+#pragma unroll
+        for (int v = 0; v < NB; ++v) sm += (a[v][0] + a[v][1]) + (a[v][2] + a[v][3]);
+        sm = quad_sum(sm);
+        if (q == 0) lnx[wave * 16 + i16] = sm;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NKG; ++w) tot += lnx[w * 16 + i16];
+        const float mean0 = tot * P.inv_k;
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NB; ++v) {
+            const float mv = (v < Jw && v < nj) ? mean0 : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mv; sq += d * d; }
+        }
+        sq = quad_sum(sq);
+        if (q == 0) lnx[NKG * 16 + wave * 16 + i16] = sq;
+        __syncthreads();
+        float tq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NKG; ++w) tq += lnx[NKG * 16 + w * 16 + i16];
+        const float rstd0 = __builtin_amdgcn_rsqf(tq * P.inv_k + SL.eps);
+        // x = rstd0 (u - mean0 c) + b + t0 + cav; column tile 0 publishes it (the feed-forward output product reads it as an operand)
+        const __amdgpu_buffer_rsrc_t rX = x_rsrc_if(P.res, bx == 0);
+        const unsigned xo = ((unsigned)mc * (unsigned)P.res_ld + colw) * 4u;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            f4 uu = uv[j][0];
+#pragma unroll
+            for (int u = 1; u < NS; ++u) uu += uv[j][u];
+            f4 y = a[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (((uu[e] - mean0 * gav[j][e]) * rstd0 + bev[j][e]) + y[e]) + cv[j][e];
+            a[j] = y;                                            // (blocks that do not exist: every operand is zero)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), rX, (int)((m < M && vj[j] != XOOB) ? xo + vj[j] : XOOB), 0, 0);
+        }
+    }
+    if (PROC >= 2) {
         // LayerNorm over the whole row: the 8 waves hold all k-blocks of the row between them
         float sm = 0.f;
 #pragma unroll

@@ -15,7 +15,7 @@ c_i32p = C.c_void_p
 
 # enums (include/echoscene_hip.h)
 SEG_DIRECT, SEG_GATHER, SEG_CSRMEAN, SEG_CSRSUM, SEG_CSRWAVG = 0, 1, 2, 3, 4
-PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU = 0, 1, 2, 3, 4, 5
+PRO_NONE, PRO_SILU, PRO_GN, PRO_GN_SILU, PRO_LN, PRO_GEGLU, PRO_LN_ATTN = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_SIGMOID = 0, 1, 2, 3, 4
 CONV_SAME, CONV_DOWN_HW, CONV_UP_HW, CONV_UP_DHW, CONV_DOWN_DHW = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
@@ -143,6 +143,7 @@ EXPORTS = {
     'es_options_string': (C.c_int, [C.c_char_p, C.c_int]),
     'es_model_file_options': (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     'es_linear_rows_slices': (C.c_int, [C.POINTER(LinearArgs), C.POINTER(C.c_int)]),
+    'es_linear_rows_takes_ln_attn': (C.c_int, [C.POINTER(LinearArgs)]),
     'es_linear_rows_auto_slices': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'es_row_select': (C.c_int, [C.POINTER(RowSelArgs), C.c_void_p]),
     'es_ddpm_update': (C.c_int, [C.POINTER(UpdateArgs), C.c_void_p]),

@@ -7,6 +7,7 @@ for device allocations, host-side weight preparation (BatchNorm folding, centre-
 concatenation of projection matrices) and host->device copies.
 """
 import ctypes as C
+from ctypes import byref as _byref
 import os
 
 import numpy as np
@@ -24,6 +25,11 @@ ROWS_CAV_SLICES = 1      # cross-attention-vector product: 1 / 2 / 3 / 4 slices 
 ROWS_LN_SPLIT = 2        # slices of a product whose consumer is a LayerNorm (whole-row statistics): 1 -> 1067, 2 -> 1093
 ROWS_VO1_SLICES = 2      # attention-with-one-token product: 2 / 1 -> 1124 / 1122
 ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's launch: measured -1.1 %
+# Round 5 (second half): the one-token self-attention of a transformer block, t2 = vo1(LayerNorm1(t0)) + t0 + cav, is linear in t0 up to the
+# row statistics: vo1(LN1(t0)) = rstd (t0 W1^T - mean c) + b with c = the row sums of W1, and t0 W1^T = GN(x) (W1 Wp)^T + W1 bp comes out
+# of the input projection's OWN launch (weights [Wp ; W1 Wp], folded in fp64).  The feed-forward launch then forms t2 in its prologue
+# (ES_PRO_LN_ATTN) and the self-attention product is no launch of its own: 11 dependent launches less per layout step.
+ROWS_FOLD_ATTN1 = True
 # The head of the UNet1D trunk (conv_in ... the first transformer's proj_in: 9 dependent products that do not need the GCN output)
 # rides on the launches of the GCN chain instead of following it: 9 launches off the critical path of a layout step.  Not a numerical
 # choice (every product keeps its own K slices: same bits), a planner constant (not an environment switch): 0 = off, 1 = conv_in on the box embedding's
@@ -271,6 +277,14 @@ def fold_bn(sd, lin, bn):
     b = sd[lin + '.bias'].double()
     s = sd[bn + '.weight'].double() / torch.sqrt(sd[bn + '.running_var'].double() + 1e-5)
     return (W * s[:, None]).float(), ((b - sd[bn + '.running_mean'].double()) * s + sd[bn + '.bias'].double()).float()
+
+
+def fold_affine64(W, b, gamma, beta):
+    """fold_affine in fp64, unrounded (for folds that continue)"""
+    Wd = W.detach().double()
+    g, be = gamma.detach().double().to(Wd.device), beta.detach().double().to(Wd.device)
+    bb = (b.detach().double().to(Wd.device) if b is not None else torch.zeros(W.shape[0], dtype=torch.float64, device=Wd.device)) + mm64(Wd, be)
+    return Wd * g[None, :], bb
 
 
 def fold_affine(W, b, gamma, beta):
@@ -954,6 +968,15 @@ class UNet1DWeights:
                                                      sd[tb + '.attn1.to_out.0.bias'], sd[tb + '.norm1.weight'], sd[tb + '.norm1.bias']), device)
                 d['ff1'] = PackedLinear(*fold_affine(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'],
                                                      sd[tb + '.norm3.weight'], sd[tb + '.norm3.bias']), device, geglu=True)
+                if ROWS_FOLD_ATTN1 and it[1] <= 512 and it[1] % 16 == 0:
+                    # [t0 | u] = GN(x) [Wp ; W1 Wp]^T + [bp ; W1 bp]  and the two vectors of  t2 = rstd (u - mean c) + b + t0 + cav
+                    Wp64, bp64 = fold_affine64(centre_tap(sd[name + '.proj_in.weight']), sd[name + '.proj_in.bias'],
+                                               sd[name + '.norm.weight'], sd[name + '.norm.bias'])
+                    W164, b164 = fold_affine64(mm64(sd[tb + '.attn1.to_out.0.weight'], sd[tb + '.attn1.to_v.weight']),
+                                               sd[tb + '.attn1.to_out.0.bias'], sd[tb + '.norm1.weight'], sd[tb + '.norm1.bias'])
+                    d['proj_in_u'] = PackedLinear(torch.cat([Wp64, mm64(W164, Wp64)], 0).float(), torch.cat([bp64, mm64(W164, bp64)], 0).float(), device)
+                    d['a1_c'] = own(W164.sum(dim=1), device)
+                    d['a1_b'] = own(b164, device)
                 # x_out = proj_out(ff2(g) + b2 + t2) + x_in is linear in (g, t2): ONE op over the K-concatenation [g | t2] with
                 # [Wpo.Wff2 | Wpo] (folded in fp64) -- one dependent launch less per transformer block
                 Wpo = centre_tap(sd[name + '.proj_out.weight']).double()
@@ -1117,10 +1140,33 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
             elif kind == 'attn':
                 C = it[1]
                 xin = h_segs[0]
-                t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C, b=b, M=O), d['proj_in'], O, split=ln_kbps(C))
+                fold = ROWS_FOLD_ATTN1 and 'proj_in_u' in d and b.allow_split
+                t0 = b.linear(norm_segs([xin], d['gn'][0], d['gn'][1], 1e-6, False, C=C, b=b, M=O), d['proj_in_u' if fold else 'proj_in'], O,
+                              split=ln_kbps(C))
+                if fold:
+                    t0 = t0.cols(0, C)               # (u = t0 W1^T sits C columns further in the same slabs)
                 yield
                 yield 'CTX'                      # the next product adds the cross-attention vector of the GCN output
                 cavo = box['cavo']
+                if fold:
+                    # the feed-forward launch forms t2 = attn1(norm1(t0)) + t0 + attn2 in its prologue and publishes it (ES_PRO_LN_ATTN)
+                    t2 = View(b.buf(O, C, scratch=True))
+                    n_ops, acct = len(b.ops), (b.weight_bytes, b.flops)
+                    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, gamma=d['a1_c'], beta=d['a1_b'], eps=1e-5, gs=C)], d['ff1'], O,
+                                  res=t2, res2=cavo[name])
+                    if hip.lib().es_linear_rows_takes_ln_attn(_byref(b.ops[-1].u.linear)) != 1:
+                        del b.ops[n_ops:]            # (no kernel for this shape: the self-attention product stays a launch of its own)
+                        b.weight_bytes, b.flops = acct
+                        fold = False
+                if fold:
+                    yield
+                    b.tags[name + '.transformer_blocks.0:in'] = t0
+                    b.tags[name + '.transformer_blocks.0:attn2'] = t2
+                    o = b.linear([seg(gl), seg(t2)], d['ff2po'], O, res=xin)
+                    yield
+                    h_segs, hC = [o], C
+                    b.tags[name] = h_segs[0]
+                    continue
                 # x = attn1(norm1(x)) + x ; x = attn2(norm2(x), ctx) + x.  With one token attn1 is the folded matrix
                 # to_out.to_v applied to LN1(x); with one key the second line adds the per-node vector
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.

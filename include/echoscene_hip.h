@@ -51,7 +51,7 @@ int es_device_info(char* name_out, int name_cap, int* cu_count);
 enum { ES_SEG_DIRECT = 0, ES_SEG_GATHER = 1, ES_SEG_CSRMEAN = 2, ES_SEG_CSRSUM = 3, ES_SEG_CSRWAVG = 4 };
 /* CSRSUM: pooling='sum' (graph.py:186-199 without the division); CSRWAVG: pooling='wAvg' (graph.py:163-184): every entry is scaled by
  * its learned weight (es_seg.ent_wt) before the sum and the sum is divided by (sum of the weights + 1e-4) */
-enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5 };
+enum { ES_PRO_NONE = 0, ES_PRO_SILU = 1, ES_PRO_GN = 2, ES_PRO_GN_SILU = 3, ES_PRO_LN = 4, ES_PRO_GEGLU = 5, ES_PRO_LN_ATTN = 6 };
 enum { ES_ACT_NONE = 0, ES_ACT_RELU = 1, ES_ACT_SILU = 2, ES_ACT_GEGLU = 3, ES_ACT_SIGMOID = 4 };   /* SIGMOID: WeightNetGCN's heads (graph.py:44-57) */
 /* ES_ACT_GEGLU: W/bias rows are interleaved per 16-row tile as [8 value rows | 8 gate rows] (es_pack_linear_geglu_f32);
  * the kernel writes N/2 columns: value * gelu(gate)  (GEGLU.forward, attention.py:39-46). */
@@ -74,7 +74,13 @@ typedef struct es_seg {
                               own ReLU; build_mlp's final_nonlinearity, model/layers.py:33-37)          */
     /* per-segment prologue (the op-level `prologue` below is shorthand for the same prologue on every segment):
      * ES_PRO_GN / GN_SILU: GroupNorm over THIS segment in groups of `gs` channels (4..32, power of two), affine gamma/beta
-     * [width]; ES_PRO_LN: LayerNorm over the segment (must be the only one); ES_PRO_SILU; ES_PRO_GEGLU.             */
+     * [width]; ES_PRO_LN: LayerNorm over the segment (must be the only one); ES_PRO_SILU; ES_PRO_GEGLU.             
+     * ES_PRO_LN_ATTN (round 5; the only segment, direct, launches the library routes to its register-operand kernel -- ask
+     * es_linear_rows_takes_ln_attn()): LayerNorm over a row that the launch FORMS first from the producer's output [t0 | u]
+     * (u = `gs` columns behind the segment's pointer, same slabs): x = rstd(t0) * (u - mean(t0) * gamma) + beta + t0 + res2, with
+     * gamma / beta the two vectors of the folded one-token self-attention (plan.py, attention.py:172-219 on one token) and res2 the
+     * cross-attention vector -- i.e. x = attn1(norm1(t0)) + t0 + attn2(norm2(.), ctx).  The launch's `res` is then an OUTPUT: x is
+     * written there ([M, res_ld], by the workgroups of column tile 0) and neither res nor res2 is added in the epilogue.          */
     int32_t pro;
     const float* gamma; const float* beta;
     float eps;
@@ -163,6 +169,9 @@ int es_options_string(char* out, int cap);              /* + "rows_family=..." :
 int es_model_file_options(const char* path, char* out, int cap);   /* the options string recorded in a model file (no device needed) */
 /* number of slices the launch will run for `args` (and the rounded kb_per_slice) -- the planner sizes the slab buffer with it */
 int es_linear_rows_slices(const es_linear_args* args, int* kb_per_slice);
+/* host-only: 1 when a launch with an ES_PRO_LN_ATTN segment (es_seg.pro) would run, 0 when the library has no kernel for its shape
+ * (the planner then keeps the self-attention product as a launch of its own), -1 on invalid arguments */
+int es_linear_rows_takes_ln_attn(const es_linear_args* args);
 /* the library's default kb_per_slice for a [*, K] x [K, N] product whose slices must be multiples of kalign_cols columns
  * (~256 workgroups per 32 rows, >= 128 columns per slice, <= 8 slabs); 0 = do not split */
 int es_linear_rows_auto_slices(int K, int N, int kalign_cols);

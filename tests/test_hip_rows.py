@@ -554,6 +554,47 @@ def test_linear_split_k_slab_chain_and_rowsel(dev):
     assert torch.equal(out[:, 8:308].cpu(), table[4].cpu().expand(5, 300)) and float(out[:, :8].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('C,M', [(512, 32), (128, 8), (256, 45)])
+def test_rows_formed_row_layernorm_prologue(dev, C, M):
+    """ES_PRO_LN_ATTN (round 5): the launch forms x = rstd(t0) (u - mean(t0) c) + b + t0 + cav from the producer's [t0 | u] slab
+    tensor, publishes it through ``res`` and multiplies LayerNorm(x) by a GEGLU projection -- against the unfolded arithmetic
+    x = LN(t0) W1^T + b + t0 + cav in float64 (attention.py:172-219 on one token), incl. a row tile with rows past M and a row
+    and rows
+    whose mean is large against their spread (the cancellation the fold introduces)."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, PackedLinear, View, seg
+    import ctypes
+    rs = np.random.RandomState(C + M)
+    f = lambda *sh: torch.from_numpy(rs.standard_normal(sh).astype(np.float32))
+    Xin = f(M, C)
+    Wp, bp = f(C, C) / np.sqrt(C), 0.1 * f(C) + 4.0          # rows of t0 with |mean| = 4 x their spread
+    W1, b1 = f(C, C) / np.sqrt(C), 0.1 * f(C)
+    Wg, bg = f(8 * C, C) / np.sqrt(C), 0.1 * f(8 * C)
+    cav = f(M, C)
+    Wu = (W1.double() @ Wp.double())
+    bu = (W1.double() @ bp.double())
+    b = Builder(dev)
+    x = b.dev(Xin)
+    t0u = b.linear([seg(View(x))], PackedLinear(torch.cat([Wp.double(), Wu], 0).float(), torch.cat([bp.double(), bu], 0).float(), dev), M,
+                   split=max(8, (C // 16 + 1) // 2))
+    assert t0u.nslab <= 2
+    t0 = t0u.cols(0, C)
+    t2 = View(b.buf(M, C, zero=True))
+    cv = b.dev(cav)
+    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, gamma=b.dev(W1.double().sum(1).float()), beta=b.dev(b1), eps=1e-5, gs=C)],
+                  PackedLinear(Wg, bg, dev, geglu=True), M, res=t2, res2=View(cv))
+    assert hip.lib().es_linear_rows_takes_ln_attn(ctypes.byref(b.ops[-1].u.linear)) == 1
+    b.finish().run()
+    torch.cuda.synchronize()
+    T0 = F.linear(Xin.double(), Wp.double(), bp.double())
+    X2 = F.linear(F.layer_norm(T0, (C,), None, None, 1e-5), W1.double(), b1.double()) + T0 + cav.double()
+    H = F.linear(F.layer_norm(X2, (C,), None, None, 1e-5), Wg.double(), bg.double())
+    ref = H[:, :4 * C] * F.gelu(H[:, 4 * C:])
+    _close(t0.value().cpu(), T0.float(), 2e-5)
+    _close(t2.value().cpu(), X2.float(), 5e-5)
+    _close(gl.value().cpu(), ref.float(), 1e-4)
+
+
 def test_linear_multi_problem_launch(dev):
     """Independent products marked ``fuse_next`` run as ONE grid (es_linear_rows_multi_f32): different M / K / N / slice counts, a
     gathered operand next to a direct one -- results identical to launching them one by one (ES_ROWS_FUSE semantics)."""

@@ -45,7 +45,14 @@ def _linear_io(a, hip):
             base = (sg.ptr or 0) + 4 * j * sg.slab_stride
             span = 4 * (max(sg.ld, 0) * ((a.M - 1) if sg.mode == hip.SEG_DIRECT else rows_max) + sg.width)
             reads.append((base, span, sg.mode != hip.SEG_DIRECT))
-    for ptr, ld, ns, ss in ((a.res, a.res_ld, a.res_nslab, a.res_slab_stride), (a.res2, a.res2_ld, a.res2_nslab, a.res2_slab_stride)):
+    ln_attn = a.nseg == 1 and a.seg[0].pro == hip.PRO_LN_ATTN        # res is an OUTPUT (the formed row), u sits gs columns behind t0
+    if ln_attn:
+        sg = a.seg[0]
+        for j in range(max(sg.nslab, 1)):
+            reads.append(((sg.ptr or 0) + 4 * (j * sg.slab_stride + sg.gs), 4 * (sg.ld * (a.M - 1) + sg.width), False))
+        for v in (sg.gamma, sg.beta):
+            reads.append((v, 4 * sg.width, False))
+    for ptr, ld, ns, ss in ((None if ln_attn else a.res, a.res_ld, a.res_nslab, a.res_slab_stride), (a.res2, a.res2_ld, a.res2_nslab, a.res2_slab_stride)):
         if ptr:
             for j in range(max(ns, 1)):
                 reads.append((ptr + 4 * j * ss, 4 * (ld * (a.M - 1) + a.N), False))
@@ -57,6 +64,8 @@ def _linear_io(a, hip):
         S = hip.lib().es_linear_rows_slices(C.byref(a), C.byref(got))       # (the library's rule: segment-aligned cuts since round 5)
     for j in range(S):
         writes.append(Rect(a.out + 4 * j * a.out_slab_stride, 4 * (a.out_ld * (a.M - 1) + Nout), 4 * a.out_ld, 4 * Nout))
+    if ln_attn:
+        writes.append(Rect(a.res, 4 * (a.res_ld * (a.M - 1) + a.seg[0].width), 4 * a.res_ld, 4 * a.seg[0].width))
     return reads, writes
 
 
