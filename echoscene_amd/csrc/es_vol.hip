@@ -82,11 +82,19 @@ __device__ __forceinline__ void gn_reduce_stats(const es_gn_args& a, const float
     const int C = a.C1 + a.C2, gs = C / a.groups;
     const int gi = threadIdx.x % a.groups, sl = threadIdx.x / a.groups, nsl = 256 / a.groups;
     double s = 0.0, q = 0.0;
-    if (sl < nsl)
-        for (int t = sl; t < ntiles; t += nsl) {
-            const float* p = part + (((long)o * ntiles + t) * a.groups + gi) * 2;
-            s += p[0]; q += p[1];
+    if (sl < nsl) {
+        // four partials in flight per thread, added in tile order (the bits of the plain loop: round 5 -- with one dependent L2 round
+        // trip per tile the 128-tile lists of a few-objects launch made this prologue most of k_gn_apply's 10 us)
+        typedef float f2g __attribute__((ext_vector_type(2)));
+        const f2g* pp = (const f2g*)part + ((long)o * ntiles * a.groups + gi);
+        const long st = (long)nsl * a.groups;
+        int t = sl;
+        for (; t + 3 * nsl < ntiles; t += 4 * nsl) {
+            const f2g p0 = pp[(long)t * a.groups], p1 = pp[(long)t * a.groups + st], p2 = pp[(long)t * a.groups + 2 * st], p3 = pp[(long)t * a.groups + 3 * st];
+            s += p0[0]; q += p0[1]; s += p1[0]; q += p1[1]; s += p2[0]; q += p2[1]; s += p3[0]; q += p3[1];
         }
+        for (; t < ntiles; t += nsl) { const f2g p0 = pp[(long)t * a.groups]; s += p0[0]; q += p0[1]; }
+    }
     ds[threadIdx.x] = s; dq[threadIdx.x] = q;
     __syncthreads();
     if (threadIdx.x < a.groups) {
@@ -205,33 +213,66 @@ __global__ __launch_bounds__(256) void k_gn_apply(const es_gn_args a, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm over tokens: one wave per row, fp32 in, fp16 out.
+// LayerNorm over tokens: fp32 in, fp16 out.  A wave owns rows wave, wave + W, wave + 2 W, ... (W = waves of the grid): 16-byte
+// loads (lane l: columns 4 (l + 64 i) ..+3), the NEXT row's loads are in flight while the current one is reduced and stored, the
+// affine vectors sit in registers for the whole launch, 8-byte stores.  Round 5: the one-row-per-wave version (8192 workgroups of four
+// short-lived waves, 4-byte loads, 2-byte stores) reached 4.1-4.5 TB/s on the two shapes of the UNet (32768 x 448, 8192 x 672).
+// Statistics as before: mean, then the centred sum of squares, from the registers (one pass over memory).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_layernorm(const es_ln_args a) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.M) return;
-    const float* p = a.x + (long)row * a.C;
-    float v[16];                                   // C <= 1024
-    float s = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int C = a.C, c4n = C >> 2;                 // (C % 4 == 0: host-checked; C <= 1024 -> at most 4 chunks per lane)
+    f4 ga[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int c = lane + 64 * j; v[j] = c < a.C ? p[c] : 0.f; s += v[j]; }
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = lane + 64 * i;
+        ga[i] = c4 < c4n ? *(const f4*)(a.gamma + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+        be[i] = c4 < c4n ? *(const f4*)(a.beta + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_c = 1.0f / (float)C;
+    f4 nx[4];
+    auto load = [&](int row) __attribute__((always_inline)) {
+        const float* p = a.x + (long)row * C;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)a.C;
-    float q = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            nx[i] = (row < a.M && c4 < c4n) ? *(const f4*)(p + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (wid < a.M) load(wid);
+    for (int row = wid; row < a.M; row += nw) {
+        f4 v[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int c = lane + 64 * j; const float d = c < a.C ? v[j] - mean : 0.f; q += d * d; }
+        for (int i = 0; i < 4; ++i) v[i] = nx[i];
+        load(row + nw);                              // (past the end: zeros, nothing is read)
+        float s = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
-    _Float16* y = (_Float16*)a.y_f16 + (long)row * a.C;
-    float* y32 = (float*)a.y_f16 + (long)row * a.C;          // y_is_f32: the fp32-operand validation route
+        for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c = lane + 64 * j;
-        if (c < a.C) {
-            const float t = (v[j] - mean) * rstd * a.gamma[c] + a.beta[c];
-            if (a.y_is_f32) y32[c] = t; else y[c] = (_Float16)t;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (lane + 64 * i < c4n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * inv_c + a.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < c4n) {
+                f4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * ga[i][e] + be[i][e];
+                if (a.y_is_f32) *(f4*)((float*)a.y_f16 + (long)row * C + 4 * c4) = t;          // the fp32-operand validation route
+                else *(h4*)((_Float16*)a.y_f16 + (long)row * C + 4 * c4) = h4{(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+            }
         }
     }
 }
@@ -2611,8 +2652,13 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
 }
 
 extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
-    ES_REQUIRE(a->C <= 1024 && a->C > 0, "es_layernorm_tokens: C=%d (max 1024)", a->C);
-    hipLaunchKernelGGL(k_layernorm, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+    ES_REQUIRE(a->C <= 1024 && a->C > 0 && a->C % 4 == 0, "es_layernorm_tokens: C=%d (a multiple of 4, max 1024)", a->C);
+    // resident waves loop over the rows: 8 workgroups of 4 waves per CU at most (timing-only switch ES_LN_WGS: workgroups of the launch)
+    static const char* ln_env = getenv("ES_LN_WGS");
+    long wgs = ((long)a->M + 3) / 4;
+    const long cap = ln_env && atoi(ln_env) > 0 ? atoi(ln_env) : 2048;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;
 }

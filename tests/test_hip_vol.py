@@ -232,6 +232,27 @@ def test_groupnorm_layernorm_geglu_tocl(dev):
     assert _rel(xcl[:, :3], _cl(xin)) < 1e-3 and xcl[:, 3:].abs().max() == 0
 
 
+@pytest.mark.parametrize('M,Cc', [(9001, 448), (8192, 672), (37, 1024), (3, 8), (20000, 100)])
+def test_layernorm_tokens_row_loop(dev, M, Cc):
+    """k_layernorm (round 5: resident waves loop over the rows, the next row's loads in flight): row counts above / below the
+    launch's wave count and not a multiple of it, widths with 1-4 chunks per lane and partial last chunks; f16 and fp32 outputs."""
+    from echoscene_amd.plan import Builder
+    t = _rnd((M, Cc), 11) * 3 - 1
+    ga, be = 1 + 0.1 * _rnd((Cc,), 12), 0.1 * _rnd((Cc,), 13)
+    ref = F.layer_norm(t, (Cc,), ga, be, 1e-5)
+    b = Builder(dev)
+    y16 = b.buf(M + 1, Cc, dtype=torch.float16, zero=True)
+    y32 = b.buf(M + 1, Cc, zero=True)
+    x = b.dev(t)
+    b.layernorm(x, M, Cc, b.dev(ga), b.dev(be), y16)
+    b.layernorm(x, M, Cc, b.dev(ga), b.dev(be), y32)
+    b.finish().run()
+    torch.cuda.synchronize()
+    assert (y32[:M].cpu() - ref).abs().max() < 2e-5
+    assert (y16[:M].float().cpu() - ref).abs().max() < 4e-3
+    assert float(y16[M].abs().max()) == 0.0 and float(y32[M].abs().max()) == 0.0        # nothing past the last row
+
+
 def test_gelu_of_the_volume_path_over_its_whole_range(dev):
     """es_gelu_fast (erfc by Abramowitz-Stegun 7.1.26 on the non-cancelling side; FeedForward GEGLU, reference attention.py:39-46
     uses F.gelu = exact erf): gate values on a grid over [-12, 12] with value 1 -> the fp16 output IS gelu(gate).  Bound: one fp16
