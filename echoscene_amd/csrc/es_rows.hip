@@ -974,7 +974,7 @@ XPre x_prefetch_of_next() {
     XPlan xp;
     if (!x_plan(pr, &xp)) return pf;
     const int nct = (pr.a.N + 15) / 16;
-    const int nt = (pr.has_ln && pr.gepi && xp.S == 1 && nct % 2 == 0 && !pr.lnattn) ? 2 : 1;
+    const int nt = (pr.has_ln && pr.gepi && xp.S == 1 && nct % 2 == 0) ? 2 : 1;
     pf.w = (const char*)pr.a.wpack;
     pf.gx = nct / nt * xp.S;
     pf.smagic = xp.S | (((32768 + xp.S - 1) / xp.S) << 16);
@@ -1022,9 +1022,9 @@ int x_launch(const RowsPrep* pr, int n, es_stream stream, const RowsLaunch& RL, 
     if (has_ln) {
         if (n != 1 || gather) return -1;
         const RowsPrep& p0 = pr[0];
-        const bool nt2 = p0.gepi && xp[0].S == 1 && ((p0.a.N + 15) / 16) % 2 == 0 && !p0.lnattn;
+        const bool nt2 = p0.gepi && xp[0].S == 1 && ((p0.a.N + 15) / 16) % 2 == 0;
         nt = nt2 ? 2 : 1;
-        if (p0.lnattn) fn = (const void*)k_rows_x<4, 2, 3, 1, 1, true, 1>;
+        if (p0.lnattn) fn = nt2 ? (const void*)k_rows_x<4, 2, 3, 1, 2, true, 1> : (const void*)k_rows_x<4, 2, 3, 1, 1, true, 1>;
         else if (xp[0].S == 2) fn = (const void*)k_rows_x<2, 2, 2, 2, 1, true, 1>;
         else fn = nt2 ? (const void*)k_rows_x<4, 2, 2, 1, 2, true, 1> : (const void*)k_rows_x<4, 2, 2, 1, 1, true, 1>;
     } else {
