@@ -15,7 +15,7 @@ den.sample(obj_embed, triples, noise=None, n_steps=3)
 st = next(iter(den._plans.values()))
 plan = st['plan']
 ops = list(plan._arr)
-PRO = {0: '-', 1: 'silu', 2: 'gn', 3: 'gn_silu', 4: 'ln', 5: 'geglu'}
+PRO = {0: '-', 1: 'silu', 2: 'gn', 3: 'gn_silu', 4: 'ln', 5: 'geglu', 6: 'ln_attn'}
 
 
 def sig(op):
