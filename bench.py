@@ -303,15 +303,23 @@ def cpu_baseline_layout(net, obj_embed, triples, O, budget_s=15.0):
 
 
 def cpu_baseline(net, obj_embed, triples, O, full, df=None, uc=None):
-    """The CPU oracle on the box's host cores, SURVEY 8(d) protocol.  Round 5: the thread count is SWEPT over
-    {8, 16, 32, 64, all logical CPUs} -- a quick pass per count (layout: a bounded loop after a warm-up; shape: 1 warm-up + 1 timed DDIM
+    """The CPU oracle on the box's host cores, SURVEY 8(d) protocol.  Round 5: the thread count is SWEPT upwards over
+    {8, 16, 32, 64, all logical CPUs} until more threads are clearly worse (or 75 s are spent) -- a quick pass per count (layout: a bounded loop after a warm-up; shape: 1 warm-up + 1 timed DDIM
     step on 4 of the O objects) -- and the best count is then timed properly: shape = 1 warm-up + 2 timed DDIM steps on 8 objects, scaled
     by O / 8 (the per-object cost ratio O = 8 / O = 4 is recorded).  ``value`` / ``cores`` are those of the best thread count."""
     ncores = os.cpu_count() or torch.get_num_threads()
     default_threads = torch.get_num_threads()
     sweep = sorted({t for t in (8, 16, 32, 64, ncores) if t <= ncores} | {min(8, ncores)})
-    res = {}
+    key = 'full_steps_per_s_estimate' if full else 'layout_steps_per_s'
+    res, not_run = {}, []
+    t_sweep = time.perf_counter()
     for nt in sweep:
+        # the sweep ends as soon as more threads are clearly worse (torch's CPU kernels thrash beyond 16-32 threads on these hosts:
+        # 256 threads measured 0.001 steps/s, minutes per shape step) or its wall-clock budget is spent -- the default run of this
+        # script must finish within minutes on any box; the counts not run are listed
+        if res and (res[max(res)][key] < 0.7 * max(r[key] for r in res.values()) or time.perf_counter() - t_sweep > 75.0):
+            not_run.append(nt)
+            continue
         torch.set_num_threads(nt)
         v, n = cpu_baseline_layout(net, obj_embed, triples, O, budget_s=2.5 if full else 4.0)
         r = {'threads': nt, 'layout_steps_per_s': round(v, 3), 'layout_steps_timed': n}
@@ -320,7 +328,6 @@ def cpu_baseline(net, obj_embed, triples, O, full, df=None, uc=None):
             r['shape_s_per_step_O4_quick'] = round(ts, 3)
             r['full_steps_per_s_estimate'] = round(1.0 / (1.0 / v + ts * (O / 4)), 5)
         res[nt] = r
-    key = 'full_steps_per_s_estimate' if full else 'layout_steps_per_s'
     best = max(res.values(), key=lambda r: r[key])
     nt = best['threads']
     torch.set_num_threads(nt)
@@ -340,7 +347,8 @@ def cpu_baseline(net, obj_embed, triples, O, full, df=None, uc=None):
                      (('shape: 1 warm-up + 2 timed DDIM steps on %d of the %d objects, scaled x%d (cost is linear in objects); '
                        % (Os, O, O // Os)) if full else '') +
                      'torch-CPU oracle fp32 at the best thread count of the sweep below (by_threads: the quick pass per count)',
-           'measured_at_best': final, 'by_threads': [res[k] for k in sorted(res)]}
+           'measured_at_best': final, 'by_threads': [res[k] for k in sorted(res)],
+           'thread_counts_not_run': not_run}
     if full:
         out.update({'objects_timed': Os, 'objects_of_workload': O, 'extrapolated': True,
                     'extrapolation': 'shape step timed on %d objects and scaled x%d; SURVEY.md 8(d) probe of the reference itself at O = 32 on 8 '
