@@ -815,10 +815,10 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
                 has_ln = true;
             } else if (sg.pro == ES_PRO_LN_ATTN) {
                 // LayerNorm over a row formed from [t0 | u], two vectors and the cross-attention vector (echoscene_hip.h, es_seg.pro)
-                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && sg.gamma && sg.beta && sg.width <= 512 && sg.width % 16 == 0 &&
+                ES_REQUIRE(a.nseg == 1 && sg.mode == ES_SEG_DIRECT && !sg.gamma && !sg.beta && sg.width <= 512 && sg.width % 16 == 0 &&
                            sg.gs >= sg.width && sg.gs % 4 == 0 && a.res && a.res2 && a.res_nslab <= 1 && a.res2_nslab <= 1 &&
                            a.res_ld % 4 == 0 && a.res2_ld % 4 == 0 && !a.res_step,
-                           "es_linear_rows_f32: ES_PRO_LN_ATTN needs ONE direct segment of width <= 512, both vectors, u at gs >= width columns, "
+                           "es_linear_rows_f32: ES_PRO_LN_ATTN needs ONE direct segment of width <= 512, no affine vectors, u at gs >= width columns, "
                            "and plain res (output) / res2 (cross-attention vector) matrices");
                 has_ln = true; lnattn = true;
             } else if (sg.pro == ES_PRO_GEGLU) {

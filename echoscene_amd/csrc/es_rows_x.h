@@ -94,9 +94,10 @@ __device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // JW: bound of the k-blocks per wave and slice; NS: bound of the slab counts; PROC 0: raw / ReLU'd operands, 1: + GroupNorm(+SiLU),
 // 2: LayerNorm over the row (SLN = slices the row is cut into: the statistics need all of them); 3: LayerNorm over a row that is
 // FORMED here (ES_PRO_LN_ATTN, the one-token self-attention of a transformer block folded into its input projection, plan.py: the
-// producer wrote [t0 | u] with u = t0 W1^T through folded weights; the row is x = rstd(t0) (u - mean(t0) c) + b + t0 + cav, i.e.
-// attn1(LayerNorm1(t0)) + t0 + attn2 -- a dependent launch less per block; c / b arrive as the slice's gamma / beta vectors, cav as
-// the launch's res2, and the workgroups of column tile 0 publish x through the launch's res pointer); NT: column tiles per workgroup;
+// producer wrote [t0 | u] with u = W1 P t0 through folded weights, P = I - 11^T / C the mean subtraction of LayerNorm1 -- linear, so
+// it sits in the weights; the row is x = rstd(t0) u + t0 + cav, i.e. attn1(LayerNorm1(t0)) + t0 + attn2 with attn1's bias inside cav
+// -- a dependent launch less per block; cav arrives as the launch's res2, and the workgroups of column tile 0 publish x through the
+// launch's res pointer); NT: column tiles per workgroup;
 // NP: problems the launch may carry (1: single-problem launches read a 3x smaller argument block and skip the problem lookup).
 // GATHER: rows may be gathered through an index (a dependent round trip in front of the A loads: its own variants).
 template <int JW, int NS, int PROC, int SLN, int NT, bool GEGLU_EPI, int NP, bool GATHER = false>
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         }
     }
     // PROC 3: the other operands of the formed row -- u at the same rows, SL.gs columns behind t0 in the producer's output (same
-    // slabs); the cross-attention vector (the launch's res2: plain rows, one slab); c and b come through the gamma / beta loads below
+    // slabs); the cross-attention vector (the launch's res2: plain rows, one slab)
     f4 uv[PROC == 3 ? JW : 1][NS], cv[PROC == 3 ? JW : 1];
     if (PROC == 3) {
         const unsigned uo = (unsigned)SL.gs * 4u;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         for (int j = 0; j < JW; ++j) cv[j] = x_ld4(rC, co + vj[j], 0);
     }
     const bool aff = PROC >= 1 && PROC != 3 && SL.gamma != nullptr;     // NULL: the affine of the norm is folded into the weights (host)
-    if (PROC >= 1) {
+    if (PROC >= 1 && PROC != 3) {
         const __amdgpu_buffer_rsrc_t rG = x_rsrc_if(SL.gamma, (SL.flags & (2 | 8)) != 0), rB = x_rsrc_if(SL.beta, (SL.flags & (2 | 8)) != 0);
         const unsigned go = colw * 4u, gso = PROC == 2 ? (unsigned)(slice * SL.nkb) * 64u : 0u;
 #pragma unroll
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
 #pragma unroll
         for (int w = 0; w < NKG; ++w) tq += lnx[NKG * 16 + w * 16 + i16];
         const float rstd0 = __builtin_amdgcn_rsqf(tq * P.inv_k + SL.eps);
-        // x = rstd0 (u - mean0 c) + b + t0 + cav; column tile 0 publishes it (the feed-forward output product reads it as an operand)
+        // x = rstd0 u + t0 + cav; column tile 0 publishes it (the feed-forward output product reads it as an operand)
         const __amdgpu_buffer_rsrc_t rX = x_rsrc_if(P.res, bx == 0);
         const unsigned xo = ((unsigned)mc * (unsigned)P.res_ld + colw) * 4u;
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
             for (int u = 1; u < NS; ++u) uu += uv[j][u];
             f4 y = a[j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (((uu[e] - mean0 * gav[j][e]) * rstd0 + bev[j][e]) + y[e]) + cv[j][e];
+            for (int e = 0; e < 4; ++e) y[e] = (uu[e] * rstd0 + y[e]) + cv[j][e];
             a[j] = y;                                            // (blocks that do not exist: every operand is zero)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), rX, (int)((m < M && vj[j] != XOOB) ? xo + vj[j] : XOOB), 0, 0);
         }

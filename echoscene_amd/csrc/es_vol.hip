@@ -2653,11 +2653,9 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
 
 extern "C" int es_layernorm_tokens(const es_ln_args* a, es_stream stream) {
     ES_REQUIRE(a->C <= 1024 && a->C > 0 && a->C % 4 == 0, "es_layernorm_tokens: C=%d (a multiple of 4, max 1024)", a->C);
-    // resident waves loop over the rows: 8 workgroups of 4 waves per CU at most (timing-only switch ES_LN_WGS: workgroups of the launch)
-    static const char* ln_env = getenv("ES_LN_WGS");
+    // resident waves loop over the rows: 8 workgroups of 4 waves per CU at most
     long wgs = ((long)a->M + 3) / 4;
-    const long cap = ln_env && atoi(ln_env) > 0 ? atoi(ln_env) : 2048;
-    if (wgs > cap) wgs = cap;
+    if (wgs > 2048) wgs = 2048;
     hipLaunchKernelGGL(k_layernorm, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, *a);
     ES_CHECK_HIP(hipGetLastError());
     return 0;

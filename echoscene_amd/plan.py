@@ -25,9 +25,10 @@ ROWS_CAV_SLICES = 1      # cross-attention-vector product: 1 / 2 / 3 / 4 slices 
 ROWS_LN_SPLIT = 2        # slices of a product whose consumer is a LayerNorm (whole-row statistics): 1 -> 1067, 2 -> 1093
 ROWS_VO1_SLICES = 2      # attention-with-one-token product: 2 / 1 -> 1124 / 1122
 ROWS_SKIP_EARLY = False  # a ResBlock's skip projection on its first conv's launch: measured -1.1 %
-# Round 5 (second half): the one-token self-attention of a transformer block, t2 = vo1(LayerNorm1(t0)) + t0 + cav, is linear in t0 up to the
-# row statistics: vo1(LN1(t0)) = rstd (t0 W1^T - mean c) + b with c = the row sums of W1, and t0 W1^T = GN(x) (W1 Wp)^T + W1 bp comes out
-# of the input projection's OWN launch (weights [Wp ; W1 Wp], folded in fp64).  The feed-forward launch then forms t2 in its prologue
+# Round 5 (second half): the one-token self-attention of a transformer block, t2 = vo1(LayerNorm1(t0)) + t0 + cav, is linear in t0 up to ONE
+# row statistic: LayerNorm1's mean subtraction is the fixed projection P = I - 11^T / C, so vo1(LN1(t0)) = rstd(t0) (W1 P) t0 + b, and
+# u = (W1 P) t0 = GN(x) (W1 P Wp)^T + W1 P bp comes out of the input projection's OWN launch (weights [Wp ; W1 P Wp], folded in fp64; the
+# bias b joins the cross-attention vector's bias).  The feed-forward launch then forms t2 = rstd u + t0 + cav in its prologue
 # (ES_PRO_LN_ATTN) and the self-attention product is no launch of its own: 11 dependent launches less per layout step.
 ROWS_FOLD_ATTN1 = True
 # The head of the UNet1D trunk (conv_in ... the first transformer's proj_in: 9 dependent products that do not need the GCN output)
@@ -969,14 +970,17 @@ class UNet1DWeights:
                 d['ff1'] = PackedLinear(*fold_affine(sd[tb + '.ff.net.0.proj.weight'], sd[tb + '.ff.net.0.proj.bias'],
                                                      sd[tb + '.norm3.weight'], sd[tb + '.norm3.bias']), device, geglu=True)
                 if ROWS_FOLD_ATTN1 and it[1] <= 512 and it[1] % 16 == 0:
-                    # [t0 | u] = GN(x) [Wp ; W1 Wp]^T + [bp ; W1 bp]  and the two vectors of  t2 = rstd (u - mean c) + b + t0 + cav
+                    # [t0 | u] = GN(x) [Wp ; W1 P Wp]^T + [bp ; W1 P bp],  t2 = rstd(t0) u + t0 + (cav + b): W1 P = W1 with the mean of
+                    # every row removed; the bias b of the self-attention rides in the cross-attention vector's bias (below) --
+                    # a plan that keeps the self-attention launch for such a block (kernel family 0, the separate-GroupNorm route)
+                    # runs it without its own bias (d['a1_bias_in_cav'])
                     Wp64, bp64 = fold_affine64(centre_tap(sd[name + '.proj_in.weight']), sd[name + '.proj_in.bias'],
                                                sd[name + '.norm.weight'], sd[name + '.norm.bias'])
                     W164, b164 = fold_affine64(mm64(sd[tb + '.attn1.to_out.0.weight'], sd[tb + '.attn1.to_v.weight']),
                                                sd[tb + '.attn1.to_out.0.bias'], sd[tb + '.norm1.weight'], sd[tb + '.norm1.bias'])
-                    d['proj_in_u'] = PackedLinear(torch.cat([Wp64, mm64(W164, Wp64)], 0).float(), torch.cat([bp64, mm64(W164, bp64)], 0).float(), device)
-                    d['a1_c'] = own(W164.sum(dim=1), device)
-                    d['a1_b'] = own(b164, device)
+                    W1P = W164 - W164.mean(dim=1, keepdim=True)
+                    d['proj_in_u'] = PackedLinear(torch.cat([Wp64, mm64(W1P, Wp64)], 0).float(), torch.cat([bp64, mm64(W1P, bp64)], 0).float(), device)
+                    d['a1_bias_in_cav'] = b164
                 # x_out = proj_out(ff2(g) + b2 + t2) + x_in is linear in (g, t2): ONE op over the K-concatenation [g | t2] with
                 # [Wpo.Wff2 | Wpo] (folded in fp64) -- one dependent launch less per transformer block
                 Wpo = centre_tap(sd[name + '.proj_out.weight']).double()
@@ -988,7 +992,8 @@ class UNet1DWeights:
                 # [C x ctx_dim] matrix per block (fp64): all blocks' vectors are ONE product per step
                 self.ca[name] = (len(ca_v), it[1])
                 ca_v.append(mm64(sd[tb + '.attn2.to_out.0.weight'], sd[tb + '.attn2.to_v.weight']).float())
-                ca_b.append(sd[tb + '.attn2.to_out.0.bias'])
+                ca_b.append(sd[tb + '.attn2.to_out.0.bias'] if 'a1_bias_in_cav' not in d else
+                            (sd[tb + '.attn2.to_out.0.bias'].detach().double().to(d['a1_bias_in_cav'].device) + d['a1_bias_in_cav']).float())
             elif kind == 'down':
                 d['conv'] = P(name + '.op.weight', name + '.op.bias')
             elif kind == 'up':
@@ -1152,8 +1157,7 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
                     # the feed-forward launch forms t2 = attn1(norm1(t0)) + t0 + attn2 in its prologue and publishes it (ES_PRO_LN_ATTN)
                     t2 = View(b.buf(O, C, scratch=True))
                     n_ops, acct = len(b.ops), (b.weight_bytes, b.flops)
-                    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, gamma=d['a1_c'], beta=d['a1_b'], eps=1e-5, gs=C)], d['ff1'], O,
-                                  res=t2, res2=cavo[name])
+                    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, eps=1e-5, gs=C)], d['ff1'], O, res=t2, res2=cavo[name])
                     if hip.lib().es_linear_rows_takes_ln_attn(_byref(b.ops[-1].u.linear)) != 1:
                         del b.ops[n_ops:]            # (no kernel for this shape: the self-attention product stays a launch of its own)
                         b.weight_bytes, b.flops = acct
@@ -1172,7 +1176,7 @@ def _trunk(b, w, O, x, emb_all, emb_ld, box, eps_out):
                 # to_out2(to_v2(ctx)) (precomputed above) -> second residual of the same op.
                 vs_ = ROWS_VO1_SLICES
                 t2 = b.linear([seg(t0, pro=hip.PRO_LN, gamma=d['ln1'][0], beta=d['ln1'][1], eps=1e-5, gs=C)], d['vo1'], O,
-                              res=t0, res2=cavo[name],
+                              res=t0, res2=cavo[name], use_bias='a1_bias_in_cav' not in d,      # (else: the bias already sits in cavo)
                               split=(False if vs_ <= 1 else max(8, ((C + 15) // 16 + vs_ - 1) // vs_)))
                 yield
                 b.tags[name + '.transformer_blocks.0:in'] = t0

@@ -75,12 +75,13 @@ typedef struct es_seg {
     /* per-segment prologue (the op-level `prologue` below is shorthand for the same prologue on every segment):
      * ES_PRO_GN / GN_SILU: GroupNorm over THIS segment in groups of `gs` channels (4..32, power of two), affine gamma/beta
      * [width]; ES_PRO_LN: LayerNorm over the segment (must be the only one); ES_PRO_SILU; ES_PRO_GEGLU.             
-     * ES_PRO_LN_ATTN (round 5; the only segment, direct, launches the library routes to its register-operand kernel -- ask
-     * es_linear_rows_takes_ln_attn()): LayerNorm over a row that the launch FORMS first from the producer's output [t0 | u]
-     * (u = `gs` columns behind the segment's pointer, same slabs): x = rstd(t0) * (u - mean(t0) * gamma) + beta + t0 + res2, with
-     * gamma / beta the two vectors of the folded one-token self-attention (plan.py, attention.py:172-219 on one token) and res2 the
-     * cross-attention vector -- i.e. x = attn1(norm1(t0)) + t0 + attn2(norm2(.), ctx).  The launch's `res` is then an OUTPUT: x is
-     * written there ([M, res_ld], by the workgroups of column tile 0) and neither res nor res2 is added in the epilogue.          */
+     * ES_PRO_LN_ATTN (round 5; the only segment, direct, gamma = beta = NULL, launches the library routes to its register-operand
+     * kernel -- ask es_linear_rows_takes_ln_attn()): LayerNorm over a row that the launch FORMS first from the producer's output
+     * [t0 | u] (u = `gs` columns behind the segment's pointer, same slabs): x = rstd(t0) * u + t0 + res2, where u = W1 P t0 was
+     * produced through folded weights (W1: the one-token self-attention's matrix with LayerNorm1's affine, P = I - 11^T / C its mean
+     * subtraction: plan.py, attention.py:172-219 on one token) and res2 is the cross-attention vector plus the self-attention's
+     * bias -- i.e. x = attn1(norm1(t0)) + t0 + attn2(norm2(.), ctx).  The launch's `res` is then an OUTPUT: x is written there
+     * ([M, res_ld], by the workgroups of column tile 0) and neither res nor res2 is added in the epilogue.                          */
     int32_t pro;
     const float* gamma; const float* beta;
     float eps;

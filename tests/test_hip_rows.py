@@ -556,11 +556,10 @@ def test_linear_split_k_slab_chain_and_rowsel(dev):
 
 @pytest.mark.parametrize('C,M', [(512, 32), (128, 8), (256, 45)])
 def test_rows_formed_row_layernorm_prologue(dev, C, M):
-    """ES_PRO_LN_ATTN (round 5): the launch forms x = rstd(t0) (u - mean(t0) c) + b + t0 + cav from the producer's [t0 | u] slab
-    tensor, publishes it through ``res`` and multiplies LayerNorm(x) by a GEGLU projection -- against the unfolded arithmetic
-    x = LN(t0) W1^T + b + t0 + cav in float64 (attention.py:172-219 on one token), incl. a row tile with rows past M and a row
-    and rows
-    whose mean is large against their spread (the cancellation the fold introduces)."""
+    """ES_PRO_LN_ATTN (round 5): the launch forms x = rstd(t0) u + t0 + cav from the producer's [t0 | u] slab tensor (u = W1 P t0
+    through folded weights, P = LayerNorm's mean subtraction), publishes it through ``res`` and multiplies LayerNorm(x) by a GEGLU
+    projection -- against the unfolded arithmetic x = LN(t0) W1^T + b + t0 + cav in float64 (attention.py:172-219 on one token), incl.
+    a row tile with rows past M and rows whose mean is large against their spread."""
     from echoscene_amd import hip
     from echoscene_amd.plan import Builder, PackedLinear, View, seg
     import ctypes
@@ -571,18 +570,17 @@ def test_rows_formed_row_layernorm_prologue(dev, C, M):
     W1, b1 = f(C, C) / np.sqrt(C), 0.1 * f(C)
     Wg, bg = f(8 * C, C) / np.sqrt(C), 0.1 * f(8 * C)
     cav = f(M, C)
-    Wu = (W1.double() @ Wp.double())
-    bu = (W1.double() @ bp.double())
+    W1P = W1.double() - W1.double().mean(dim=1, keepdim=True)
     b = Builder(dev)
     x = b.dev(Xin)
-    t0u = b.linear([seg(View(x))], PackedLinear(torch.cat([Wp.double(), Wu], 0).float(), torch.cat([bp.double(), bu], 0).float(), dev), M,
+    t0u = b.linear([seg(View(x))], PackedLinear(torch.cat([Wp.double(), W1P @ Wp.double()], 0).float(),
+                                                torch.cat([bp.double(), W1P @ bp.double()], 0).float(), dev), M,
                    split=max(8, (C // 16 + 1) // 2))
     assert t0u.nslab <= 2
     t0 = t0u.cols(0, C)
     t2 = View(b.buf(M, C, zero=True))
-    cv = b.dev(cav)
-    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, gamma=b.dev(W1.double().sum(1).float()), beta=b.dev(b1), eps=1e-5, gs=C)],
-                  PackedLinear(Wg, bg, dev, geglu=True), M, res=t2, res2=View(cv))
+    cv = b.dev(cav + b1)                                     # (the self-attention's bias rides in the cross-attention vector)
+    gl = b.linear([seg(t0, pro=hip.PRO_LN_ATTN, eps=1e-5, gs=C)], PackedLinear(Wg, bg, dev, geglu=True), M, res=t2, res2=View(cv))
     assert hip.lib().es_linear_rows_takes_ln_attn(ctypes.byref(b.ops[-1].u.linear)) == 1
     b.finish().run()
     torch.cuda.synchronize()

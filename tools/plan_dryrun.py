@@ -50,8 +50,6 @@ def _linear_io(a, hip):
         sg = a.seg[0]
         for j in range(max(sg.nslab, 1)):
             reads.append(((sg.ptr or 0) + 4 * (j * sg.slab_stride + sg.gs), 4 * (sg.ld * (a.M - 1) + sg.width), False))
-        for v in (sg.gamma, sg.beta):
-            reads.append((v, 4 * sg.width, False))
     for ptr, ld, ns, ss in ((None if ln_attn else a.res, a.res_ld, a.res_nslab, a.res_slab_stride), (a.res2, a.res2_ld, a.res2_nslab, a.res2_slab_stride)):
         if ptr:
             for j in range(max(ns, 1)):
