@@ -91,6 +91,46 @@ __device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
+// Row statistics in ONE workgroup round (PROC 3; the two-round form -- mean, barrier, centred squares, barrier -- costs 1.1 us per
+// LayerNorm in the stamp timelines, r05b_rows_stamps_fold.txt): every wave reduces its own blocks about its own pivot p_w (its local
+// mean), publishes (S_w, Q_w) = (sum, sum of squares about p_w), and every thread combines the eight pairs with the identity that
+// holds for ANY pivot:  sum (x - mu)^2 = Q_w - 2 (mu - p_w) (S_w - n_w p_w) + n_w (mu - p_w)^2.  Fixed order over the waves.
+// a: the wave's blocks (absent blocks are zeros), nb = its number of existing blocks (<= NB), Jw / nkb: blocks per wave / of the row.
+template <int NB>
+__device__ __forceinline__ void x_row_stats(const f4 (&a)[NB], int nb, int Jw, int nkb, float inv_k, float eps, float* buf, int wave, int i16,
+                                            int q, float& mean, float& rstd) {
+    float sm = 0.f;
+#pragma unroll
+    for (int v = 0; v < NB; ++v) sm += (a[v][0] + a[v][1]) + (a[v][2] + a[v][3]);
+    sm = quad_sum(sm);
+    const float pw = nb > 0 ? sm * __builtin_amdgcn_rcpf(16.0f * (float)nb) : 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+        const float mv = v < nb ? pw : 0.f;                        // (an absent block holds zeros: against a zero pivot it adds exact zeros)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mv; sq += d * d; }
+    }
+    sq = quad_sum(sq);
+    if (q == 0) { buf[wave * 16 + i16] = sm; buf[NKG * 16 + wave * 16 + i16] = sq; }
+    __syncthreads();
+    float S[NKG], Q[NKG], tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKG; ++w) { S[w] = buf[w * 16 + i16]; Q[w] = buf[NKG * 16 + w * 16 + i16]; tot += S[w]; }
+    mean = tot * inv_k;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKG; ++w) {
+        int nbw = nkb - w * Jw;
+        nbw = nbw < 0 ? 0 : nbw > Jw ? Jw : nbw;
+        const float n = 16.0f * (float)nbw;
+        const float p = nbw > 0 ? S[w] * __builtin_amdgcn_rcpf(n) : 0.f;      // (the pivot the wave used: same inputs, same bits)
+        const float d = mean - p;
+        m2 += (Q[w] - 2.0f * d * (S[w] - n * p)) + n * d * d;
+    }
+    rstd = __builtin_amdgcn_rsqf(fmaxf(m2, 0.f) * inv_k + eps);
+}
+
 // JW: bound of the k-blocks per wave and slice; NS: bound of the slab counts; PROC 0: raw / ReLU'd operands, 1: + GroupNorm(+SiLU),
 // 2: LayerNorm over the row (SLN = slices the row is cut into: the statistics need all of them); 3: LayerNorm over a row that is
 // FORMED here (ES_PRO_LN_ATTN, the one-token self-attention of a transformer block folded into its input projection, plan.py: the
@@ -103,7 +143,7 @@ __device__ __forceinline__ float x_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 template <int JW, int NS, int PROC, int SLN, int NT, bool GEGLU_EPI, int NP, bool GATHER = false>
 __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
     __shared__ __attribute__((aligned(16))) float red[NT * NKG * 256];
-    __shared__ float lnx[PROC >= 2 ? 2 * NKG * 16 : 1];
+    __shared__ float lnx[PROC == 2 ? 2 * NKG * 16 : PROC == 3 ? 4 * NKG * 16 : 1];     // (PROC 3: one buffer per statistics round)
     static_assert(PROC == 2 || SLN == 1, "k_rows_x: only LayerNorm reads foreign slices");
 #ifdef ES_STAMP
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -154,7 +194,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < (PROC == 3 ? 5 : PROC == 2 ? 3 : 1); ++i) __syncthreads();
+        for (int i = 0; i < (PROC >= 2 ? 3 : 1); ++i) __syncthreads();
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink));
         return;
     }
@@ -292,31 +332,14 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         for (int j = 0; j < JW; ++j) if (j < Jw && j < nj) a[j] = o[j];      // (a[] stayed raw for the partner block of a 32-channel group)
     }
     if (PROC == 3) {
-        // statistics of the t0 row (LayerNorm 1 of the block: its affine sits in u's weights), exactly as the LayerNorm below forms them
-        float sm = 0.f;
-#pragma unroll
-        for (int v = 0; v < NB; ++v) sm += (a[v][0] + a[v][1]) + (a[v][2] + a[v][3]);
-        sm = quad_sum(sm);
-        if (q == 0) lnx[wave * 16 + i16] = sm;
-        __syncthreads();
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < NKG; ++w) tot += lnx[w * 16 + i16];
-        const float mean0 = tot * P.inv_k;
-        float sq = 0.f;
-#pragma unroll
-        for (int v = 0; v < NB; ++v) {
-            const float mv = (v < Jw && v < nj) ? mean0 : 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = a[v][e] - mv; sq += d * d; }
-        }
-        sq = quad_sum(sq);
-        if (q == 0) lnx[NKG * 16 + wave * 16 + i16] = sq;
-        __syncthreads();
-        float tq = 0.f;
-#pragma unroll
-        for (int w = 0; w < NKG; ++w) tq += lnx[NKG * 16 + w * 16 + i16];
-        const float rstd0 = __builtin_amdgcn_rsqf(tq * P.inv_k + SL.eps);
+        // statistics of the t0 row (LayerNorm 1 of the block: its affine and mean subtraction sit in u's weights): one round
+        const int nbv = nj < 0 ? 0 : nj > Jw ? Jw : nj;
+        float mean0, rstd0;
+        x_row_stats<NB>(a, nbv, Jw, SL.nkb, P.inv_k, SL.eps, lnx, wave, i16, q, mean0, rstd0);
+        (void)mean0;
+#if defined(ES_STAMP) && ES_STAMP_P3 == 1
+        ES_RSTAMP(3);                              // (instrumented builds: where the prologue of this variant spends its time)
+#endif
         // x = rstd0 u + t0 + cav; column tile 0 publishes it (the feed-forward output product reads it as an operand)
         const __amdgpu_buffer_rsrc_t rX = x_rsrc_if(P.res, bx == 0);
         const unsigned xo = ((unsigned)mc * (unsigned)P.res_ld + colw) * 4u;
@@ -331,9 +354,17 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
             a[j] = y;                                            // (blocks that do not exist: every operand is zero)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), rX, (int)((m < M && vj[j] != XOOB) ? xo + vj[j] : XOOB), 0, 0);
         }
+#if defined(ES_STAMP) && ES_STAMP_P3 == 2
+        ES_RSTAMP(3);
+#endif
     }
     if (PROC >= 2) {
         // LayerNorm over the whole row: the 8 waves hold all k-blocks of the row between them
+        float mean, rstd;
+        if (PROC == 3) {
+            const int nbv = nj < 0 ? 0 : nj > Jw ? Jw : nj;
+            x_row_stats<NB>(a, nbv, Jw, SL.nkb, P.inv_k, SL.eps, lnx + 2 * NKG * 16, wave, i16, q, mean, rstd);
+        } else {
         float sm = 0.f;
 #pragma unroll
         for (int v = 0; v < NB; ++v) sm += (a[v][0] + a[v][1]) + (a[v][2] + a[v][3]);      // (blocks that do not exist are zeros)
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
 #pragma unroll
         for (int w = 0; w < NKG; ++w) tot += lnx[w * 16 + i16];
         const float inv_k = P.inv_k;
-        const float mean = tot * inv_k;
+        mean = tot * inv_k;
         float sq = 0.f;
 #pragma unroll
         for (int v = 0; v < NB; ++v) {
@@ -360,7 +391,8 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         float tq = 0.f;
 #pragma unroll
         for (int w = 0; w < NKG; ++w) tq += lnx[NKG * 16 + w * 16 + i16];
-        const float rstd = __builtin_amdgcn_rsqf(tq * inv_k + SL.eps);
+        rstd = __builtin_amdgcn_rsqf(tq * inv_k + SL.eps);
+        }
         // the own slice's blocks, normalised, move to a[0 .. JW)
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
@@ -404,7 +436,11 @@ __global__ __launch_bounds__(NTHREAD + 64) void k_rows_x(const XLaunch<NP> L) {
         }
         e_bias = x_ld1(x_rsrc_if(P.bias, first), tid < 256 * NT && n_e < N ? (unsigned)n_e * 4u : XOOB, 0);
     }
+#if !defined(ES_STAMP) || !defined(ES_STAMP_P3) || ES_STAMP_P3 == 0
     ES_RSTAMP(3);
+#else
+    if (PROC != 3) ES_RSTAMP(3);
+#endif
 
     // (5) products: two accumulators (even / odd k-steps), combined once
     f4 acc[NT];
