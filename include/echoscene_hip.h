@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 8
+#define ES_ABI_VERSION 9
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(L):
     for name in sorted(declared):
         assert hasattr(raw, name), 'libechoscene_hip.so lacks %s' % name
     assert declared == set(hip.EXPORTS), 'ctypes table and header disagree: %s' % (declared ^ set(hip.EXPORTS))
-    assert L.es_abi_version() == 8
+    assert L.es_abi_version() == 9
 
 
 def test_struct_sizes_match_header(L, tmp_path):
