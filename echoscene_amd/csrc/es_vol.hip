@@ -83,12 +83,19 @@ __device__ __forceinline__ void gn_reduce_stats(const es_gn_args& a, const float
     const int gi = threadIdx.x % a.groups, sl = threadIdx.x / a.groups, nsl = 256 / a.groups;
     double s = 0.0, q = 0.0;
     if (sl < nsl) {
-        // four partials in flight per thread, added in tile order (the bits of the plain loop: round 5 -- with one dependent L2 round
-        // trip per tile the 128-tile lists of a few-objects launch made this prologue most of k_gn_apply's 10 us)
+        // sixteen partials in flight per thread, added in tile order (the bits of the plain loop: round 5 -- with one dependent L2 round
+        // trip per tile the 128-tile lists of a few-objects launch made this prologue most of k_gn_apply's 10 us; four in flight: 8.3 us)
         typedef float f2g __attribute__((ext_vector_type(2)));
         const f2g* pp = (const f2g*)part + ((long)o * ntiles * a.groups + gi);
         const long st = (long)nsl * a.groups;
         int t = sl;
+        for (; t + 15 * nsl < ntiles; t += 16 * nsl) {
+            f2g p[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p[k] = pp[(long)t * a.groups + k * st];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { s += p[k][0]; q += p[k][1]; }
+        }
         for (; t + 3 * nsl < ntiles; t += 4 * nsl) {
             const f2g p0 = pp[(long)t * a.groups], p1 = pp[(long)t * a.groups + st], p2 = pp[(long)t * a.groups + 2 * st], p3 = pp[(long)t * a.groups + 3 * st];
             s += p0[0]; q += p0[1]; s += p1[0]; q += p1[1]; s += p2[0]; q += p2[1]; s += p3[0]; q += p3[1];
