@@ -97,3 +97,47 @@ def test_other_planner_constants_keep_the_order_valid(monkeypatch, consts):
     dry, b = _emit(monkeypatch, 2, mc=128, O=8)
     n, problems = dry.check(b)
     assert problems == [], problems
+
+
+def test_self_attention_fold_and_its_fallbacks(monkeypatch):
+    """Round 5: the one-token self-attention of a transformer block is folded into its input projection where the library has the
+    kernel (ES_PRO_LN_ATTN: model_channels <= 512) -- one launch less per block, the dependency check still green (the launch's
+    ``res`` is an OUTPUT there: tools/plan_dryrun.py knows) -- and stays a launch of its own elsewhere (model_channels 1024, the
+    planner constant off)."""
+    from echoscene_amd import hip, plan
+    counts = {}
+    for mc, fold in ((128, True), (128, False), (1024, True)):
+        monkeypatch.setattr(plan, 'ROWS_FOLD_ATTN1', fold)
+        dry, b = _emit(monkeypatch, 2, mc=mc, O=8)
+        n, problems = dry.check(b)
+        assert problems == [], problems
+        lin = [op.u.linear for op in b.ops if op.kind == hip.OP_LINEAR]
+        n_attn = sum(1 for a in lin if a.seg[0].pro == hip.PRO_LN_ATTN)
+        n_ln = sum(1 for a in lin if a.seg[0].pro == hip.PRO_LN)
+        counts[(mc, fold)] = (n, n_attn, n_ln)
+        for a in lin:
+            if a.seg[0].pro == hip.PRO_LN_ATTN:
+                assert a.nseg == 1 and a.res and a.res2 and not a.seg[0].gamma and not a.seg[0].beta and a.seg[0].gs == a.K
+                assert hip.lib().es_linear_rows_takes_ln_attn(__import__('ctypes').byref(a)) == 1
+    (n1, a1, l1), (n0, a0, l0), (nb, ab, lb) = counts[(128, True)], counts[(128, False)], counts[(1024, True)]
+    assert a1 == 11 and l1 == 0 and a0 == 0 and l0 == 22 and n0 - n1 == 11, counts
+    assert ab == 0 and lb == 22, counts                      # K = 1024: 8 k-blocks per wave, no formed-row kernel -> not folded
+
+
+def test_groupnorm_widths_outside_the_register_prologue_are_separate_launches(monkeypatch):
+    """model_channels = 384 (GroupNorm groups of 12 / 24 / 36 channels; reference: any channels % 32 == 0): the norms are OP_GN
+    launches over whole matrices, no rows product carries a GroupNorm prologue or a K split, nothing rides or is folded."""
+    from echoscene_amd import hip, plan
+    assert plan.rows_gn_in_registers(512) and plan.rows_gn_in_registers(1024) and plan.rows_gn_in_registers(128)
+    assert not plan.rows_gn_in_registers(384) and not plan.rows_gn_in_registers(768) and not plan.rows_gn_in_registers(1152)
+    for concat in (False, True):
+        dry, b = _emit(monkeypatch, 2, mc=384, O=8, concat=concat)
+        n, problems = dry.check(b)
+        assert problems == [], problems
+        assert sum(1 for op in b.ops if op.kind == hip.OP_GN) >= 34
+        for op in b.ops:
+            if op.kind == hip.OP_LINEAR:
+                a = op.u.linear
+                assert a.kb_per_slice == 0                                   # no K-split slab outputs anywhere in this plan
+                for s in range(a.nseg):
+                    assert a.seg[s].pro not in (hip.PRO_GN, hip.PRO_GN_SILU, hip.PRO_LN_ATTN)
