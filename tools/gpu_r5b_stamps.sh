@@ -1,6 +1,7 @@
 #!/bin/bash
 # where the formed-row (ES_PRO_LN_ATTN) launch spends its prologue: three instrumented builds, stamp 3 after the LayerNorm (0), after the
-# statistics of t0 (1), after the row is formed (2)
+# statistics of t0 (1), after the row is formed (2).  Build them in the container first (they travel with the snapshot):
+#   for v in 0 1 2; do ES_BUILD_TAG=_stamp$v ES_BUILD_FLAGS="-DES_STAMP -DES_STAMP_P3=$v" python -m echoscene_amd.build --force; done
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5b_stamps}
