@@ -141,3 +141,59 @@ def test_groupnorm_widths_outside_the_register_prologue_are_separate_launches(mo
                 assert a.kb_per_slice == 0                                   # no K-split slab outputs anywhere in this plan
                 for s in range(a.nseg):
                     assert a.seg[s].pro not in (hip.PRO_GN, hip.PRO_GN_SILU, hip.PRO_LN_ATTN)
+
+
+def _unpack(pl):
+    """[N, K] matrix of a PackedLinear's MFMA-fragment image (es_pack_linear_f32: ((n tile, k block), lane, 4) with
+    n = 16 nt + lane % 16, k = 16 kb + 4 (lane / 16) + e)"""
+    import torch
+    NT, KB = (pl.N + 15) // 16, (pl.K + 15) // 16
+    img = pl.w.detach().cpu().reshape(NT, KB, 4, 16, 4)                  # [nt, kb, q, j, e]
+    W = img.permute(0, 3, 1, 2, 4).reshape(NT * 16, KB * 16)             # [(nt, j), (kb, q, e)]
+    return W[:pl.N, :pl.K].double()
+
+
+def test_self_attention_fold_weights_reproduce_the_block_on_the_host():
+    """The host half of the fold, without a GPU: with the folded weight images the planner builds -- [Wp ; W1 P Wp] for the input
+    projection (GroupNorm affine inside), the cross-attention vector's matrix with the self-attention's bias in its bias --
+    t2 = rstd(t0) u + t0 + cav, evaluated in float64 from the oracle's own block input and GCN output, is the oracle's
+    attn1(norm1(t0)) + t0 + attn2(norm2(.), ctx) (attention.py:237-245 on one token) at every transformer block of the tiny denoiser."""
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from conftest import load_golden
+    from echoscene_amd import synth, config as escfg, plan
+    from echoscene_amd.model.unet import UNet1DModel
+    from echoscene_amd.samplers import _cpu_sd
+    from oracle import echoscene_oracle as orc
+    assert plan.ROWS_FOLD_ATTN1
+    g = load_golden('unet1d_tiny')
+    kw = dict(escfg.layout_denoiser_kwargs(128))
+    kw['concat_dim'] = kw['crossattn_dim'] = 128
+    net = UNet1DModel(**kw)
+    synth.seeded_fill_(net, prefix='unet1d_tiny.')
+    sd = _cpu_sd(net)
+    w = plan.UNet1DWeights(sd, net, torch.device('cpu'))
+    trace = {}
+    orc.unet1d_forward({k: v for k, v in sd.items()}, g['box'], g['obj_embed'], g['triples'], g['t'], trace=trace)
+    ctx = trace['ctx'].double().reshape(g['box'].shape[0], -1)
+    Wc, bc = _unpack(w.cav_all), w.cav_all.b.double()
+    cav_all = ctx @ Wc.t() + bc
+    n_blocks = 0
+    for name, (k, C) in w.ca.items():
+        d = w.items[name]
+        assert 'proj_in_u' in d and d['proj_in_u'].N == 2 * C
+        pre, idx = name.rsplit('.', 1)
+        xin = trace['%s.%d' % (pre, int(idx) - 1)].double().reshape(-1, C)              # the ResBlock in front of the transformer
+        xn = F.group_norm(xin.unsqueeze(-1), 32, None, None, 1e-6).squeeze(-1)          # (the affine sits in the weights)
+        t0u = xn @ _unpack(d['proj_in_u']).t() + d['proj_in_u'].b.double()
+        t0, u = t0u[:, :C], t0u[:, C:]
+        rstd = 1.0 / torch.sqrt(t0.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
+        off = sum(c for n2, (k2, c) in w.ca.items() if k2 < k)
+        t2 = rstd * u + t0 + cav_all[:, off:off + C]
+        tb = name + '.transformer_blocks.0'
+        ref0, ref2 = trace[tb + ':in'].double().reshape(-1, C), trace[tb + ':attn2'].double().reshape(-1, C)
+        assert (t0 - ref0).abs().max() < 2e-5 * max(1.0, float(ref0.abs().max())), name
+        assert (t2 - ref2).abs().max() < 5e-5 * max(1.0, float(ref2.abs().max())), (name, float((t2 - ref2).abs().max()))
+        n_blocks += 1
+    assert n_blocks == 11
