@@ -50,10 +50,14 @@ def _linear_io(a, hip):
         sg = a.seg[0]
         for j in range(max(sg.nslab, 1)):
             reads.append(((sg.ptr or 0) + 4 * (j * sg.slab_stride + sg.gs), 4 * (sg.ld * (a.M - 1) + sg.width), False))
+    # (ES_PRO_LN_ATTN: res2 is an operand of the prologue, as wide as the segment -- with the launch's N = 8 C here the range ran
+    #  past the end of the cross-attention vectors and, depending on where the allocator had put the next buffer, into a tensor a
+    #  later launch writes: a spurious finding about once in three full test runs)
+    rw = a.seg[0].width if ln_attn else a.N
     for ptr, ld, ns, ss in ((None if ln_attn else a.res, a.res_ld, a.res_nslab, a.res_slab_stride), (a.res2, a.res2_ld, a.res2_nslab, a.res2_slab_stride)):
         if ptr:
             for j in range(max(ns, 1)):
-                reads.append((ptr + 4 * j * ss, 4 * (ld * (a.M - 1) + a.N), False))
+                reads.append((ptr + 4 * j * ss, 4 * (ld * (a.M - 1) + rw), False))
     Nout = a.N // 2 if a.act == hip.ACT_GEGLU else a.N
     S = 1
     if a.kb_per_slice > 0:
