@@ -386,11 +386,29 @@ def main():
                          'JSON line ("check"): with --deterministic the N-rank run must reproduce the 1-rank CRC bit for bit')
     a = ap.parse_args()
 
+    backend = os.environ.get('ES_DIST_BACKEND', 'nccl')     # 'gloo' only for single-GPU multi-rank smoke tests
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` (the documented contract, line 4 of this file): launched without a rendezvous environment, so this
+        # process becomes the launcher -- one rank per GPU under torch.distributed.run on the loopback address, same arguments.  (Until
+        # round 5 --gpus was parsed and never read: the plain-python form silently ran ONE rank and printed n_gpus 1.)
+        ndev = torch.cuda.device_count()
+        if backend == 'nccl' and ndev < a.gpus:
+            sys.exit('bench.py: --gpus %d asked for, %d visible device(s) (one rank per GPU over RCCL; ES_DIST_BACKEND=gloo lets several '
+                     'ranks share a device for smoke tests)' % (a.gpus, ndev))
+        import socket, subprocess
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus != world:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE is %d: launch `python bench.py --gpus N` (it starts the ranks itself) or '
+                 '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`' % (a.gpus, world))
     ndev = torch.cuda.device_count()
-    backend = os.environ.get('ES_DIST_BACKEND', 'nccl')     # 'gloo' only for single-GPU multi-rank smoke tests
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

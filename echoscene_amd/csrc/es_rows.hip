@@ -720,7 +720,15 @@ extern "C" int es_linear_rows_slices(const es_linear_args* a, int* kb_per_slice)
         int S = 0;
         for (int s = 0; s < a->nseg; ++s) {
             if (a->seg[s].width % 16) return -1;
-            const int kb = (a->seg_slices >> (1 + s)) & 1 ? (kbps + 1) / 2 : kbps;
+            const bool half = (a->seg_slices >> (1 + s)) & 1;
+            const int kb = half ? (kbps + 1) / 2 : kbps;
+            if (half) {
+                // a half-length slice of a GroupNorm segment must still hold whole groups (the kernel pairs k-blocks (j, j ^ 1) of a
+                // 32-channel group): -2 = misaligned (the planner checks the same before it sets the bit)
+                const int pro = a->seg[s].pro ? a->seg[s].pro : a->prologue;
+                const int gs = a->seg[s].gs ? a->seg[s].gs : a->K / 32;
+                if ((pro == ES_PRO_GN || pro == ES_PRO_GN_SILU) && kb % ((gs + 15) / 16) != 0) return -2;
+            }
             S += (a->seg[s].width / 16 + kb - 1) / kb;
         }
         return S;
@@ -836,6 +844,7 @@ int rows_prepare(const es_linear_args* a_in, RowsPrep* out) {
     ES_REQUIRE(a.act != ES_ACT_GEGLU || (a.N % 16 == 0 && (!a.res2 || lnattn)), "es_linear_rows_f32: GEGLU epilogue needs N %% 16 == 0");
     int kbps = 0;
     const int S = es_linear_rows_slices(&a, &kbps);
+    ES_REQUIRE(S != -2, "es_linear_rows_f32: a half-length slice (seg_slices bits 1..3, kb_per_slice=%d) would cut a GroupNorm group", a.kb_per_slice);
     ES_REQUIRE(S >= 1, "es_linear_rows_f32: segment-aligned slices need segment widths that are multiples of 16");
     ES_REQUIRE(S == 1 || (a.act == ES_ACT_NONE && nb == 1 && a.out_slab_stride >= a.M * a.out_ld),
                "es_linear_rows_f32: a K split (%d slices) needs no activation epilogue, no batching and out_slab_stride >= M * out_ld", S);
@@ -875,6 +884,19 @@ bool x_plan(const RowsPrep& p, XPlan* xp) {
         if (sg.step || sg.nslab > 6 || sg.width % 16) return false;
         if ((sg.pro == ES_PRO_GN || sg.pro == ES_PRO_GN_SILU) && sg.gs < 4) return false;
         koff += sg.width;
+    }
+    {
+        // k_rows_x addresses its operands with 32-bit byte offsets inside a 2 GiB buffer window: an operand whose extent
+        // reaches 2^31 bytes stays on k_linear_rows (64-bit pointers).  Gathered segments index node-level tables (a few thousand rows).
+        const long lim = (1L << 31) - 4096;
+        for (int s = 0; s < a.nseg; ++s) {
+            const es_seg& sg = a.seg[s];
+            const long rows = sg.mode == ES_SEG_DIRECT ? a.M : 0;
+            const long ext = (rows * sg.ld + sg.width) * 4 + (long)(sg.nslab > 1 ? sg.nslab - 1 : 0) * sg.slab_stride * 4;
+            if (ext >= lim) return false;
+        }
+        const long oext = ((long)a.M * a.out_ld + a.N) * 4;
+        if (oext >= lim || (a.res && ((long)a.M * a.res_ld + a.N) * 4 >= lim) || (a.res2 && ((long)a.M * a.res2_ld + a.N) * 4 >= lim)) return false;
     }
     const int nkb = a.K / 16;
     if (a.seg_slices) {
@@ -1237,15 +1259,19 @@ extern "C" int es_rows_set_kernel_family(int family) {
 
 extern "C" int es_linear_rows_f32(const es_linear_args* a_in, es_stream stream) {
     RowsPrep pr;
-    if (int rc = rows_prepare(a_in, &pr)) return rc;
-    return rows_launch(&pr, 1, stream);
+    if (int rc = rows_prepare(a_in, &pr)) { g_rows_next = nullptr; return rc; }
+    const int rc = rows_launch(&pr, 1, stream);
+    g_rows_next = nullptr;          // the hint lives for ONE launch call, whichever kernel took it (it points into the caller's plan)
+    return rc;
 }
 
 extern "C" int es_linear_rows_multi_f32(const es_linear_args* const* args, int n, es_stream stream) {
     ES_REQUIRE(args && n >= 1 && n <= 3, "es_linear_rows_multi_f32: n=%d (1..3)", n);
     RowsPrep pr[3];
-    for (int i = 0; i < n; ++i) if (int rc = rows_prepare(args[i], &pr[i])) return rc;
-    return rows_launch(pr, n, stream);
+    for (int i = 0; i < n; ++i) if (int rc = rows_prepare(args[i], &pr[i])) { g_rows_next = nullptr; return rc; }
+    const int rc = rows_launch(pr, n, stream);
+    g_rows_next = nullptr;
+    return rc;
 }
 
 extern "C" int es_row_select(const es_rowsel_args* a, es_stream stream) {

@@ -184,9 +184,10 @@ extern "C" int es_plan_run(es_plan* p, es_stream stream) {
                 continue;
             }
         }
-        if (int rc = dispatch(op, s)) return rc;
+        if (int rc = dispatch(op, s)) { es_rows_hint_next(nullptr); return rc; }
         if (dbg) ES_CHECK_HIP(hipStreamSynchronize(s));
     }
+    es_rows_hint_next(nullptr);      // (every rows launch call clears the hint itself; nothing of this plan may outlive the run)
     return 0;
 }
 

@@ -14,6 +14,8 @@ def descale_box_params(normed_box_params, file=None, angle=False, stats=None):
     assert file is not None or stats is not None
     ncol = 7 if angle else 6
     st = np.loadtxt(file) if stats is None else np.asarray(stats)
+    if st.size < (14 if angle else 12):
+        raise ValueError('descale_box_params: %d statistics given, %d needed%s' % (st.size, 14 if angle else 12, ' (angle=True reads entries 12, 13)' if angle else ''))
     x = normed_box_params
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] >= ncol and x.stride(1) == 1):
         raise ValueError('descale_box_params: expects a float32 CUDA tensor [O, >=%d]' % ncol)

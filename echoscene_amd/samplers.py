@@ -385,15 +385,22 @@ class ShapeDenoiser:
         if noise1 is None:
             noise1 = torch.randn((1,) + self.z_shape, device=self.device)
         st['x'].copy_(noise1.to(self.device).expand(st['hi'] - st['lo'], *self.z_shape))
-        if st.get('snoise') is not None:
+        if st.get('snoise') is not None or (self.ddim_eta != 0.0 and st.get('empty')):
             if step_noise is None and self.world > 1:
                 # one table for the WHOLE scene from this rank's generator, then this rank's objects: ranks seeded alike (as they
                 # must be for noise1) draw what the unsharded run draws -- a local normal_() gave every world size its own noise
-                per = st['snoise'].shape[1] // max(st['hi'] - st['lo'], 1) if st['hi'] > st['lo'] else 0
-                if per:
-                    full = torch.randn(self.S, st['O'], per, device=self.device)
+                # EVERY rank draws the table, also one that owns no object (more ranks than objects): a rank that skipped the draw left
+                # its generator behind the others', and the next call's noise1 differed between ranks.  One call for the
+                # whole table, as the unsharded run's normal_() -- a chunked draw is another Philox stream (transient: S*O*latent floats)
+                per = 1
+                for d in self.z_shape:
+                    per *= int(d)
+                full = torch.randn(self.S, st['O'], per, device=self.device)
+                if st['hi'] > st['lo']:
                     st['snoise'].copy_(full[:, st['lo']:st['hi']].reshape(self.S, -1))
-                    del full
+                del full
+            elif st.get('snoise') is None:
+                pass                                 # (an empty shard with a caller-given table: nothing to fill)
             elif step_noise is None:
                 st['snoise'].normal_()
             else:

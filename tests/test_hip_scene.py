@@ -583,3 +583,14 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
         assert d['check']['objects'] == 8
         crcs.append((d['check']['latents_crc32'], d['check']['abs_sum']))
     assert crcs[0] == crcs[1], 'the 2-rank sharded run does not reproduce the 1-rank latents: %s' % (crcs,)
+    # the plain-python form of the contract (`python bench.py --gpus N`, no rendezvous environment): bench.py starts the ranks itself
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['ES_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+           '--no-sub-records', '--nodes', '8', '--check']
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and (d['check']['latents_crc32'], d['check']['abs_sum']) == crcs[0]

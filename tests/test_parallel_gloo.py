@@ -177,3 +177,19 @@ def test_world_8_uneven_partition_with_partial_and_empty_shards(tmp_path):
         got = torch.load(out % r)
         assert (got['lo'], got['hi']) == shares[r]
         assert torch.equal(got['z'], z1), r
+
+
+def test_bench_gpus_flag_is_the_world_size():
+    """`python bench.py --gpus N` is the documented contract: without a rendezvous environment bench.py launches N ranks itself and
+    refuses when fewer than N devices are visible (here: none); inside a launched job --gpus must equal WORLD_SIZE.  (Until round 5
+    the flag was parsed and never read.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'ES_DIST_BACKEND')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '--gpus 2 asked for' in r.stderr, r.stderr[-800:]
+    env.update(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'WORLD_SIZE is 2' in r.stderr, r.stderr[-800:]
