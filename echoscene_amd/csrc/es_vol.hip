@@ -1153,11 +1153,23 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 
 // One (tile, K range) of k_conv_ws: producer / consumer roles, 3-slot ring, epilogue.  S > 1: the raw partial tile goes to slab bz of
 // a.workspace (split K / stream-K); S == 1: the final epilogue.  Every wave of the workgroup calls it with the same arguments.
-template <int BM_, int NC_, int NP_, bool UP_, int EPI_, bool STATS_>
+// counted wait of a producer wave that runs up to MAXA units of NL loads ahead of the unit it publishes
+template <int NL, int MAXA>
+__device__ __forceinline__ void wait_ahead(int ahead) {
+    if constexpr (MAXA > 0) {
+        if (ahead >= MAXA) { wait_vmcnt<MAXA * NL>(); return; }
+        wait_ahead<NL, MAXA - 1>(ahead);
+    } else {
+        wait_vmcnt<0>();
+    }
+}
+
+template <int BM_, int NC_, int NP_, bool UP_, int EPI_, bool STATS_, int NS_ = 3>
 __device__ __forceinline__ void conv_ws_tile(const es_conv_args& a, const ConvGeom& g, int ncdhw, char* smem, const int wave, const int lane,
                                              const long M, const int bx, const int by, const int ks_begin, const int ks_end,
                                              const int S, const int bz, unsigned long long* stamp) {
-    constexpr int NS = 3, UPS_ = 1;                               // ring depth; K units per barrier
+    constexpr int NS = NS_, UPS_ = 1;                             // ring depth (3; deeper for the small tiles of round 6, whose K units are
+                                                                  // bound by the landing latency of a unit / (NS - 1)); K units per barrier
     constexpr int WROWS = BM_ / (NC_ / 2);
     constexpr int MI = WROWS / 16;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, UNIT_BYTES = A_BYTES + B_BYTES;
@@ -1291,13 +1303,15 @@ __device__ __forceinline__ void conv_ws_tile(const es_conv_args& a, const ConvGe
                 if (issued < nloc) { issue_unit(base + u * UNIT_BYTES); ++issued; }
         };
         {
-            issue_stage(0);
-            if (nstage > 1) issue_stage(1);
+            static_assert(NLOAD * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+            for (int st = 0; st < NS - 1; ++st)
+                if (st < nstage) issue_stage(st);
             for (int st = 0; st < nstage; ++st) {
-                if (st + 1 < nstage) wait_vmcnt<NLOAD>(); else wait_vmcnt<0>();     // own pieces of unit st have landed
-                __builtin_amdgcn_s_barrier();        // unit st visible to the consumers; slot (st+2)%3 released by them
+                wait_ahead<NLOAD, NS - 2>(nstage - 1 - st);                      // own pieces of unit st have landed (up to NS - 2 later units in flight)
+                __builtin_amdgcn_s_barrier();        // unit st visible to the consumers; the slot of unit st - 1 released by them
                 if (st == 0) ES_STAMP_AT(2);
-                if (st + 2 < nstage) issue_stage(st + 2);
+                if (st + NS - 1 < nstage) issue_stage(st + NS - 1);
             }
         }
         ES_STAMP_AT(3);
@@ -1367,7 +1381,7 @@ __device__ __forceinline__ void conv_ws_tile(const es_conv_args& a, const ConvGe
     ES_STAMP_AT(4);
 }
 
-template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool STATS_ = false>
+template <int BM_, int NC_, int NP_, bool UP_ = false, int EPI_ = ES_EPI_NONE, bool STATS_ = false, int NS_ = 3>
 __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_args a, const ConvGeom g, int ncdhw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1383,7 +1397,280 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
     const int S = gridDim.z;
     int ks_begin, ks_end;
     split_range(a.taps * (a.Cin >> 5), a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz, S, ks_begin, ks_end);
-    conv_ws_tile<BM_, NC_, NP_, UP_, EPI_, STATS_>(a, g, ncdhw, smem, wave, lane, M, bx, by, ks_begin, ks_end, S, bz, stamp);
+    conv_ws_tile<BM_, NC_, NP_, UP_, EPI_, STATS_, NS_>(a, g, ncdhw, smem, wave, lane, M, bx, by, ks_begin, ks_end, S, bz, stamp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_kw (round 6): K split INSIDE a workgroup -- the small problems of the few-objects regime (a shard of 4 .. 16 objects, the
+// transformer linears of every level there, the 16x4x4 level at any object count).  Such a launch has fewer 256-row tiles than the
+// chip has CUs; until round 5 it kept the big tiles and split K over workgroups: every partial tile went to HBM as an fp32 slab and a
+// second launch (k_conv_splitk_reduce) read S slabs per output -- 2.9 of the 4.7 ms of a 4-object step were such round trips and
+// the lone K chains of the 64-row kernels (profiles/r05b_shard_emulation.txt).  Here a workgroup owns a 64 x (112 NCH_) tile -- enough
+// tiles to cover the CUs without a cross-workgroup split -- and its consumer waves are KS_ K STREAMS x NCH_ column halves:
+// stream s multiplies the s-th of KS_ contiguous K ranges (the cuts of split_range, i.e. exactly the ranges an S = KS_ split over
+// workgroups has) into its own 64 x 112 accumulator tile; the streams' tiles meet in LDS and are added in stream order, then the
+// ordinary epilogue (bias / per-object vector / residual / f16 copy / GEGLU) runs on the sum.  No slab, no reduction launch, a K chain
+// KS_ times shorter -- and the SAME BITS as a split of S = KS_ over workgroups followed by k_conv_splitk_reduce (same ranges, same
+// MFMA chains, same left fold, same epilogue order), which is what lets a bit-exact shard use it where the whole problem splits.
+// Roles: KS_ x NCH_ consumer waves (the 64 x 112 wave tile of k_conv_ws: 112 accumulators), 8 producer waves = 8 / KS_ per stream,
+// each stream with its own K-step generator; one barrier per STAGE = one K unit of every stream; 3-stage ring of KS_ x (4 KiB A +
+// NCH_ x 7 KiB B).  gridDim = (row tiles of 64, column tiles of 112 NCH_, S): a cross-workgroup split on top (S > 1) writes partial
+// slabs like every other conv kernel (virtual split index bz KS_ + s of S KS_).
+// ---------------------------------------------------------------------------------------------
+template <int KS_, int NCH_, bool UP_ = false, int EPI_ = ES_EPI_NONE>
+__global__ __launch_bounds__(64 * (KS_ * NCH_ + 8), 3) void k_conv_kw(const es_conv_args a, const ConvGeom g, int ncdhw) {
+    constexpr int BM_ = 64, NC_ = KS_ * NCH_, NP_ = 8, NPW = NP_ / KS_;            // producer waves per stream
+    static_assert(NC_ == 4 && (KS_ == 2 || KS_ == 4), "4 consumer waves: 4 streams x 1 column half or 2 streams x 2");
+    constexpr int NS = 3;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = NCH_ * 112 * BK * 2, UNIT_BYTES = A_BYTES + B_BYTES, STAGE_BYTES = KS_ * UNIT_BYTES;
+    constexpr int APIECES = BM_ / 16, BPIECES = NCH_ * 7, NPIECE = APIECES + BPIECES;
+    constexpr int JA = APIECES / NPW, JMAX = (NPIECE + NPW - 1) / NPW;              // pieces j < JA of a producer wave are A pieces
+    static_assert(APIECES % NPW == 0, "A pieces must divide over a stream's producer waves");
+    constexpr int PART_FLOATS = 112 * 64;                                         // one consumer wave's accumulators, [register][lane]
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    // tile mapping: XCD-contiguous ranges of logical ids, row tiles fastest (neighbours share the weight slab and the halo)
+    int bx, byh, bz;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy * (int)gridDim.z;
+        const int orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int per_z = gx * gy;
+        bz = L / per_z;
+        const int t = L - bz * per_z;
+        bx = t % gx;
+        byh = t / gx;
+    }
+    const int by = NCH_ == 2 ? byh : (byh >> 1), half0 = NCH_ == 2 ? 0 : (byh & 1);      // 224-column weight tile, first 112-column half
+    const int S = gridDim.z;
+    const long m0 = (long)bx * BM_;
+    const int kch0 = a.Cin >> 5;
+    const int nks0 = a.taps * kch0;
+    // stream s of this workgroup = virtual split index bz KS_ + s of S KS_
+    int nstage = 0;
+#pragma unroll
+    for (int s = 0; s < KS_; ++s) {
+        int b0, e0;
+        split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz * KS_ + s, S * KS_, b0, e0);
+        nstage = (e0 - b0) > nstage ? (e0 - b0) : nstage;
+    }
+    if (wave >= NC_) {
+        // =============================== producer ===============================
+        const int pw = wave - NC_, strm = pw / NPW, sub = pw - strm * NPW;
+        int ks_begin, ks_end;
+        split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz * KS_ + strm, S * KS_, ks_begin, ks_end);
+        const int nloc = ks_end - ks_begin;
+        const int npc = (NPIECE - sub + NPW - 1) / NPW;          // pieces of this wave per unit (JMAX or JMAX - 1)
+        int a_lc[JA], a_o[JA], a_d[JA], a_h[JA], a_w[JA];
+        bool a_ok[JA];
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int p = (sub + NPW * j) * 64 + lane;   // 16-B slot of the A tile: row = p >> 2, physical chunk = p & 3
+            const int row = p >> 2;
+            a_lc[j] = (p & 3) ^ f_swz(row);
+            const long m = m0 + row;
+            a_ok[j] = m < M;
+            const long mm = a_ok[j] ? m : 0;
+            a_w[j] = (int)(mm & (g.W - 1));
+            a_h[j] = (int)((mm >> g.lw) & (g.H - 1));
+            a_d[j] = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+            a_o[j] = (int)(mm >> (g.lw + g.lh + g.ld));
+        }
+        int st_phase = ks_begin >= nks0 ? 1 : 0;
+        int st_tap = st_phase ? 0 : ks_begin % a.taps;
+        int st_c = st_phase ? (ks_begin - nks0) : (ks_begin / a.taps);
+        int st_ntap = st_phase ? 1 : a.taps, st_kch = st_phase ? (a.Cin2 >> 5) : kch0;
+        unsigned st_boff = (unsigned)(st_phase ? (ks_begin - nks0) : ks_begin) * (unsigned)(BNP * BK * 2);      // weight images: 16 KiB per K step
+        unsigned voff[JA], msk[JA];
+        int upm[JA][3], upp[JA][3];
+        int dtab = 0;
+        __amdgpu_buffer_rsrc_t rA, rB;
+        auto set_phase = [&]() __attribute__((always_inline)) {
+            const _Float16* Wg = (const _Float16*)(st_phase ? a.w2 : a.w);
+            const long nks_ph = st_phase ? (long)(a.Cin2 >> 5) : (long)nks0;
+            rB = __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + ((long)by * nks_ph) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+            const _Float16* Ag = (const _Float16*)(st_phase ? a.a2 : a.a);
+            const int Cin = st_phase ? a.Cin2 : a.Cin;
+            const bool down = !st_phase && (a.mode == ES_CONV_DOWN_HW || a.mode == ES_CONV_DOWN_DHW);
+            const bool downd = !st_phase && a.mode == ES_CONV_DOWN_DHW;
+            const int Dsrc = downd ? 2 * g.D : g.D;
+            const int Hi = st_phase ? g.H : g.Hi, Wi = st_phase ? g.W : g.Wi;
+            const int ntap = st_phase ? 1 : a.taps;
+            const bool updhw = UP_ && a.mode == ES_CONV_UP_DHW;
+            const int Di = updhw ? g.D / 2 : g.D;
+            const int bias = ntap == 27 ? ((Hi + 1) * Wi + 1) * Cin * 2 : 0;
+            rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Ag - bias), (short)0, (int)OOB, 0x00020000);
+            {
+                const int t = lane < 27 ? lane : 13;
+                const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+                dtab = ntap == 27 ? ((kd * Hi + kh) * Wi + kw) * Cin * 2 + bias : 0;
+                if (UP_) dtab = ntap == 27 ? (updhw ? 0 : kd * Hi * Wi * Cin * 2) + bias : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                const int ch = down ? 2 * a_h[j] : a_h[j];
+                const int cw = down ? 2 * a_w[j] : a_w[j];
+                const int cd = downd ? 2 * a_d[j] : a_d[j];
+                voff[j] = (unsigned)(((((long)a_o[j] * Dsrc + cd) * Hi + ch) * Wi + cw) * Cin * 2 + a_lc[j] * 16);
+                if (UP_) {
+                    const int sd = updhw ? a_d[j] >> 1 : a_d[j];
+                    voff[j] = (unsigned)(((((long)a_o[j] * Di + sd) * Hi + (a_h[j] >> 1)) * Wi + (a_w[j] >> 1)) * Cin * 2 + a_lc[j] * 16);
+                    const int SD = Hi * Wi * Cin * 2, SH = Wi * Cin * 2, SW = Cin * 2;
+                    upm[j][0] = (updhw && !(a_d[j] & 1)) ? -SD : 0; upp[j][0] = (updhw && (a_d[j] & 1)) ? SD : 0;
+                    upm[j][1] = !(a_h[j] & 1) ? -SH : 0;            upp[j][1] = (a_h[j] & 1) ? SH : 0;
+                    upm[j][2] = !(a_w[j] & 1) ? -SW : 0;            upp[j][2] = (a_w[j] & 1) ? SW : 0;
+                }
+                unsigned m = 0;
+                if (ntap == 1) m = a_ok[j] ? 1u : 0u;
+                else m = a_ok[j] ? tap_mask27(cd, Dsrc, ch, UP_ ? g.H : Hi, cw, UP_ ? g.W : Wi) : 0u;
+                msk[j] = m;
+            }
+        };
+        set_phase();
+        const unsigned voffB = (unsigned)lane * 16u;
+        auto issue_unit = [&](char* dst) __attribute__((always_inline)) {        // dst: LDS base of this stream's unit (A tile, then B tile)
+            const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, st_tap) + (unsigned)st_c * 64u;
+            const unsigned sbit = 1u << st_tap;
+            int ukd = 0, ukh = 0, ukw = 0;
+            if (UP_) { ukd = st_tap / 9 - 1; ukh = (st_tap / 3) % 3 - 1; ukw = st_tap % 3 - 1; }
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                unsigned vs = voff[j];
+                if (UP_) {
+                    vs += (unsigned)(ukd < 0 ? upm[j][0] : ukd > 0 ? upp[j][0] : 0);
+                    vs += (unsigned)(ukh < 0 ? upm[j][1] : ukh > 0 ? upp[j][1] : 0);
+                    vs += (unsigned)(ukw < 0 ? upm[j][2] : ukw > 0 ? upp[j][2] : 0);
+                }
+                const unsigned vo = (msk[j] & sbit) ? vs : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (sub + NPW * j) * 1024), 16, (int)vo, (int)sA, 0, 0);
+            }
+#pragma unroll
+            for (int j = JA; j < JMAX; ++j) {
+                const int qb = sub + NPW * j - APIECES;                           // 1 KiB piece (16 weight rows) of this tile's NCH_ x 7
+                if (j < JMAX - 1 || qb < BPIECES)                                 // (wave-uniform: the last piece exists for the first waves only)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + A_BYTES + qb * 1024), 16, (int)voffB,
+                                                             (int)(st_boff + (unsigned)(half0 * 7 + qb) * 1024u), 0, 0);
+            }
+            st_boff += (unsigned)(BNP * BK * 2);
+            if (++st_tap == st_ntap) {
+                st_tap = 0;
+                if (++st_c == st_kch && !st_phase && a.a2) {
+                    st_phase = 1; st_c = 0; st_ntap = 1; st_kch = a.Cin2 >> 5; st_boff = 0;
+                    set_phase();
+                }
+            }
+        };
+        auto wait_own = [&](bool more) __attribute__((always_inline)) {           // the pieces of the oldest unit in flight have landed
+            if (!more) wait_vmcnt<0>();
+            else if (npc == JMAX) wait_vmcnt<JMAX>();
+            else wait_vmcnt<JMAX - 1>();
+        };
+        char* const base = smem + strm * UNIT_BYTES;
+        if (nloc > 0) issue_unit(base);
+        if (nloc > 1) issue_unit(base + STAGE_BYTES);
+        for (int st = 0; st < nstage; ++st) {
+            if (st < nloc) wait_own(st + 1 < nloc);                               // own pieces of unit st (a stream may be one unit shorter)
+            __builtin_amdgcn_s_barrier();        // stage st visible to the consumers; the slot of stage st - 1 released by them
+            if (st + 2 < nloc) issue_unit(base + ((st + 2) % NS) * STAGE_BYTES);
+        }
+        __builtin_amdgcn_s_barrier();            // (A) ring free
+        __builtin_amdgcn_s_barrier();            // (B) stream tiles in LDS
+        f4 dummy[1][7];
+        if constexpr (NCH_ == 1) conv_epilogue<64, 8, false, true, EPI_>(a, g, dummy, smem, M, m0, 0, wave, lane, S, bz, ncdhw);
+        else { f4 dummy2[2][7]; conv_epilogue<64, 4, false, true, EPI_>(a, g, dummy2, smem, M, m0, 0, wave, lane, S, bz, ncdhw); }
+        return;
+    }
+    // =============================== consumer ===============================
+    const int strm = wave / NCH_, hh = wave - strm * NCH_;
+    int ks_begin, ks_end;
+    split_range(nks0, a.a2 ? (a.Cin2 >> 5) : 0, a.taps, bz * KS_ + strm, S * KS_, ks_begin, ks_end);
+    const int nloc = ks_end - ks_begin;
+    constexpr int MI = 4;
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fragA = strm * UNIT_BYTES + i16 * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = strm * UNIT_BYTES + A_BYTES + hh * (112 * 64) + i16 * 64 + ((q ^ f_swz(i16)) << 4);
+    {
+        h8 af[MI], bfr[7];
+        int slot = 0, done = 0;                                                 // barriers passed so far
+        if (nloc > 0) {
+            __builtin_amdgcn_s_barrier();                                       // stage 0 published
+            done = 1;
+            ws_read_frags<MI>(smem, fragA, fragB, af, bfr);
+            for (int ks = 0; ks + 1 < nloc; ++ks) {                             // pipelined as in k_conv_ws
+                slot = slot == NS - 1 ? 0 : slot + 1;
+                const char* const An = smem + slot * STAGE_BYTES;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfr[j], acc[0][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                ++done;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 1; i < MI; ++i) {
+                    af[i - 1] = *(const h8*)(An + fragA + (i - 1) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i < MI - 1) {
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            bfr[j] = *(const h8*)(An + fragB + j * 1024);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                af[MI - 1] = *(const h8*)(An + fragA + (MI - 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ws_mma<MI>(acc, af, bfr);                                           // last unit of this stream
+        }
+        for (; done < nstage; ++done) __builtin_amdgcn_s_barrier();             // a shorter stream keeps the others' stage barriers company
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // (A) every wave is done with the ring
+    {
+        f4* P = (f4*)smem + (long)wave * (PART_FLOATS / 4);                    // this wave's tile, [MFMA tile][lane][4]: lane-linear 16-byte writes
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) P[(i * 7 + j) * 64 + lane] = acc[i][j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // (B) stream tiles in LDS
+    // wave (strm, hh) finishes rows [16 MI2 strm, 16 MI2 (strm + 1)) of column half hh: the streams' tiles added in stream order
+    constexpr int MI2 = MI / KS_;
+    f4 fin[MI2][7];
+#pragma unroll
+    for (int i2 = 0; i2 < MI2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int i = strm * MI2 + i2;
+            f4 v = ((const f4*)smem)[(long)(0 * NCH_ + hh) * (PART_FLOATS / 4) + (i * 7 + j) * 64 + lane];
+#pragma unroll
+            for (int s = 1; s < KS_; ++s) v += ((const f4*)smem)[(long)(s * NCH_ + hh) * (PART_FLOATS / 4) + (i * 7 + j) * 64 + lane];
+            fin[i2][j] = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the ordinary epilogue on the sum: (KS_ 4, one column half) wave = 16 rows x 112 columns -> the <64, 8> geometry with wn = 0;
+    // (KS_ 2, two halves) wave = 32 rows x 112 columns -> the <64, 4> geometry as it is
+    if constexpr (NCH_ == 1) conv_epilogue<64, 8, true, true, EPI_>(a, g, fin, smem, M, m0, by * BN + half0 * 112, 2 * wave, lane, S, bz, ncdhw);
+    else conv_epilogue<64, 4, true, true, EPI_>(a, g, fin, smem, M, m0, by * BN, wave, lane, S, bz, ncdhw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2294,6 +2581,10 @@ static VolOpt g_vo[] = {
     {"conv_deep", 1},          // 0: no k_linear_deep for small K-short linear launches
     {"conv_tinysplit", 1},     // 0: tiny K-short launches without split K
     {"gn_rg", 1},              // 0: GroupNorm statistics always from a pass over the tensor
+    {"conv_st_bm", 0},         // tools only: 64 / 128 = every producer/consumer-eligible launch on k_conv_ws tiles of that many rows
+    {"conv_st_np", 4},         // tools only: producer waves of that tile (4; 8 with 128-row tiles)
+    {"conv_st_ns", 3},         // tools only: ring depth of that tile (3; 6 with 64-row tiles, 5 with 128-row tiles and 8 producers)
+    {"conv_kw_ks", 0},         // tools only: 4 / 2 = every eligible launch on k_conv_kw with that many K streams per workgroup
 };
 static int vo(const char* name) {
     for (const VolOpt& o : g_vo) if (!strcmp(o.name, name)) return o.value;
@@ -2310,6 +2601,64 @@ extern "C" int es_vol_options(char* out, int cap) {
     for (const VolOpt& o : g_vo) { s += o.name; s += '='; s += std::to_string(o.value); s += ';'; }
     if (out && cap > 0) { strncpy(out, s.c_str(), (size_t)cap - 1); out[cap - 1] = 0; }
     return (int)s.size() + 1;
+}
+
+// k_conv_ws on tiles of fewer than 256 rows (round 6: the few-objects regime): 4 consumer waves as 2 x 2 (wave tile BM_/2 x 112), NP_
+// producer waves; the instantiation's dynamic-LDS limit is set once per process
+template <int BM_, int NP_, int NS_>
+static int launch_ws_small(const es_conv_args* a, const ConvGeom& g, int ncdhw, dim3 grid, hipStream_t st, bool upm, bool geglu, bool stats) {
+    constexpr int LDS = NS_ * (BM_ * BK * 2 + BNP * BK * 2);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        auto set = [](const void* f) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+        };
+        set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, false, NS_>);
+        set((const void*)k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, false, NS_>);
+        set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_GEGLU, false, NS_>);
+        if constexpr (BM_ == 128) {
+            set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, true, NS_>);
+            set((const void*)k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, true, NS_>);
+        }
+    });
+    ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    const dim3 blk(64 * (4 + NP_));
+    if (geglu) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_GEGLU, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    else if (stats) {
+        if constexpr (BM_ == 128) {
+            if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+            else hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+        } else ES_REQUIRE(false, "launch_ws_small: row-group sums need 64-row waves");
+    }
+    else if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    else hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    return 0;
+}
+
+// k_conv_kw: K split inside the workgroup (KS_ streams x NCH_ column halves of 112)
+template <int KS_, int NCH_>
+static int launch_kw(const es_conv_args* a, const ConvGeom& g, int ncdhw, long M, int ntn, int S, hipStream_t st, bool upm, bool geglu) {
+    constexpr int RING = 3 * KS_ * (64 * BK * 2 + NCH_ * 112 * BK * 2), PART = 4 * 112 * 64 * 4;
+    constexpr int LDS = RING > PART ? RING : PART;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        auto set = [](const void* f) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+        };
+        set((const void*)k_conv_kw<KS_, NCH_, false, ES_EPI_NONE>);
+        set((const void*)k_conv_kw<KS_, NCH_, true, ES_EPI_NONE>);
+        set((const void*)k_conv_kw<KS_, NCH_, false, ES_EPI_GEGLU>);
+    });
+    ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)(ntn * (2 / NCH_)), (unsigned)S), blk(768);
+    if (geglu) hipLaunchKernelGGL((k_conv_kw<KS_, NCH_, false, ES_EPI_GEGLU>), grid, blk, LDS, st, *a, g, ncdhw);
+    else if (upm) hipLaunchKernelGGL((k_conv_kw<KS_, NCH_, true, ES_EPI_NONE>), grid, blk, LDS, st, *a, g, ncdhw);
+    else hipLaunchKernelGGL((k_conv_kw<KS_, NCH_, false, ES_EPI_NONE>), grid, blk, LDS, st, *a, g, ncdhw);
+    return 0;
 }
 
 // emits != nullptr: dry run -- report whether this launch would form gn_stats_out in its epilogue, launch nothing
@@ -2509,18 +2858,27 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             if (s3 >= 2) { S = s3; tiny_split = true; }
         }
     }
-    const bool route256 = (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split && !deep;
+    // tools: every eligible launch on the small producer/consumer tiles (split K as the caller says, 1 when it says nothing)
+    const int kw_ks = ws && (!geglu || !upm) ? vo("conv_kw_ks") : 0;
+    const int st_bm = kw_ks ? 64 : (ws && (!geglu || !upm) ? vo("conv_st_bm") : 0);
+    if (st_bm) {
+        deep = tiny_split = ws_split = split256 = false;
+        S = a->splitk > 1 && can_split && !geglu ? a->splitk : 1;
+    }
+    const bool route256 = !st_bm && (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split && !deep;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
     if (route256 && ws && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME && S == 1 && ntn >= 2 && !(lin_env && atoi(lin_env) == 0)) {
         static const int cand[5] = {8, 6, 4, 3, 2};
+        static const char* ncb_env = getenv("ES_LIN_NCB_MAX");    // A/B switch (timing only: same K order, same bits): cap of the walk
+        const int ncb_max = ncb_env ? atoi(ncb_env) : 8;
         for (int k = 0; k < 5; ++k)
-            if (ntn % cand[k] == 0 && ((M + 255) / 256) * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
+            if (cand[k] <= ncb_max && ntn % cand[k] == 0 && ((M + 255) / 256) * (ntn / cand[k]) >= 256) { ncb = cand[k]; break; }
     }
     // the producer/consumer 256-row kernel forms the row-group sums of gn_stats_out in its epilogue; every other route runs
     // k_rowgroup_stats over the finished output
-    const bool epi_stats = route256 && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
+    const bool epi_stats = (route256 || st_bm == 128) && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
                            (a->D * a->H * a->W) % 64 == 0;
     // (bit 1) a split launch can form the next GroupNorm's per-tile partial sums in its reduction kernel (gn_part_out)
     const bool part_ok = S > 1 && !deep && a->out_f32 && !ncdhw && a->N % 4 == 0 && a->N <= 2048 && a->out_ld == a->N && a->gn_part_groups > 0 &&
@@ -2552,7 +2910,27 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
-    if (deep) {
+    if (kw_ks) {
+        int rc = 1;
+        if (kw_ks == 4) rc = launch_kw<4, 1>(a, g, ncdhw, M, ntn, S, st, upm, geglu);
+        else if (kw_ks == 2) rc = launch_kw<2, 2>(a, g, ncdhw, M, ntn, S, st, upm, geglu);
+        else ES_REQUIRE(false, "es_conv_mfma_f16: conv_kw_ks=%d (2 or 4)", kw_ks);
+        if (rc) return rc;
+    } else if (st_bm) {
+        const int np = vo("conv_st_np");
+        const dim3 grid((unsigned)((M + st_bm - 1) / st_bm), ntn, S);
+        const bool stt = want_stats && epi_stats;
+        int rc = 1;
+        const int ns = vo("conv_st_ns");
+        if (st_bm == 64 && np == 4 && ns == 3) rc = launch_ws_small<64, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 64 && np == 4 && ns == 6) rc = launch_ws_small<64, 4, 6>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 4 && ns == 3) rc = launch_ws_small<128, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 8 && ns == 3) rc = launch_ws_small<128, 8, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 8 && ns == 5) rc = launch_ws_small<128, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else ES_REQUIRE(false, "es_conv_mfma_f16: conv_st_bm=%d conv_st_np=%d conv_st_ns=%d is not a built tile", st_bm, np, ns);
+        if (rc) return rc;
+        stats_done = stt;
+    } else if (deep) {
         S = 1;
         hipLaunchKernelGGL(k_linear_deep, dim3((unsigned)((M + 63) / 64), ntn, 1), dim3(256), 7 * (64 * BK * 2 + BNP * BK * 2), st, *a, g);
     } else if (route256) {

@@ -173,6 +173,61 @@ def test_conv_mfma(dev, mode, N, Cin, dims):
     assert _rel(out16, ref) < 2e-3
 
 
+@pytest.mark.parametrize('taps,Cin,Cs,N,dims,O', [(27, 96, 0, 224, (4, 8, 8), 3), (27, 64, 96, 250, (4, 4, 8), 3), (1, 448, 0, 448, (4, 4, 8), 5),
+                                                  (1, 160, 64, 72, (2, 4, 8), 3)])
+def test_conv_few_objects_kernels_bit_for_bit(dev, taps, Cin, Cs, N, dims, O):
+    """Round 6, the few-objects kernels.  (a) producer/consumer tiles of 64 / 128 rows: the unsplit launch has the K order and the
+    MFMA chain of every other conv kernel -> the same bits as the dispatcher's own unsplit route.  (b) k_conv_kw, K split INSIDE the
+    workgroup over KS streams: stream s multiplies the s-th range of split_range(KS) and the streams are added in stream order -> the
+    same bits as a split of S = KS over workgroups followed by k_conv_splitk_reduce.  Ragged rows, fused 1x1 skip phase, per-object
+    vector, residual, f16 copy; vs the fp32 reference as well."""
+    from echoscene_amd import hip
+    from echoscene_amd.plan import Builder, View
+    from echoscene_amd.plan_vol import PackedConv
+    D, H, W = dims
+    M = O * D * H * W
+    x = _rnd((O, Cin) + dims, 1).half().float()
+    wt = (_rnd((N, Cin, 3, 3, 3) if taps == 27 else (N, Cin), 2) / np.sqrt(Cin * taps)).half().float()
+    bias, rowv, res = _rnd((N,), 3), _rnd((O, N), 4), _rnd((M, N), 5)
+    ref = F.conv3d(x, wt if taps == 27 else wt[:, :, None, None, None], bias, padding=1 if taps == 27 else 0)
+    skip = None
+    if Cs:
+        xs = _rnd((O, Cs) + dims, 6).half().float()
+        ws = (_rnd((N, Cs), 7) / np.sqrt(Cs)).half().float()
+        ref = ref + F.conv3d(xs, ws[:, :, None, None, None])
+    ref = _cl(ref) + rowv.repeat_interleave(D * H * W, 0) + res
+    lib = hip.lib()
+
+    def run(opts, splitk):
+        for k, v in opts.items():
+            hip.check(lib.es_vol_set_option(k.encode(), v), 'es_vol_set_option')
+        try:
+            b = Builder(dev)
+            o32, o16 = b.buf(M, N, zero=True), b.buf(M, N, dtype=torch.float16, zero=True)
+            sk = (b.dev(_cl(xs), torch.float16), PackedConv(ws, None, dev)) if Cs else None
+            b.conv(b.dev(_cl(x), torch.float16), PackedConv(wt, bias, dev), O, dims, rowvec=View(b.dev(rowv)), res=b.dev(res),
+                   out_f32=o32, out_f16=o16, skip=sk, splitk=splitk)
+            b.finish().run()
+            torch.cuda.synchronize()
+            return o32.clone(), o16.clone()
+        finally:
+            for k in opts:
+                hip.check(lib.es_vol_set_option(k.encode(), 4 if k == 'conv_st_np' else 0), 'es_vol_set_option')
+
+    plain = {S: run({}, S) for S in (1, 2, 4)}
+    assert _rel(plain[1][0], ref) < 1e-4
+    for opts in ({'conv_st_bm': 64}, {'conv_st_bm': 128}, {'conv_st_bm': 128, 'conv_st_np': 8}):
+        for S in (1, 2):
+            got = run(opts, S)
+            assert torch.equal(got[0], plain[S][0]) and torch.equal(got[1], plain[S][1]), (opts, S)
+    for ks in (4, 2):
+        got = run({'conv_kw_ks': ks}, 1)
+        assert _rel(got[0], ref) < 1e-4
+        assert torch.equal(got[0], plain[ks][0]) and torch.equal(got[1], plain[ks][1]), ks
+        got2 = run({'conv_kw_ks': ks}, 2)             # a split over workgroups on top: partial slabs of pre-summed streams
+        assert _rel(got2[0], ref) < 1e-4
+
+
 def test_conv_fused_skip_and_ncdhw(dev):
     from echoscene_amd.plan import Builder
     from echoscene_amd.plan_vol import PackedConv
@@ -850,7 +905,11 @@ def test_splitk_reduction_leaves_the_next_groupnorm_partials(dev, monkeypatch, O
 
 
 @pytest.mark.parametrize('env', [{'ES_TEST_VOL_OPTIONS': 'conv_ws=0'}, {'ES_TEST_VOL_OPTIONS': 'conv_tile=128'}, {'ES_TEST_VOL_OPTIONS': 'conv_force256=1'},
-                                 {'ES_TEST_VOL_OPTIONS': 'conv_wssplit=0'}, {'ES_CONV_LINWS': '0'}])
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_wssplit=0'}, {'ES_CONV_LINWS': '0'},
+                                 # round 6: the few-objects kernels forced for EVERY eligible launch -- producer/consumer tiles of 64 and
+                                 # 128 rows, and K split inside the workgroup (4 streams x 112 columns, 2 streams x 224 columns)
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_st_bm=64'}, {'ES_TEST_VOL_OPTIONS': 'conv_st_bm=128,conv_st_np=8'},
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=4'}, {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=2'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
     128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
