@@ -49,7 +49,7 @@ def build_layout(dev, O, seed, graph_seed=None):
     return net, den, obj_embed, triples
 
 
-def build_shape(dev, O, seed, triples, rank=0, world=1, deterministic=True):
+def build_shape(dev, O, seed, triples, rank=0, world=1, deterministic=False):
     from echoscene_amd import synth, config as escfg
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
@@ -369,11 +369,12 @@ def main():
     ap.add_argument('--scenes-per-gpu', type=int, default=2,
                     help='weak scaling: scenes per GPU (configs[4] is 8 per GPU; 2 keeps the default run inside ~20 GB)')
     ap.add_argument('--no-sub-records', action='store_true')
-    ap.add_argument('--deterministic', action='store_true', help='(the default since round 4; kept for old command lines)')
-    ap.add_argument('--tuned', action='store_true',
-                    help='N > 1, strong scaling: every rank tunes split-K / GroupNorm tiling to its own share of the objects.  Default '
-                         '(off): shards reproduce the single-GPU latents BIT FOR BIT (SURVEY.md 8(e)): the tiling is a function of the '
-                         'layer and the global object count only')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='the CANONICAL arithmetic (ShapeDenoiser(deterministic=True)): split-K / GroupNorm tiling of a 4-object reference '
+                         'shard on every rank of every world size, 1 included -- the latents are the same BIT FOR BIT for N = 1, 2, 4, 8 '
+                         '(SURVEY.md 8(e)).  Default (off, round 6): every rank tunes the tiling to its own share of the objects; at 4 '
+                         'objects per GPU the two modes coincide')
+    ap.add_argument('--tuned', action='store_true', help='(the default since round 6; kept for old command lines)')
     ap.add_argument('--fuse-loops', type=int, default=-1,
                     help='1: one hipGraph per full step with the layout step as a parallel branch of the shape step; 0: two streams; '
                          '-1: the default of this build')
@@ -383,7 +384,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--check', action='store_true',
                     help='seeded initial latents (the same for every world size) and a CRC32 of the final latents of the whole scene in the '
-                         'JSON line ("check"): with --deterministic the N-rank run must reproduce the 1-rank CRC bit for bit')
+                         'JSON line ("check"): with --deterministic the N-rank run reproduces the 1-rank CRC (of a --deterministic run) bit for bit')
     a = ap.parse_args()
 
     backend = os.environ.get('ES_DIST_BACKEND', 'nccl')     # 'gloo' only for single-GPU multi-rank smoke tests
@@ -447,7 +448,7 @@ def main():
     st['noise'].normal_()
     st['x'].copy_(st['noise'][0])
     if full:
-        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=not a.tuned)
+        df, sden, uc = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=a.deterministic)
         noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
         sden.sample(uc, triples_all, noise1=noise1, n_steps=max(min(a.warmup, 3), 1), use_graph=use_graph)
         ss = next(iter(sden._plans.values()))
@@ -599,10 +600,10 @@ def main():
     alt = None
     if full and sh_world > 1 and not a.check and not a.no_alt_mode:
         # The OTHER sharding mode on the same ranks, shape loop only, same K steps inside the same barrier bracket: the line's `value`
-        # is the bit-exact default (or --tuned); this record puts the other curve next to it, so that one multi-GPU run of the driver
-        # shows both (bit-exact shards cannot be as fast as shards tuned to their own object count).
+        # is the tuned default (or --deterministic); this record puts the other curve next to it, so that one multi-GPU run of the
+        # driver shows both (round 6: the canonical arithmetic is that of a 4-object shard, so at N = 8 the two agree).
         from echoscene_amd.parallel import sharded_ddim_loop
-        _, sden2, _ = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=a.tuned)
+        _, sden2, _ = build_shape(dev, O_all, 100, triples_all, sh_rank, sh_world, deterministic=not a.deterministic)
         sden2.sample(uc, triples_all, noise1=noise1, n_steps=2, use_graph=use_graph)
         ss2 = next(iter(sden2._plans.values()))
         ws2 = []
@@ -623,7 +624,7 @@ def main():
             tm = torch.tensor([time.perf_counter() - t0], device=dev if backend == 'nccl' else 'cpu')
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             ws2.append(float(tm.item()))
-        alt = {'mode': 'bit-exact shards' if a.tuned else 'tuned shards (--tuned: K splits chosen from the local object count)',
+        alt = {'mode': 'tuned shards (K splits chosen from the local object count)' if a.deterministic else 'bit-exact shards (--deterministic: the canonical K splits of a 4-object shard on every rank)',
                'what': 'shape loop only, %d steps, max over ranks, median of %d' % (a.steps, len(ws2)),
                'shape_ms_per_step': _stats([w * 1e3 / a.steps for w in ws2])}
         del sden2, ss2
@@ -671,8 +672,8 @@ def main():
                                                  'batch graph): no per-step collective' % (scenes_local, world)) if weak
                                           else ('1 scene (configs[3] when N > 1: objects sharded over %d GPU(s), echo all-gather of '
                                                 '[O,64] codes every DDIM step over RCCL)' % world)),
-                           'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': (not a.tuned) if sh_world > 1 else None,
-                           'deterministic': not a.tuned,       # ShapeDenoiser(deterministic=...): bit-exact object shards (the default since round 4; --tuned flips it)
+                           'scenes': scenes, 'hip_graph': use_graph, 'deterministic_shards': a.deterministic if sh_world > 1 else None,
+                           'deterministic': a.deterministic,   # ShapeDenoiser(deterministic=...): the canonical arithmetic, bit-exact across world sizes (opt-in since round 6)
                            'step_graph': os.environ.get('ES_STEP_GRAPH', '0') == '1',      # sharded DDIM step captured as ONE graph (opt-in)
                            'route_options': route_options_string(),
                            'loops': ('one hipGraph per full step, layout step as a parallel branch '

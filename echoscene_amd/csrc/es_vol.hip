@@ -2581,6 +2581,7 @@ static VolOpt g_vo[] = {
     {"conv_deep", 1},          // 0: no k_linear_deep for small K-short linear launches
     {"conv_tinysplit", 1},     // 0: tiny K-short launches without split K
     {"gn_rg", 1},              // 0: GroupNorm statistics always from a pass over the tensor
+    {"conv_few", 1},           // 0: the few-objects routes of round 6 off (round-5 routing for small problems)
     {"conv_st_bm", 0},         // tools only: 64 / 128 = every producer/consumer-eligible launch on k_conv_ws tiles of that many rows
     {"conv_st_np", 4},         // tools only: producer waves of that tile (4; 8 with 128-row tiles)
     {"conv_st_ns", 3},         // tools only: ring depth of that tile (3; 6 with 64-row tiles, 5 with 128-row tiles and 8 producers)
@@ -2603,11 +2604,14 @@ extern "C" int es_vol_options(char* out, int cap) {
     return (int)s.size() + 1;
 }
 
-// k_conv_ws on tiles of fewer than 256 rows (round 6: the few-objects regime): 4 consumer waves as 2 x 2 (wave tile BM_/2 x 112), NP_
-// producer waves; the instantiation's dynamic-LDS limit is set once per process
-template <int BM_, int NP_, int NS_>
-static int launch_ws_small(const es_conv_args* a, const ConvGeom& g, int ncdhw, dim3 grid, hipStream_t st, bool upm, bool geglu, bool stats) {
+// k_conv_ws launcher for one (tile rows, consumer waves, producer waves, ring depth): the 256-row tile of rounds 1-5 (8 consumers as
+// 4 x 2, 4 producers) and, round 6, the few-objects tiles of 64 / 128 rows (4 consumers as 2 x 2 of BM_/2 x 112, 4 or 8 producers,
+// deeper rings).  The instantiation's dynamic-LDS limit is set once per process.
+template <int BM_, int NC_, int NP_, int NS_>
+static int launch_ws(const es_conv_args* a, const ConvGeom& g, int ncdhw, dim3 grid, hipStream_t st, bool upm, bool geglu, bool stats) {
     constexpr int LDS = NS_ * (BM_ * BK * 2 + BNP * BK * 2);
+    constexpr bool CAN_STATS = BM_ / (NC_ / 2) == 64;             // row-group sums are per 64-row wave
+    static_assert(LDS <= 160 * 1024, "ring exceeds the CU's LDS");
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -2615,25 +2619,25 @@ static int launch_ws_small(const es_conv_args* a, const ConvGeom& g, int ncdhw, 
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
         };
-        set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, false, NS_>);
-        set((const void*)k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, false, NS_>);
-        set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_GEGLU, false, NS_>);
-        if constexpr (BM_ == 128) {
-            set((const void*)k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, true, NS_>);
-            set((const void*)k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, true, NS_>);
+        set((const void*)k_conv_ws<BM_, NC_, NP_, false, ES_EPI_NONE, false, NS_>);
+        set((const void*)k_conv_ws<BM_, NC_, NP_, true, ES_EPI_NONE, false, NS_>);
+        set((const void*)k_conv_ws<BM_, NC_, NP_, false, ES_EPI_GEGLU, false, NS_>);
+        if constexpr (CAN_STATS) {
+            set((const void*)k_conv_ws<BM_, NC_, NP_, false, ES_EPI_NONE, true, NS_>);
+            set((const void*)k_conv_ws<BM_, NC_, NP_, true, ES_EPI_NONE, true, NS_>);
         }
     });
     ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
-    const dim3 blk(64 * (4 + NP_));
-    if (geglu) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_GEGLU, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    const dim3 blk(64 * (NC_ + NP_));
+    if (geglu) hipLaunchKernelGGL((k_conv_ws<BM_, NC_, NP_, false, ES_EPI_GEGLU, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
     else if (stats) {
-        if constexpr (BM_ == 128) {
-            if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
-            else hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
-        } else ES_REQUIRE(false, "launch_ws_small: row-group sums need 64-row waves");
+        if constexpr (CAN_STATS) {
+            if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, NC_, NP_, true, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+            else hipLaunchKernelGGL((k_conv_ws<BM_, NC_, NP_, false, ES_EPI_NONE, true, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+        } else ES_REQUIRE(false, "launch_ws: row-group sums need 64-row waves");
     }
-    else if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, true, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
-    else hipLaunchKernelGGL((k_conv_ws<BM_, 4, NP_, false, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    else if (upm) hipLaunchKernelGGL((k_conv_ws<BM_, NC_, NP_, true, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
+    else hipLaunchKernelGGL((k_conv_ws<BM_, NC_, NP_, false, ES_EPI_NONE, false, NS_>), grid, blk, LDS, st, *a, g, ncdhw);
     return 0;
 }
 
@@ -2684,7 +2688,11 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     ES_REQUIRE(!ncdhw || (a->out_f32 && !a->res && !a->out_f16), "es_conv_mfma_f16: NCDHW output is fp32-only, no residual");
     const long M = (long)a->O * a->D * a->H * a->W;
     // split-K factors are derived from Mh: the row count of the WHOLE problem when this launch is one shard of it
-    const long Mh = (long)(a->O_hint > a->O ? a->O_hint : a->O) * a->D * a->H * a->W;
+    // O_hint < 0 (round 6): the CANONICAL arithmetic of a reference shard of -O_hint objects, whatever the launch's own object count --
+    // every rank of every world size (1 included) cuts K where a shard of that size is cut best, so all of them leave the same bits
+    // and the small shards are the fast ones (until round 5 the reference was the unsharded run and its shards paid 2x)
+    const long Oh = a->O_hint < 0 ? -(long)a->O_hint : (long)(a->O_hint > a->O ? a->O_hint : a->O);
+    const long Mh = Oh * a->D * a->H * a->W;
     // The kernels address their operands with 31-bit byte offsets from a buffer descriptor.  Larger tensors are processed in
     // object chunks (every object is independent; O_hint keeps the split-K choice of the whole problem).
     {
@@ -2701,7 +2709,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             for (long o0 = 0; o0 < a->O; o0 += omax) {
                 es_conv_args c = *a;
                 c.O = (int32_t)std::min(omax, (long)a->O - o0);
-                c.O_hint = a->O_hint > a->O ? a->O_hint : a->O;
+                c.O_hint = a->O_hint < 0 ? a->O_hint : (a->O_hint > a->O ? a->O_hint : a->O);
                 c.a = (const char*)a->a + o0 * per_obj_in;
                 if (a->a2) c.a2 = (const char*)a->a2 + o0 * per_obj_in2;
                 if (a->rowvec) c.rowvec = a->rowvec + o0 * a->rowvec_ld;
@@ -2783,7 +2791,46 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
                "es_conv_mfma_f16: gn_stats_out needs a channels-last output, N %% 4 == 0 and voxels per object %% 64 == 0");
     int S = a->splitk;
     const bool can_split = a->workspace && !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0);
-    if (S < 0) {                                           // auto
+    const bool no256 = vo("conv_tile") == 128;               // (route options: es_vol_set_option, no environment access)
+    const bool force256 = vo("conv_force256") == 1;
+    const bool geglu = a->epilogue == ES_EPI_GEGLU;
+    const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
+    // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
+    const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
+                                M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) &&
+                                (!a->rowvec || (a->D * a->H * a->W) % 64 == 0);      // a wave's 64 rows in one object: rowvec per wave
+    const bool ws = vo("conv_ws") != 0 && ws_epilogue_ok;
+    // ---- round 6: the few-objects routes (fewer than 256 tiles of 256 rows in the reference problem) --------------------------------
+    // few_ref: what the REFERENCE problem (Mh rows) decides -- 1: a plain split of S over workgroups, 2: S = 4 K streams inside the
+    // workgroup (k_conv_kw, no slabs; the same bits as a plain split of 4).  The launch's own row count only picks the tile that
+    // realises that split: 64- / 128-row producer/consumer tiles, k_conv_kw, or the 256-row tiles when it has >= 256 of them.
+    // Measured at 4 objects per GPU (profiles/r06_tiles_microbench.txt): 3x3x3 launches -5 ... -15 % on 128-row tiles with half the
+    // slabs of the 256-row split; 1x1 launches with 14-105 K units -20 ... -25 % on k_conv_kw; wide 1x1 launches -15 ... -25 % on
+    // 64-row producer/consumer tiles (no split).
+    int few_ref = 0, few_bm = 0;
+    bool few_kw = false;
+    if (vo("conv_few") != 0 && ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 &&
+        !vo("conv_st_bm") && !vo("conv_kw_ks")) {
+        const long h128 = ((Mh + 127) / 128) * ntn, h64h = ((Mh + 63) / 64) * ((a->N + 111) / 112);
+        if (a->taps == 27 || nks >= 112) {
+            int s2 = (int)((256 + h128 / 2) / h128);
+            s2 = s2 < 1 ? 1 : (s2 > 8 ? 8 : s2);
+            while (s2 > 1 && nks / s2 < 24) --s2;
+            // (very long K on a handful of tiles -- 1344 -> 672 at 16x4x4 with 4 objects -- stays on the 256-row tiles with S = 16)
+            if (!(nks >= 800 && h128 * 8 < 256)) { few_ref = 1; S = s2; }
+        } else if (a->taps == 1) {
+            if (h64h <= 384 && nks >= 12) { few_ref = 2; S = 4; }
+            else { few_ref = 1; S = 1; }
+        }
+        if (few_ref) {
+            const long l128 = ((M + 127) / 128) * ntn, l64h = ((M + 63) / 64) * ((a->N + 111) / 112);
+            if (wg256 >= 256) few_bm = 0;                                          // enough 256-row tiles: they take the split as it is
+            else if (few_ref == 2 && l64h <= 768) few_kw = true;
+            else if (a->taps == 1 && few_ref == 1 && S == 1) few_bm = l128 >= 320 ? 128 : 64;
+            else few_bm = 128;
+        }
+    }
+    if (S < 0 && !few_ref) {                               // auto
         S = 1;
         if (can_split && hg256 < 256 && hg128 < 512) {
             // ~3 workgroups per CU: enough for the dynamic scheduler to balance the tail, few enough that the epilogue
@@ -2796,7 +2843,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         }
     }
     bool split256 = false;
-    if (a->splitk < 0 && S == 1 && can_split && hg256 >= 256) {
+    if (a->splitk < 0 && !few_ref && S == 1 && can_split && hg256 >= 256) {
         // tile quantisation: e.g. 384 workgroups of 256 rows on 256 CUs = 2 rounds, the second half empty.  Split K by
         // the smallest factor that fills the last round (>= 95 %) if the plain launch wastes more than 20 %.
         const long r1 = (hg256 + 255) / 256;
@@ -2807,23 +2854,14 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             }
     }
     if (S <= 1 || !can_split) S = 1;
-    const bool no256 = vo("conv_tile") == 128;               // (route options: es_vol_set_option, no environment access)
-    const bool upm = a->mode == ES_CONV_UP_HW || a->mode == ES_CONV_UP_DHW;
     ES_REQUIRE(!upm || (!a->a2 && a->taps == 27), "es_conv_mfma_f16: nearest-up modes take 3x3x3 convs without a fused skip");
-    const bool force256 = vo("conv_force256") == 1;
     if (force256 && a->splitk < 0 && !split256) S = 1;
-    // k_conv_ws's epilogue is compiled for vector-aligned channels-last outputs addressed with 32-bit element offsets
-    const bool ws_epilogue_ok = !ncdhw && a->N % 4 == 0 && a->out_ld % 4 == 0 && (!a->rowvec || a->rowvec_ld % 4 == 0) &&
-                                M * (long)a->out_ld < (1L << 30) && M * (long)a->N < (1L << 30) &&
-                                (!a->rowvec || (a->D * a->H * a->W) % 64 == 0);      // a wave's 64 rows in one object: rowvec per wave
-    const bool ws = vo("conv_ws") != 0 && ws_epilogue_ok;
-    const bool geglu = a->epilogue == ES_EPI_GEGLU;
     // Small problems (few objects per GPU: the strong-scaling regime, or the 16x4x4 level): fewer than 256 tiles of 256 rows.  The
     // 128- / 64-row kernels below stream the weight tile twice / four times per 256 rows and cost 0.9 us per K unit and workgroup
     // against 0.64 us for a 256-row producer/consumer tile, so keep the 256-row tiles and split K until about one workgroup per
     // CU runs (A/B ES_CONV_WSSPLIT: shape step 21.44 -> 20.76 ms at 32 objects, 13.69 -> 12.61 / 9.22 -> 8.32 / 6.68 -> 6.27 ms at 16 / 8 / 4).
     bool ws_split = false;
-    if (ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 && vo("conv_wssplit") != 0) {
+    if (ws && !geglu && a->splitk < 0 && !few_ref && can_split && hg256 < 256 && !no256 && !force256 && vo("conv_wssplit") != 0) {
         // (hg256: the tile count of the WHOLE problem -- a shard with O_hint makes the choice the unsharded run makes, so its
         //  partial sums are cut in the same places and the results stay bit-identical; it then simply runs fewer workgroups)
         const long wst = vo("conv_wss_target");              // workgroup target of the split (256 = one round)
@@ -2843,13 +2881,13 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     bool deep = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
-        deep = !ws_split && a->splitk <= 0 && !force256 && !no256 && hg256 < 256 && hg64 <= 256 && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME &&
+        deep = !ws_split && !few_ref && a->splitk <= 0 && !force256 && !no256 && hg256 < 256 && hg64 <= 256 && a->taps == 1 && !a->a2 && a->mode == ES_CONV_SAME &&
                nks >= 4 && nks <= 28 && !ncdhw && M * (long)a->Cin * 2 < (1L << 31) && vo("conv_deep") != 0;
     }
     bool tiny_split = false;
     {
         const long hg64 = ((Mh + 63) / 64) * ntn;
-        if (!deep && !ws_split && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
+        if (!deep && !ws_split && !few_ref && a->splitk < 0 && can_split && !force256 && hg256 < 256 && hg128 < 128 && hg64 < 256 && nks >= 10 &&
             vo("conv_tinysplit") != 0) {
             int s3 = (int)((256 + hg64 - 1) / hg64);
             const int s3max = Mh * (long)a->N <= (1L << 22) ? 16 : 8;
@@ -2865,7 +2903,8 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         deep = tiny_split = ws_split = split256 = false;
         S = a->splitk > 1 && can_split && !geglu ? a->splitk : 1;
     }
-    const bool route256 = !st_bm && (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split && !deep;
+    const bool few_small = few_ref && (few_kw || few_bm);      // a few-objects launch on its own kernels (not the 256-row tiles)
+    const bool route256 = !st_bm && !few_small && (wg256 >= 256 || force256 || ws_split) && (S == 1 || split256 || ws_split || wg256 >= 256) && !no256 && !tiny_split && !deep;
     // 1x1 / linear launches with several column tiles: one workgroup walks NCB column tiles of its row tile (k_linear_ws)
     static const char* lin_env = getenv("ES_CONV_LINWS");        // A/B switch: 0 = off
     int ncb = 1;
@@ -2878,12 +2917,14 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     }
     // the producer/consumer 256-row kernel forms the row-group sums of gn_stats_out in its epilogue; every other route runs
     // k_rowgroup_stats over the finished output
-    const bool epi_stats = (route256 || st_bm == 128) && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
+    const bool epi_stats = (route256 || st_bm == 128 || (few_small && few_bm == 128)) && ncb == 1 && ws && !geglu && S == 1 && (a->out_f32 || a->out_f16) && a->N % 4 == 0 && a->out_ld % 4 == 0 &&
                            (a->D * a->H * a->W) % 64 == 0;
     // (bit 1) a split launch can form the next GroupNorm's per-tile partial sums in its reduction kernel (gn_part_out)
-    const bool part_ok = S > 1 && !deep && a->out_f32 && !ncdhw && a->N % 4 == 0 && a->N <= 2048 && a->out_ld == a->N && a->gn_part_groups > 0 &&
+    // (the few-objects routes: from the REFERENCE problem's decision -- K streams inside the workgroup have no reduction launch,
+    //  whatever kernel realises the split in this launch)
+    const bool part_ok = S > 1 && !deep && few_ref != 2 && a->out_f32 && !ncdhw && a->N % 4 == 0 && a->N <= 2048 && a->out_ld == a->N && a->gn_part_groups > 0 &&
                          a->gn_part_groups <= 64 && a->N % a->gn_part_groups == 0;
-    if (emits) { *emits = (epi_stats ? 1 : 0) | (part_ok ? 2 : 0); return 0; }
+    if (emits) { *emits = (epi_stats ? 1 : 0) | (part_ok ? 2 : 0) | ((few_kw ? 1 : S) << 8); return 0; }
     {   // one-off per process, thread-safe: dynamic LDS limits of the conv kernels
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
@@ -2898,11 +2939,6 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             set((const void*)k_conv_lean<256, 8, true>, LDS256);
             set((const void*)k_conv_lean<128, 4, true>, LDS128);
             set((const void*)k_conv_lean<64, 4, true>, LDS64);
-            set((const void*)k_conv_ws<256, 8, 4, false>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, true>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>, LDS256);
-            set((const void*)k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>, LDS256);
             set((const void*)k_linear_deep, 7 * (64 * BK * 2 + BNP * BK * 2));
             set((const void*)k_linear_ws<ES_EPI_NONE>, LDS256 + 8 * 16 * 116 * 4);
             set((const void*)k_linear_ws<ES_EPI_GEGLU>, LDS256 + 8 * 16 * 116 * 4);
@@ -2910,7 +2946,18 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         });
         ES_REQUIRE(attr_err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     }
-    if (kw_ks) {
+    if (few_kw) {
+        if (int rc = launch_kw<4, 1>(a, g, ncdhw, M, ntn, 1, st, upm, geglu)) return rc;
+        S = 1;                                                 // (the four K ranges met in LDS: no slabs, no reduction launch)
+    } else if (few_small) {
+        const dim3 grid((unsigned)((M + few_bm - 1) / few_bm), ntn, S);
+        const bool stt = want_stats && epi_stats;
+        int rc;
+        if (few_bm == 64) rc = launch_ws<64, 4, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else rc = launch_ws<128, 4, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        if (rc) return rc;
+        stats_done = stt;
+    } else if (kw_ks) {
         int rc = 1;
         if (kw_ks == 4) rc = launch_kw<4, 1>(a, g, ncdhw, M, ntn, S, st, upm, geglu);
         else if (kw_ks == 2) rc = launch_kw<2, 2>(a, g, ncdhw, M, ntn, S, st, upm, geglu);
@@ -2922,11 +2969,11 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         const bool stt = want_stats && epi_stats;
         int rc = 1;
         const int ns = vo("conv_st_ns");
-        if (st_bm == 64 && np == 4 && ns == 3) rc = launch_ws_small<64, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (st_bm == 64 && np == 4 && ns == 6) rc = launch_ws_small<64, 4, 6>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (st_bm == 128 && np == 4 && ns == 3) rc = launch_ws_small<128, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (st_bm == 128 && np == 8 && ns == 3) rc = launch_ws_small<128, 8, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (st_bm == 128 && np == 8 && ns == 5) rc = launch_ws_small<128, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        if (st_bm == 64 && np == 4 && ns == 3) rc = launch_ws<64, 4, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 64 && np == 4 && ns == 6) rc = launch_ws<64, 4, 4, 6>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 4 && ns == 3) rc = launch_ws<128, 4, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 8 && ns == 3) rc = launch_ws<128, 4, 8, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+        else if (st_bm == 128 && np == 8 && ns == 5) rc = launch_ws<128, 4, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
         else ES_REQUIRE(false, "es_conv_mfma_f16: conv_st_bm=%d conv_st_np=%d conv_st_ns=%d is not a built tile", st_bm, np, ns);
         if (rc) return rc;
         stats_done = stt;
@@ -2945,14 +2992,16 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             else if (geglu) hipLaunchKernelGGL((k_linear_ws<ES_EPI_GEGLU>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
             else hipLaunchKernelGGL((k_linear_ws<ES_EPI_NONE>), lgrid, dim3(768), LDSLIN, st, *a, g, ncb);
         } else if (ws && (!geglu || !upm)) {
-            if (geglu) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_GEGLU>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
-            else if (want_stats && epi_stats) {       // row-group sums for the next GroupNorm from the epilogue's own values
-                if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true, ES_EPI_NONE, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
-                else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false, ES_EPI_NONE, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
-                stats_done = true;
-            }
-            else if (upm) hipLaunchKernelGGL((k_conv_ws<256, 8, 4, true>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
-            else hipLaunchKernelGGL((k_conv_ws<256, 8, 4, false>), grid, dim3(768), LDS256, st, *a, g, ncdhw);
+            // ring depth of the 256-row tile: 3 (rounds 1-5); ES_CONV_NS = 4 / 5 is a timing-only A/B switch (same K order, same bits)
+            static const char* ns_env = getenv("ES_CONV_NS");
+            const int ns = ns_env ? atoi(ns_env) : 3;
+            const bool stt = want_stats && epi_stats;
+            int rc;
+            if (ns == 4) rc = launch_ws<256, 8, 4, 4>(a, g, ncdhw, grid, st, upm, geglu, stt);
+            else if (ns == 5) rc = launch_ws<256, 8, 4, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
+            else rc = launch_ws<256, 8, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
+            if (rc) return rc;
+            if (stt) stats_done = true;
         }
         else if (upm) hipLaunchKernelGGL((k_conv_lean<256, 8, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
@@ -2970,7 +3019,7 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
         if (a->gn_part_out && part_ok) {
             const int V = a->D * a->H * a->W;
-            const int vt = gn_voxel_tile(a->O_hint > a->O ? a->O_hint : a->O, V);
+            const int vt = gn_voxel_tile(Oh, V);
             hipLaunchKernelGGL(k_conv_splitk_reduce_gn, dim3((V + vt - 1) / vt, a->O), dim3(256), 0, st, *a, M, V, S, vt);
         } else
             hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(blocks), dim3(256), 0, st, *a, M, a->D * a->H * a->W, S);
@@ -3001,13 +3050,21 @@ extern "C" int es_conv_emits_gn_part(const es_conv_args* a) {
     return conv_dispatch(a, nullptr, &e) == 0 ? ((e >> 1) & 1) : -1;
 }
 
+// The number of fp32 slabs [S][M][N] es_conv_mfma_f16(args) writes into args->workspace (1: none -- no split, or K split inside the
+// workgroup), -1 on invalid arguments.  Host-only: the planner sizes the workspace with it.
+extern "C" int es_conv_split_of(const es_conv_args* a) {
+    int e = 0;
+    return conv_dispatch(a, nullptr, &e) == 0 ? (e >> 8) : -1;
+}
+
 extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
     const int C = a->C1 + a->C2;
     ES_REQUIRE(C % a->groups == 0 && C <= 2048 && a->groups <= 64, "es_groupnorm_vol: C=%d groups=%d", C, a->groups);
     ES_REQUIRE(a->C1 % 8 == 0 && a->C2 % 8 == 0, "es_groupnorm_vol: channel counts must be multiples of 8 (%d,%d)", a->C1, a->C2);
     ES_REQUIRE(a->stats != nullptr, "es_groupnorm_vol: stats scratch missing");
     // voxel-tile sizes by workgroup count: small problems (few objects per GPU when sharded) get smaller tiles
-    const long Oh = a->O_hint > a->O ? a->O_hint : a->O;       // tile sizes from the whole problem when this launch is a shard
+    // tile sizes from the whole problem when this launch is a shard (O_hint > O), from the reference shard when O_hint < 0
+    const long Oh = a->O_hint < 0 ? -(long)a->O_hint : (long)(a->O_hint > a->O ? a->O_hint : a->O);
     const int vt = gn_voxel_tile(Oh, a->V);
     const int ntiles = (a->V + vt - 1) / vt;
     float* part = a->stats;      // caller-provided scratch of O*ceil(V/8)*groups*2 floats

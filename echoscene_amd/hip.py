@@ -154,6 +154,7 @@ EXPORTS = {
     'es_conv_mfma_f16': (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     'es_conv_emits_gn_stats': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_conv_emits_gn_part': (C.c_int, [C.POINTER(ConvArgs)]),
+    'es_conv_split_of': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_conv_f16_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -214,7 +215,7 @@ def lib():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)         # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.es_abi_version() != 9:
+        if L.es_abi_version() != 10:
             raise RuntimeError('libechoscene_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -7,10 +7,11 @@ UNet3D forward depends on the other objects only through the 64-d conv-pool code
 latents that feeds the shape GCN ("echo" message passing, openai_model_3d.py:800-814), so the only
 per-step exchange is an all-gather of [O_local, 64] floats (8 KB per step at O=32), after which
 every rank runs the tiny GCN redundantly on the full graph.  At the end the latents (or decoded
-SDFs) are all-gathered.  With ``ShapeDenoiser(deterministic=True)`` (the default) the results are identical to the
-single-GPU run BIT FOR BIT: every kernel treats objects independently, the GCN is computed on the full graph on every
-rank, and every K split / partial-sum tiling is chosen from the layer and the GLOBAL object count (never from the rank's
-share).  ``deterministic=False`` lets each rank tune them to its share: same values up to fp32 summation order.
+SDFs) are all-gathered.  Every kernel treats objects independently and the GCN is computed on the full graph on every rank, so
+the only thing that can differ between world sizes is WHERE a K sum is cut.  ``ShapeDenoiser(deterministic=True)``: the canonical
+cuts of a 4-object reference shard on every rank of every world size -- the results are identical BIT FOR BIT for world = 1, 2, 4,
+8, ....  ``deterministic=False`` (the default since round 6) lets each rank tune the cuts to its share: same values up to fp32
+summation order; at 4 objects per GPU the two modes coincide.
 """
 import torch
 

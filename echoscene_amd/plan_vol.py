@@ -226,20 +226,25 @@ class VolBuilderMixin:
         a.out_f16 = out_f16.data_ptr() if out_f16 is not None else None
         a.out_ld = -1 if ncdhw else (pc.N if out_ld is None else out_ld)
         a.epilogue = epilogue
-        a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem
-        # split-K scratch shared by all convs of the plan (ops are stream-ordered): 8 x the largest small-M output
+        a.O_hint = int(getattr(self, 'o_hint', 0) or 0)      # object sharding: tile / split choices of the whole problem (> 0) / of the reference shard (< 0)
+        # split-K scratch shared by all convs of the plan (ops are stream-ordered): the slabs of the launch that splits widest
         M = O * D * H * W
-        # eligibility from the WHOLE problem's row count (O_hint): a shard and the unsharded run must take the same can_split
-        # decision, or the library picks S from the global tile count for one and S = 1 for the other
-        Mh = max(a.O_hint, O) * D * H * W
+        # eligibility from the WHOLE (or reference) problem's row count (O_hint): a shard and the unsharded run must take the same
+        # can_split decision, or the library picks S from the global tile count for one and S = 1 for the other
+        Mh = (-a.O_hint if a.O_hint < 0 else max(a.O_hint, O)) * D * H * W
         if not ncdhw and Mh * pc.N <= 8192 * 5376 and pc.N % 4 == 0 and not epilogue:
-            need = max(16 if Mh * pc.N <= (1 << 22) else 8, splitk or 0) * M * pc.N     # contract of es_conv_args.splitk = -1
+            a.splitk = -1 if splitk is None else splitk
+            a.workspace = 1                                  # (any non-NULL value: es_conv_split_of only asks whether there is one)
+            S = hip.lib().es_conv_split_of(C.byref(a))       # round 6: the library says how many slabs it will write
+            if S < 0:
+                raise RuntimeError('es_conv_split_of: ' + hip.lib().es_last_error().decode())
+            need = max(S, splitk or 0, 1) * M * pc.N
             if getattr(self, '_ws', None) is None or self._ws.numel() < need:
                 self._ws = self.buf(need, scratch=True)
                 for op in self.ops:
                     if op.kind == hip.OP_CONV and op.u.conv.workspace:
                         op.u.conv.workspace = self._ws.data_ptr()
-            a.workspace, a.splitk = self._ws.data_ptr(), (-1 if splitk is None else splitk)
+            a.workspace = self._ws.data_ptr()
         self.keep += [pc, bt, skip]
         self.weight_bytes += pc.weight_bytes
         self.flops += 2 * O * D * H * W * pc.cin_true * pc.taps * pc.N
@@ -293,11 +298,11 @@ class VolBuilderMixin:
         # (VOL_GN_RG_ANY, tests: ask whatever the route -- the sums then come from k_rowgroup_stats behind the conv)
         if not VOL_GN_RG_ANY:
             q = ConvArgs.from_buffer_copy(op.u.conv)
-            if q.O_hint > q.O:
-                # a deterministic shard takes the decision of the WHOLE problem: where the unsharded run reduces row-group sums
-                # the shard must too (its own launch may be too small for the producer/consumer kernel -- k_rowgroup_stats then
-                # leaves the same bits), or the two runs would normalise with differently rounded statistics
-                q.O, q.O_hint = q.O_hint, 0
+            if q.O_hint > q.O or q.O_hint < 0:
+                # a deterministic shard takes the decision of the WHOLE problem (round 6: of the reference shard, O_hint < 0):
+                # where that run reduces row-group sums every run must too (its own launch may take a route that cannot form them
+                # -- k_rowgroup_stats then leaves the same bits), or two runs would normalise with differently rounded statistics
+                q.O, q.O_hint = abs(q.O_hint), 0
             if hip.lib().es_conv_emits_gn_stats(C.byref(q)) != 1:
                 return None
         return op
@@ -337,8 +342,8 @@ class VolBuilderMixin:
         L = hip.lib()
         if V % 64 == 0 and _gn_rg() and VOL_GN_F16:
             whole = ConvArgs.from_buffer_copy(op.u.conv)
-            if whole.O_hint > whole.O:
-                whole.O, whole.O_hint = whole.O_hint, 0
+            if whole.O_hint > whole.O or whole.O_hint < 0:
+                whole.O, whole.O_hint = abs(whole.O_hint), 0
             if L.es_conv_emits_gn_stats(C.byref(whole)) == 1:
                 st = self.buf(2 * (M // 64) * pc.N, scratch=True)
                 op.u.conv.gn_stats_out = st.data_ptr()

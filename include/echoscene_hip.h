@@ -29,7 +29,7 @@ extern "C" {
 typedef void* es_stream;          /* hipStream_t */
 typedef struct es_plan es_plan;   /* opaque: an ordered list of ops, optionally captured into a hipGraph */
 
-#define ES_ABI_VERSION 9
+#define ES_ABI_VERSION 10
 int es_abi_version(void);
 const char* es_last_error(void);
 /* device name / CU count of the current device (diagnostics for bench.py) */
@@ -255,7 +255,10 @@ typedef struct es_conv_args {
                                  out_ld < 0: out_f32 is written as NCDHW [O, N, D*H*W] (final eps conv)  */
     int32_t O_hint;           /* 0, or the object count of the WHOLE problem when this launch is one shard of it
                                  (multi-GPU object sharding): the split-K factor is then chosen as for the whole problem,
-                                 so that the fp32 partial sums -- and the result -- are bit-identical to the unsharded run */
+                                 so that the fp32 partial sums -- and the result -- are bit-identical to the unsharded run.
+                                 < 0 (round 6, ABI 10): -O_hint is the object count of a REFERENCE shard; the launch cuts K
+                                 where a launch of that many objects is cut best, whatever its own object count -- every rank
+                                 of every world size (1 included) then leaves the same bits (ShapeDenoiser(deterministic=True)) */
     int32_t epilogue;         /* ES_EPI_NONE, or ES_EPI_GEGLU: GEGLU (attention.py:39-46) fused into the FeedForward
                                  proj: the weight rows are packed tile-interleaved -- packed row 16 k + c holds the value
                                  row of output 8 k + c for c < 8 and its gate row (4C + 8 k + c - 8) for c >= 8, i.e. every
@@ -289,6 +292,10 @@ int es_conv_emits_gn_stats(const es_conv_args* args);
 /* host-only: 1 when es_conv_mfma_f16(args) would write gn_part_out (a split-K launch with a channels-last fp32 output), else 0;
  * -1 on invalid arguments.  Launches nothing. */
 int es_conv_emits_gn_part(const es_conv_args* args);
+/* host-only: the number of fp32 slabs [S][M][N] es_conv_mfma_f16(args) writes into args->workspace -- 1 when it writes none (no
+ * split, or K split inside the workgroup); -1 on invalid arguments.  With splitk = -1 the workspace must hold that many slabs (the
+ * bounds stated at `splitk` are the maximum).  Launches nothing. */
+int es_conv_split_of(const es_conv_args* args);
 /* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
  * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
  * block per K step.  h_out holds uint16 bit patterns. */
@@ -308,7 +315,8 @@ typedef struct es_gn_args {
     float* stats;                    /* scratch, O*ceil(V/8)*groups*2 + O*groups*2 floats (per-tile partials, final statistics) */
     void* y_f16;                     /* normalised (+SiLU) output [O, V, C1+C2] f16              */
     void* raw_f16;                   /* optional un-normalised f16 copy of the concat (skip conv) */
-    int32_t O_hint;                  /* 0, or the object count of the whole problem (sharding): partial-sum tiling as unsharded */
+    int32_t O_hint;                  /* 0, or the object count of the whole problem (sharding): partial-sum tiling as unsharded;
+                                        < 0: -O_hint = the object count of the reference shard (es_conv_args.O_hint)          */
     const float* stats1;             /* NULL, or the [2][O*V/64][C1] row-group sums written by the conv that produced x1
                                         (es_conv_args.gn_stats_out); with x2, stats2 [2][O*V/64][C2] must be given too.  When
                                         present the statistics pass over x1 / x2 is skipped: (object, group) statistics are

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(L):
     for name in sorted(declared):
         assert hasattr(raw, name), 'libechoscene_hip.so lacks %s' % name
     assert declared == set(hip.EXPORTS), 'ctypes table and header disagree: %s' % (declared ^ set(hip.EXPORTS))
-    assert L.es_abi_version() == 9
+    assert L.es_abi_version() == 10
 
 
 def test_struct_sizes_match_header(L, tmp_path):
@@ -202,7 +202,9 @@ def test_route_options_are_explicit_and_recorded(L, tmp_path):
     s = buf.value.decode()
     opts = dict(kv.split('=') for kv in s.strip(';').split(';'))
     assert opts == {'rows_family': '1', 'conv_tile': '0', 'conv_force256': '0', 'conv_ws': '1', 'conv_wssplit': '1', 'conv_wss_target': '256',
-                    'conv_deep': '1', 'conv_tinysplit': '1', 'gn_rg': '1'}, opts
+                    'conv_deep': '1', 'conv_tinysplit': '1', 'gn_rg': '1',
+                    # round 6: the few-objects routes (1 = on) and the tools-only forcing switches (0 / defaults = off)
+                    'conv_few': '1', 'conv_st_bm': '0', 'conv_st_np': '4', 'conv_st_ns': '3', 'conv_kw_ks': '0'}, opts
     # set / read back / restore; unknown names are errors
     assert L.es_vol_set_option(b'conv_wss_target', 512) == 0
     L.es_options_string(buf, 1024)
@@ -220,7 +222,7 @@ def test_route_options_are_explicit_and_recorded(L, tmp_path):
             del os.environ[name]
     # no getenv of a numerics-affecting switch is left in the sources: the remaining ones are listed as timing-only / debugging
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    allowed = {'ES_CONV_N16', 'ES_CONV_LINWS', 'ES_LIN_RING', 'ES_DEBUG_SYNC', 'ES_ROWS_FUSE', 'ES_ROWS_PREFETCH', 'ES_ROWS_NT2', 'ES_ROWS_U1', 'ES_ROWS_DBG'}
+    allowed = {'ES_CONV_N16', 'ES_CONV_LINWS', 'ES_LIN_RING', 'ES_LIN_NCB_MAX', 'ES_CONV_NS', 'ES_DEBUG_SYNC', 'ES_ROWS_FUSE', 'ES_ROWS_PREFETCH', 'ES_ROWS_NT2', 'ES_ROWS_U1', 'ES_ROWS_DBG'}
     found = set()
     for f in os.listdir(os.path.join(here, 'echoscene_amd', 'csrc')):
         if f.endswith(('.hip', '.h')):

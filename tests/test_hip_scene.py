@@ -576,7 +576,7 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
         env = dict(os.environ, ES_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
                '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '3', '--warmup', '1',
-               '--no-cpu-baseline', '--no-sub-records', '--nodes', '8', '--check']          # default mode: bit-exact shards
+               '--no-cpu-baseline', '--no-sub-records', '--nodes', '8', '--check', '--deterministic']      # the canonical arithmetic: bit-exact across world sizes
         r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
@@ -587,7 +587,7 @@ def test_bench_two_ranks_on_one_gpu_strong_and_weak():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env['ES_DIST_BACKEND'] = 'gloo'
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
-           '--no-sub-records', '--nodes', '8', '--check']
+           '--no-sub-records', '--nodes', '8', '--check', '--deterministic']
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]

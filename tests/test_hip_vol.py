@@ -600,13 +600,17 @@ def test_unet3d_full_eps_O32_vs_reference_golden(dev):
 
 
 @pytest.mark.parametrize('mc,ctx,prefix,world,O', [(32, 64, 'unet3d_tiny.', 2, 4), (224, 1280, 'unet3d_full.', 4, 4),
-                                                    (224, 1280, 'unet3d_full.', 8, 32)])
+                                                    (224, 1280, 'unet3d_full.', 8, 32), (224, 1280, 'unet3d_full.', 2, 32),
+                                                    (224, 1280, 'unet3d_full.', 3, 10)])
 def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world, O):
     """the sharded result must equal the single-GPU result BIT FOR BIT.  The multi-GPU decomposition
-    on one GPU: ``world`` shards stepped with a simulated all-gather.  Every kernel treats objects independently; what used
-    to differ was the fp32 summation order, because split-K factors and GroupNorm partial-sum tiles were picked from the
-    LOCAL object count -- shards now pass the global count (es_conv_args.O_hint / es_gn_args.O_hint) and all conv kernels
-    cut split-K ranges in the same places, so the tile size chosen per launch no longer matters."""
+    on one GPU: ``world`` shards stepped with a simulated all-gather.  Every kernel treats objects independently; what can
+    differ is the fp32 summation order, when split-K factors and GroupNorm partial-sum tiles are picked from the LOCAL object
+    count.  ``deterministic=True`` (round 6): every rank of every world size -- 1 included -- takes the cuts of a 4-object
+    reference shard (es_conv_args.O_hint / es_gn_args.O_hint < 0), all conv kernels cut split-K ranges in the same places and K
+    streams inside a workgroup are added in the order of the reduction kernel, so neither the tile nor the kernel chosen per
+    launch matters: 32 objects over 8 ranks (4 each: the reference itself), over 2 ranks (16 each: the 256-row tiles take the
+    reference's splits), 10 objects over 3 ranks (4 + 4 + 2)."""
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     objs, triples = synth.synthetic_graph(O, seed=6)
@@ -618,8 +622,8 @@ def test_object_shards_equal_unsharded_bitwise(dev, mc, ctx, prefix, world, O):
     synth.seeded_fill_(df, prefix=prefix)
     mpar = escfg.shape_df_conf().model.params
     nst = 4 if O <= 4 else 2                 # (the benchmarked decomposition: 32 objects over 8 ranks, full width)
-    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev).sample(uc, triples, noise1, n_steps=nst)
-    shards = [ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, rank=r, world=world) for r in range(world)]      # DEFAULT constructor: bit-exact shards
+    z_ref = ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, deterministic=True).sample(uc, triples, noise1, n_steps=nst)
+    shards = [ShapeDenoiser(df, mpar, ddim_steps=4, device=dev, rank=r, world=world, deterministic=True) for r in range(world)]
     for sh in shards:
         st = sh._plan_for(uc, triples)
         st['x'].copy_(noise1.to(dev).expand(st['hi'] - st['lo'], 3, 16, 16, 16))
@@ -691,6 +695,26 @@ def test_tuned_object_shards_vs_reference_trajectory_O16(dev):
         assert torch.allclose(z, g['z_steps'][k - 1], atol=2e-2, rtol=2e-2), (k, mx)
         del shards
         torch.cuda.empty_cache()
+
+
+def test_canonical_run_vs_reference_trajectory_O16(dev):
+    """``deterministic=True`` at world 1: 16 objects on one GPU with the K cuts of the 4-object reference shard (the 256-row tiles
+    take splits they would not choose for themselves) against the REFERENCE's own DDIMSampler (``shape_traj_full_O16``), and
+    bit for bit against 4 canonical shards of 4 objects.  Bar: the product path's fp16-operand tolerance."""
+    from echoscene_amd.model.unet import DiffusionUNet
+    from echoscene_amd.samplers import ShapeDenoiser
+    g = load_golden('shape_traj_full_O16')
+    df = DiffusionUNet(escfg.shape_unet_params(224))
+    synth.seeded_fill_(df, prefix='unet3d_full.')
+    mpar = escfg.shape_df_conf().model.params
+    noise1 = synth.shape_noise(seed=7)
+    z1 = ShapeDenoiser(df, mpar, ddim_steps=100, device=dev, deterministic=True).sample(g['uc_s'], g['triples'], noise1, n_steps=2)
+    mx = (z1.cpu() - g['z_steps'][1]).abs().max().item()
+    print('canonical arithmetic, 16 objects on one GPU, 2 DDIM steps vs the reference trajectory: max abs err %.2e' % mx)
+    assert torch.allclose(z1.cpu(), g['z_steps'][1], atol=2e-2, rtol=2e-2), mx
+    shards = [ShapeDenoiser(df, mpar, ddim_steps=100, device=dev, rank=r, world=4, deterministic=True) for r in range(4)]
+    z4 = _run_shards(shards, g['uc_s'], g['triples'], noise1, 2, dev)
+    assert torch.equal(z4, z1), 'max abs diff %.3e' % (z4 - z1).abs().max().item()
 
 
 # ---- SURVEY.md section 8(f) rank 2: 'concat'-conditioned shape denoiser (sdfusion-txt2shape_concat_mp.yaml) ----

@@ -10,6 +10,9 @@ from echoscene_amd.plan import Builder
 
 O = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device('cuda')
+for _kv in [x for x in os.environ.get('ES_TOOL_VOL_OPTIONS', '').split(',') if x]:      # route options of this run: "name=value,..."
+    from echoscene_amd import hip as _hip
+    _hip.check(_hip.lib().es_vol_set_option(_kv.split('=')[0].encode(), int(_kv.split('=')[1])), 'es_vol_set_option')
 _, triples = synth.synthetic_graph(O, seed=100)
 df, sden, uc = bench.build_shape(dev, O, 100, triples)
 noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)

@@ -12,11 +12,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--nodes', type=int, default=32)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--worlds', default='1,2,4,8')
-ap.add_argument('--deterministic', action='store_true', help='(the default since round 4; kept for old command lines)')
-ap.add_argument('--tuned', action='store_true', help='every shard tunes K splits to its local object count (not bit-exact across world sizes)')
+ap.add_argument('--deterministic', action='store_true', help='the canonical arithmetic (K splits of a 4-object reference shard at every world size, 1 included: bit-exact across world sizes)')
+ap.add_argument('--tuned', action='store_true', help='every shard tunes K splits to its local object count (the default since round 6; kept for old command lines)')
 ap.add_argument('--weak', action='store_true', help='batch of <world> scenes, one per rank (bench.py --scaling weak)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
+for _kv in [x for x in os.environ.get('ES_TOOL_VOL_OPTIONS', '').split(',') if x]:      # route options of this run: "name=value,..."
+    from echoscene_amd import hip as _hip
+    _hip.check(_hip.lib().es_vol_set_option(_kv.split('=')[0].encode(), int(_kv.split('=')[1])), 'es_vol_set_option')
 O = a.nodes
 net, lden, obj_embed, triples = bench.build_layout(dev, O, seed=100)
 
@@ -35,7 +38,7 @@ for w in [int(x) for x in a.worlds.split(',')]:
         from echoscene_amd import synth
         _, triples = synth.collate_graphs([synth.synthetic_graph(a.nodes, seed=100 + s) for s in range(w)])
         O = a.nodes * w
-    df, sden, uc = bench.build_shape(dev, O, 100, triples, 0, w, deterministic=not a.tuned)
+    df, sden, uc = bench.build_shape(dev, O, 100, triples, 0, w, deterministic=a.deterministic)
     noise1 = torch.randn(1, 3, 16, 16, 16, device=dev)
     sden.sample(uc, triples, noise1=noise1, n_steps=3)
     ss = next(iter(sden._plans.values()))

@@ -11,9 +11,13 @@ from echoscene_amd.plan import Builder
 ap = argparse.ArgumentParser()
 ap.add_argument('--world', type=int, default=8)
 ap.add_argument('--nodes', type=int, default=32)
-ap.add_argument('--tuned', action='store_true')
+ap.add_argument('--tuned', action='store_true', help='(default)')
+ap.add_argument('--deterministic', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda')
+for _kv in [x for x in os.environ.get('ES_TOOL_VOL_OPTIONS', '').split(',') if x]:      # route options of this run: "name=value,..."
+    from echoscene_amd import hip as _hip
+    _hip.check(_hip.lib().es_vol_set_option(_kv.split('=')[0].encode(), int(_kv.split('=')[1])), 'es_vol_set_option')
 O = a.nodes
 _, triples = synth.synthetic_graph(O, seed=100)
 
@@ -26,7 +30,7 @@ def fake_gather(local, num_rows, world, group=None, out=None):
 
 
 parallel.all_gather_rows = fake_gather
-df, sden, uc = bench.build_shape(dev, O, 100, triples, 0, a.world, deterministic=not a.tuned)
+df, sden, uc = bench.build_shape(dev, O, 100, triples, 0, a.world, deterministic=a.deterministic)
 noise1 = torch.randn(1, 3, 16, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
 sden.sample(uc, triples, noise1=noise1, n_steps=1, use_graph=True)
 ss = next(iter(sden._plans.values()))
@@ -74,7 +78,7 @@ for key, (fl, ops) in groups.items():
     rows.append((best * len(ops), len(ops), best, fl / best / 1e6 if fl else 0.0, key))
 tot = sum(r[0] for r in rows)
 print('# world %d (%d objects on this rank), %s shards: %d ops per step, summed stand-alone time %.3f ms'
-      % (a.world, Ol, 'tuned' if a.tuned else 'bit-exact', sum(r[1] for r in rows), tot / 1e3))
+      % (a.world, Ol, 'bit-exact' if a.deterministic else 'tuned', sum(r[1] for r in rows), tot / 1e3))
 bykind = collections.OrderedDict()
 for t, n, us, tf, key in rows:
     e = bykind.setdefault(key[0] + ('27' if key[0] == 'conv' and key[1] == 27 else ''), [0.0, 0])
