@@ -231,6 +231,38 @@ def fp32_route_record(dev, df, sden, uc, triples, conf_params, use_graph, n=2):
     return rec
 
 
+def fp32x_route_record(dev, df, sden, uc, triples, conf_params, use_graph, n=3):
+    """Round 6: the SPLIT-OPERAND route (ShapeDenoiser(precision='fp32x')) at the benchmarked shape -- fp32 activations,
+    fp32 attention / norms, every contraction as three f16 partial products (hi x hi + lo x hi + hi x lo, fp32 accumulate) on the
+    product kernels: the reference's arithmetic to ~2^-21 per product as a USABLE mode (the 'fp32' route runs the 1/16-rate fp32
+    matrix instruction).  Its step time, the matrix rate on the 3x FLOPs it executes, and its difference to the 'fp32' route."""
+    from echoscene_amd.samplers import ShapeDenoiser
+    O = uc.shape[0]
+    denx = ShapeDenoiser(df, conf_params, ddim_steps=100, device=dev, precision='fp32x')
+    x = torch.randn(O, 3, 16, 16, 16, generator=torch.Generator().manual_seed(21))
+    ex = denx.eps(x, uc, triples, iteration=50)
+    e16 = sden.eps(x, uc, triples, iteration=50)
+    d = (e16 - ex).double()
+    rel_rms = (d.pow(2).mean().sqrt() / ex.double().pow(2).mean().sqrt()).item()
+    ss = next(iter(denx._plans.values()))
+    ss['plan'].sample(ss['step'], 0, 1, use_graph=use_graph)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record(); ss['plan'].sample(ss['step'], 0, n, use_graph=use_graph); e[1].record()
+    torch.cuda.synchronize()
+    ms = e[0].elapsed_time(e[1]) / n
+    tf = 3.0 * ss['plan'].flops / (ms * 1e-3) / 1e12           # executed: three f16 partial products per product of the model
+    rec = {'config': 'split-operand route of the shape step (precision=fp32x: fp32 activations, contractions as 3 f16 partial products with fp32 '
+                     'accumulate on the product kernels), %d objects' % O,
+           'metric': 'shape steps/s', 'value': round(1e3 / ms, 4), 'ms_per_step': round(ms, 2), 'steps_timed': n, 'dtype': 'f32 activations, 2 x f16 split operands, f32 accumulate',
+           'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 4), 'kernel': 'whole step, executed FLOPs (3 x the model FLOPs)'},
+           'fp16_product_vs_fp32x_route_eps': {'rel_rms': rel_rms, 'what': 'one UNet3D + echo-GCN evaluation at DDIM iteration 50, same weights / inputs'}}
+    del denx, ss
+    torch.cuda.empty_cache()
+    return rec
+
+
 def configs4_record(dev, use_graph, scenes=8, O=32, n=5):
     """BASELINE configs[4] as ONE rank of the 8-GPU batch run sees it (64 scenes x 32 nodes over 8 GPUs = 8 scenes = 256 objects per
     GPU, partitioned by scene: no collective inside the steps), measured on this GPU: scene-steps/s and the roofline of the shape
@@ -713,6 +745,7 @@ def main():
             out['sub_records'] = sub_records(dev, lay, use_graph, a)
             try:
                 from echoscene_amd import config as escfg
+                out['sub_records'].append(fp32x_route_record(dev, df, sden, uc, triples_all, escfg.shape_df_conf(224).model.params, use_graph))
                 out['sub_records'].append(fp32_route_record(dev, df, sden, uc, triples_all, escfg.shape_df_conf(224).model.params, use_graph))
             except Exception as exc:                  # (a validation figure must not take the benchmark line down)
                 out['sub_records'].append({'config': 'fp32-operand validation route', 'error': repr(exc)})

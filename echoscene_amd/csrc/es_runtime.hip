@@ -63,6 +63,8 @@ static int dispatch(const es_op& op, hipStream_t s) {
         case ES_OP_ATTN: return es_attention_f16(&op.u.attn, s);
         case ES_OP_GEGLU: return es_geglu_f16(&op.u.geglu, s);
         case ES_OP_TO_CL:
+            if (op.u.tocl.out_is_f32 == 2)       // split-operand image of a channels-last fp32 tensor [O rows, C] (precision 'fp32x')
+                return es_split_f16x3(op.u.tocl.x, (long)op.u.tocl.O * op.u.tocl.V, op.u.tocl.C, op.u.tocl.out, s);
             return op.u.tocl.out_is_f32 ? es_latent_to_cl_f32(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s)
                                         : es_latent_to_cl_f16(op.u.tocl.x, op.u.tocl.O, op.u.tocl.C, op.u.tocl.V, op.u.tocl.Cpad, op.u.tocl.out, s);
         case ES_OP_CONV_F32: return es_conv_f32(&op.u.conv, s);

@@ -318,6 +318,27 @@ __global__ __launch_bounds__(256) void k_to_cl(const float* x, int O, int C, int
     }
 }
 
+// Split-operand image of an fp32 activation (round 6, precision 'fp32x'): x = hi + lo with hi = f16(x), lo = f16(x - hi) -- 22 bits of
+// the mantissa in two f16 values.  out[m] = [hi(0..C) | lo(0..C) | hi(0..C)] (3C channels): against the weight image [w_hi | w_hi | w_lo]
+// the ordinary f16 contraction accumulates hi w_hi + lo w_hi + hi w_lo in fp32 -- the product to ~2^-21 relative (the lo x lo term
+// is below that), at 3x the K of the f16 route instead of the 1/16 matrix rate of the fp32 instruction.
+__global__ __launch_bounds__(256) void k_split_f16x3(const float* __restrict__ x, long M, int C, _Float16* __restrict__ out) {
+    const int c4n = C >> 2;
+    const long n = M * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long m = i / c4n;
+        const int c = (int)(i - m * c4n) << 2;
+        const f4 v = *(const f4*)(x + m * C + c);
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+        _Float16* o = out + m * 3 * C + c;
+        *(h4*)o = hi;
+        *(h4*)(o + C) = lo;
+        *(h4*)(o + 2 * C) = hi;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // conv-pool stem of shape_messsage_passing (openai_model_3d.py:757-764), fp32, tiny.
 //   stage 1: Conv3d(3|4->32,k3,p1) @16^3 then MaxPool3d(2,2)  -> [O,32,8,8,8]   (4 input channels: 'concat' family)
@@ -2815,9 +2836,12 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (a->taps == 27 || nks >= 112) {
             int s2 = (int)((256 + h128 / 2) / h128);
             s2 = s2 < 1 ? 1 : (s2 > 8 ? 8 : s2);
+            while (s2 > 1 && h128 * s2 > 272) --s2;                               // never a second round of workgroups
             while (s2 > 1 && nks / s2 < 24) --s2;
-            // (very long K on a handful of tiles -- 1344 -> 672 at 16x4x4 with 4 objects -- stays on the 256-row tiles with S = 16)
-            if (!(nks >= 800 && h128 * 8 < 256)) { few_ref = 1; S = s2; }
+            // (very long K on a handful of tiles -- 1344 -> 672 at 16x4x4 with 4 objects -- stays on the 256-row tiles with S = 16;
+            //  an UNSPLIT launch that would leave a quarter of the CUs idle -- 192 tiles of 128 rows: the 16x4x4 level at 32 objects --
+            //  stays on the 256-row tiles with S = 2: the same workgroup count on the tile that moves fewer bytes, 169 against 179 us)
+            if (!(nks >= 800 && h128 * 8 < 256) && (s2 >= 2 || h128 >= 224)) { few_ref = 1; S = s2; }
         } else if (a->taps == 1) {
             if (h64h <= 384 && nks >= 12) { few_ref = 2; S = 4; }
             else { few_ref = 1; S = 1; }
@@ -3136,6 +3160,15 @@ static int latent_to_cl(const float* x, int O, int C, int V, int Cpad, void* out
 }
 extern "C" int es_latent_to_cl_f16(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) { return latent_to_cl(x, O, C, V, Cpad, out, 0, stream); }
 extern "C" int es_latent_to_cl_f32(const float* x, int O, int C, int V, int Cpad, void* out, es_stream stream) { return latent_to_cl(x, O, C, V, Cpad, out, 1, stream); }
+
+extern "C" int es_split_f16x3(const float* x, long M, int C, void* out, es_stream stream) {
+    ES_REQUIRE(x && out && M > 0 && C > 0 && C % 4 == 0, "es_split_f16x3: M=%ld C=%d (C a multiple of 4)", M, C);
+    const long n = M * (C / 4);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_split_f16x3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, M, C, (_Float16*)out);
+    ES_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int es_shape_stem(const es_stem_args* a, es_stream stream) {
     const long n1 = (long)a->O * 32 * 512, n2 = (long)a->O * 512;

@@ -155,6 +155,7 @@ EXPORTS = {
     'es_conv_emits_gn_stats': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_conv_emits_gn_part': (C.c_int, [C.POINTER(ConvArgs)]),
     'es_conv_split_of': (C.c_int, [C.POINTER(ConvArgs)]),
+    'es_split_f16x3': (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     'es_pack_conv_f16_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'es_pack_conv_f16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'es_pack_conv_f16_dev': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -98,12 +98,32 @@ class PackedConv32:
         self.cin_true = cin
 
 
+class PackedConvX3(PackedConv):
+    """Split-operand weight image (round 6, precision 'fp32x'): w = w_hi + w_lo in f16 (22 bits of the mantissa), packed as ONE f16
+    image over 3 Cin channels [w_hi | w_hi | w_lo] -- against the activation image [a_hi | a_lo | a_hi] (es_split_f16x3) the ordinary
+    f16 contraction accumulates a_hi w_hi + a_lo w_hi + a_hi w_lo in fp32.  ``cin_part``: channels of one part (Cin of the fp32
+    operand, padded to 32); GEGLU is applied by its own kernel, as on the fp32 route."""
+
+    def __init__(self, W, b, device, geglu=False):
+        W = W.detach().float()
+        cin = W.shape[1]
+        cp = (cin + 31) // 32 * 32
+        if cp != cin:
+            pad = torch.zeros((W.shape[0], cp - cin) + tuple(W.shape[2:]), dtype=W.dtype, device=W.device)
+            W = torch.cat([W, pad], 1)
+        hi = W.half().float()
+        lo = (W - hi).half().float()
+        super().__init__(torch.cat([hi, hi, lo], 1), b, device, geglu=False)
+        self.cin_part, self.cin_true = cp, cin
+        self.weight_bytes = self.N * cin * self.taps * 6
+
+
 class UNet3DWeights:
     def __init__(self, sd, net, device, precision='fp16'):
         """sd: state_dict of the UNet3DModel holder ``net`` (keys without 'diffusion_net.').  ``precision='fp32'``: fp32 weight
         images for the fp32-operand validation route."""
         self.precision = precision
-        PackedConv = globals()['PackedConv32' if precision == 'fp32' else 'PackedConv']
+        PackedConv = globals()[{'fp32': 'PackedConv32', 'fp32x': 'PackedConvX3'}.get(precision, 'PackedConv')]
         self.device, self.mc, self.topo = device, net.model_channels, net.topo
         self.enable_t_emb, self.mp = net.enable_t_emb, net.messsage_passing
         self.heads = net.num_heads
@@ -207,7 +227,18 @@ class VolBuilderMixin:
              out_f16=None, skip=None, ncdhw=False, splitk=None, epilogue=0, out_ld=None):
         """dims = (D,H,W) of the OUTPUT grid. skip = (raw_f16 tensor, PackedConv) for the fused 1x1 skip."""
         D, H, W = dims
-        if getattr(self, 'fp32', False):
+        if getattr(self, 'fp32x', False) and a_f16.dtype == torch.float32:
+            # split-operand route: the fp32 operand(s) -> [hi | lo | hi] f16 images, then the ordinary f16 launch on 3 Cin channels; an
+            # f16 operand copy of the output is the fp32 output itself, as on the fp32 route
+            assert isinstance(pc, PackedConvX3) and not epilogue
+            a3 = self.split3(a_f16, pc.cin_part)
+            if skip is not None:
+                skip = (self.split3(skip[0], skip[1].cin_part), skip[1])
+            out = out_f32 if out_f32 is not None else out_f16
+            assert out is not None and out.dtype == torch.float32 and (out_f32 is None or out_f16 is None)
+            return self.conv(a3, pc, O, dims, mode=mode, bias=bias, rowvec=rowvec, res=res, out_f32=out, skip=skip, ncdhw=ncdhw,
+                             splitk=splitk, out_ld=out_ld)
+        if getattr(self, 'fp32', False) and not getattr(self, 'fp32x', False):
             return self._conv32(a_f16, pc, O, dims, mode, bias, rowvec, res, out_f32, out_f16, skip, ncdhw, out_ld)
         a = ConvArgs()
         a.a, a.w = a_f16.data_ptr(), pc.w.data_ptr()
@@ -255,6 +286,15 @@ class VolBuilderMixin:
                 self._conv_of = {}
             self._conv_of[out_f32.data_ptr()] = (idx, M, pc.N)
         return idx
+
+    def split3(self, x32, C):
+        """f16 [rows, 3 C] split-operand image of the fp32 tensor x32 [rows, C] (es_split_f16x3), as one op of the plan"""
+        rows = x32.numel() // C
+        out = self.buf(rows, 3 * C, dtype=torch.float16, scratch=True)
+        a = ToClArgs()
+        a.x, a.O, a.C, a.V, a.Cpad, a.out, a.out_is_f32 = x32.data_ptr(), rows, C, 1, C, out.data_ptr(), 2
+        self._push(hip.OP_TO_CL, 'tocl', a)
+        return out
 
     def _conv32(self, a32, pc, O, dims, mode, bias, rowvec, res, out_f32, out_f16, skip, ncdhw, out_ld):
         """fp32-operand validation route: the same launch on es_conv_f32 (fp32 activations / weights, exact-fp32 MFMA).  A request
@@ -473,7 +513,8 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     O = Ofull
     D0, H0, W0 = dims
     V0 = D0 * H0 * W0
-    b.fp32 = getattr(w, 'precision', 'fp16') == 'fp32'     # fp32-operand validation route (csrc/es_vol32.hip)
+    b.fp32x = getattr(w, 'precision', 'fp16') == 'fp32x'   # round 6: fp32 activations, split-operand f16 contractions (3 x the K)
+    b.fp32 = b.fp32x or getattr(w, 'precision', 'fp16') == 'fp32'     # fp32-operand routes: every operand buffer of the plan is fp32
     f16 = torch.float32 if b.fp32 else torch.float16       # dtype of every contraction OPERAND buffer of the plan
     # ---- per-object (rows path) ----
     emb = None
@@ -630,8 +671,9 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
             dm = state['dims']
             M = O * V_(dm)
             if kind == 'conv_in':
-                xcl = sbuf(O * V0, d['conv'].Cin, dtype=f16)        # (channels padded to the weight image's Cin: 32, fp32 route 16)
-                b.to_cl(xc if w.concat else x, O, w.in_ch, V0, d['conv'].Cin, xcl)
+                cpad = getattr(d['conv'], 'cin_part', d['conv'].Cin)
+                xcl = sbuf(O * V0, cpad, dtype=f16)                 # (channels padded to the weight image's Cin: 32, fp32 route 16)
+                b.to_cl(xc if w.concat else x, O, w.in_ch, V0, cpad, xcl)
                 o = sbuf(M, mc)
                 state['last_op'] = b.conv(xcl, d['conv'], O, dm, out_f32=o)
                 state.update(h=o, C=mc, h16=None)

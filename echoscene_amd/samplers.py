@@ -162,8 +162,11 @@ class ShapeDenoiser:
         arithmetic (openai_model_3d.py:816-863 is fp32 everywhere), so that the cost of operand rounding is a measurement."""
         # ``ddim_eta`` != 0: stochastic DDIM -- every step adds sigma_t * randn (samplers/ddim.py:256-260); the draws of a run are a
         # device table [S, objects x latent] filled per sample() (or handed in: ``step_noise``)
-        if precision not in ('fp16', 'fp32'):
-            raise ValueError("precision must be 'fp16' or 'fp32'")
+        # 'fp32x' (round 6): fp32 activations, fp32 attention / norms, and every contraction on the f16 matrix pipe with SPLIT operands
+        # (x = hi + lo in f16, three partial products accumulated in fp32: plan_vol.PackedConvX3) -- the reference's arithmetic to
+        # ~2^-21 per product at 3x the K of the product route, instead of the 1/16 matrix rate of 'fp32'
+        if precision not in ('fp16', 'fp32', 'fp32x'):
+            raise ValueError("precision must be 'fp16', 'fp32' or 'fp32x'")
         self.precision = precision
         self.force_exchange = bool(force_exchange)
         self.device = device or torch.device('cuda')

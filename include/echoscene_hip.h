@@ -296,6 +296,10 @@ int es_conv_emits_gn_part(const es_conv_args* args);
  * split, or K split inside the workgroup); -1 on invalid arguments.  With splitk = -1 the workspace must hold that many slabs (the
  * bounds stated at `splitk` are the maximum).  Launches nothing. */
 int es_conv_split_of(const es_conv_args* args);
+/* Split-operand image of an fp32 activation [M, C] (C % 4 == 0): out f16 [M, 3 C] = [hi | lo | hi], hi = f16(x), lo = f16(x - hi).
+ * Against a weight image packed from [w_hi | w_hi | w_lo] (Cin = 3 C) es_conv_mfma_f16 accumulates hi w_hi + lo w_hi + hi w_lo in
+ * fp32: the reference's fp32 arithmetic to ~2^-21 per product on the f16 matrix pipe (ShapeDenoiser(precision='fp32x')). */
+int es_split_f16x3(const float* x, long M, int C, void* out, es_stream stream);
 /* host helpers: pack a PyTorch conv/linear weight [N, Cin, kd,kh,kw] (or [N, Cin]) into the f16 image the kernel
  * streams: [n-tile of 224][K step = (Cin chunk of 32, tap)][256 rows x 64 B, swizzled] -- one contiguous 16 KiB
  * block per K step.  h_out holds uint16 bit patterns. */
@@ -419,6 +423,8 @@ typedef struct es_copy_args {      /* device-to-device copy: flat (rows <= 1) or
     int32_t rows; size_t dst_pitch, src_pitch;
 } es_copy_args;
 typedef struct es_tocl_args { const float* x; int32_t O, C, V, Cpad; void* out; int32_t out_is_f32; } es_tocl_args;
+/* out_is_f32: 0 f16 / 1 fp32 channels-last copy of an NCDHW tensor; 2 (round 6): x is channels-last fp32 [O * V, C] already and out
+ * is its split-operand image f16 [O * V, 3 C] = [hi | lo | hi] (es_split_f16x3, ShapeDenoiser(precision='fp32x')) */
 typedef struct es_op {
     int32_t kind;
     int32_t lane;    /* execution lane (0 = main stream; >0 = side stream forked/joined with ES_OP_FORK/JOIN) */

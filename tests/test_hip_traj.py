@@ -91,23 +91,26 @@ def _iou(sdf, occ_bits):
     return inter / max(union, 1), occ.mean(), ref.mean()
 
 
-def test_shape_100_ddim_steps_fp32_operand_route_vs_reference(dev):
+@pytest.mark.parametrize('precision', ['fp32', 'fp32x'])
+def test_shape_100_ddim_steps_fp32_operand_route_vs_reference(dev, precision):
     """VERDICT r3 #7 / SURVEY.md 8(c) "fp32 HIP path: atol 1e-3 on final latents": all 100 DDIM steps at model_channels 224 (O = 4) with
     ShapeDenoiser(precision='fp32') -- the reference's arithmetic (fp32 operands, exact-fp32 MFMA) on the same plan -- against the
-    reference's own trajectory.  Turns "fp16 operands are fine" into a measurement: printed next to it is the fp16 product route."""
+    reference's own trajectory.  Turns "fp16 operands are fine" into a measurement: printed next to it is the fp16 product route.
+    Round 6, precision='fp32x': the same bar for the split-operand route (three f16 partial products per contraction on
+    the product kernels, fp32 activations / attention / norms) -- the mode that makes the reference's arithmetic usable."""
     from echoscene_amd.model.unet import DiffusionUNet
     from echoscene_amd.samplers import ShapeDenoiser
     g = load_golden('shape_traj_full')
     df = DiffusionUNet(escfg.shape_unet_params(224))
     synth.seeded_fill_(df, prefix='unet3d_full.')
-    den = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=100, device=dev, precision='fp32')
+    den = ShapeDenoiser(df, escfg.shape_df_conf().model.params, ddim_steps=100, device=dev, precision=precision)
     noise1 = synth.shape_noise(seed=7)
     steps = [int(s) for s in g['steps']]
     print()
     for k, zr in zip(steps, g['z_steps']):
         z = den.sample(g['uc_s'], g['triples'], noise1, n_steps=k)
         mx, rms, _ = _errs(z, zr)
-        print('fp32-operand route, shape O=4 mc=224, %3d DDIM steps: max abs err %.2e  rel rms %.2e' % (k, mx, rms))
+        print('%s route, shape O=4 mc=224, %3d DDIM steps: max abs err %.2e  rel rms %.2e' % (precision, k, mx, rms))
         assert torch.allclose(z.cpu(), zr, atol=1e-3, rtol=1e-3), (k, mx)
 
 
