@@ -149,6 +149,14 @@ extern "C" int es_plan_run(es_plan* p, es_stream stream) {
             if (op.kind == ES_OP_LINEAR)
                 fprintf(stderr, " M=%d K=%d N=%d pro=%d nseg=%d modes=%d,%d,%d", op.u.linear.M, op.u.linear.K, op.u.linear.N,
                         op.u.linear.prologue, op.u.linear.nseg, op.u.linear.seg[0].mode, op.u.linear.seg[1].mode, op.u.linear.seg[2].mode);
+            if (op.kind == ES_OP_CONV)
+                fprintf(stderr, " taps=%d Cin=%d+%d N=%d O=%d(%d) %dx%dx%d mode=%d epi=%d splitk=%d ws=%d res=%d f32=%d f16=%d gnst=%d gnpart=%d", op.u.conv.taps, op.u.conv.Cin,
+                        op.u.conv.a2 ? op.u.conv.Cin2 : 0, op.u.conv.N, op.u.conv.O, op.u.conv.O_hint, op.u.conv.D, op.u.conv.H, op.u.conv.W, op.u.conv.mode,
+                        op.u.conv.epilogue, op.u.conv.splitk, op.u.conv.workspace != nullptr, op.u.conv.res != nullptr, op.u.conv.out_f32 != nullptr,
+                        op.u.conv.out_f16 != nullptr, op.u.conv.gn_stats_out != nullptr, op.u.conv.gn_part_out != nullptr);
+            if (op.kind == ES_OP_GN)
+                fprintf(stderr, " C=%d+%d O=%d(%d) V=%d groups=%d f16src=%d part_in=%d stats1=%d", op.u.gn.C1, op.u.gn.C2, op.u.gn.O, op.u.gn.O_hint, op.u.gn.V, op.u.gn.groups,
+                        op.u.gn.x1_is_f16, op.u.gn.part_in != nullptr, op.u.gn.stats1 != nullptr);
             fprintf(stderr, "\n");
             fflush(stderr);
         }

@@ -3108,7 +3108,10 @@ extern "C" int es_groupnorm_vol(const es_gn_args* a, es_stream stream) {
         hipLaunchKernelGGL(k_gn_finalize_rg, dim3(a->groups, a->O), dim3(256), 0, (hipStream_t)stream, *a, part);
         fin = part;
     } else if (ntiles > 128) {
-        float* f = part + (size_t)a->O * ntiles * a->groups * 2;
+        // (with part_in the partials live in the PRODUCER's buffer, which has no room behind them: the final statistics go to the
+        //  front of the caller's own scratch then.  Until round 6 they were written behind part_in -- 256 bytes past the end of a
+        //  buffer that ends on a page boundary was a GPU memory fault at one object per GPU, 16^3 level)
+        float* f = a->part_in ? a->stats : part + (size_t)a->O * ntiles * a->groups * 2;
         hipLaunchKernelGGL(k_gn_finalize, dim3(a->groups, a->O), dim3(256), 0, (hipStream_t)stream, *a, part, ntiles, f);
         fin = f;
     }

@@ -53,8 +53,11 @@ class EchoToLayout(nn.Module):
         lb = config.layout_branch
         if lb.denoiser != 'unet1d':
             raise NotImplementedError(lb.denoiser)
-        if not lb.relation_condition:
-            raise NotImplementedError('relation_condition=False')
+        # relation_condition (echo2layout.py:12,105): when true the reference hands the relation embeddings to the denoiser as `context`,
+        # when false None -- and UNet1DModel.forward overwrites that argument with the GCN output ('crossattn', denoise_net.py:791-792)
+        # or never reads it ('concat'): the flag has no effect on SAMPLING.  (Its only effect is in training, where false raises
+        # NotImplementedError, echo2layout.py:93-96; training is out of scope here.)  Both values are accepted.
+        self.rel_condition = bool(lb.get('relation_condition', True))
         self.df = DiffusionPoint(UNet1DModel(**lb.denoiser_kwargs), lb.diffusion_kwargs)
         self.config = config
         self.translation_dim = lb.get('translation_dim', 3)

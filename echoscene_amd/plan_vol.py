@@ -777,7 +777,7 @@ def emit_unet3d_step(b, w, g, x, uc_dev, temb, step, eps_out, dims=(16, 16, 16),
     return objbuf
 
 
-for _n in ('_push', 'conv', '_conv32', 'conv_gn_intermediate', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
+for _n in ('_push', 'conv', '_conv32', 'split3', 'conv_gn_intermediate', '_rowgroup_producer', '_rowgroup_stats', 'groupnorm', 'layernorm', 'attention', 'geglu', 'to_cl', 'stem'):
     setattr(Builder, _n, getattr(VolBuilderMixin, _n))
 
 

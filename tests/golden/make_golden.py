@@ -886,7 +886,13 @@ def case_scene_e2e_O2():
     case_scene_e2e(concat=False, O=2, name='scene_e2e_O2_tiny')
 
 
-def case_scene_e2e(concat=False, O=8, name=None):
+def case_scene_e2e_norel():
+    """``layout_branch.relation_condition: false`` (echo2layout.py:12,105): the reference's ``SGDiff('echolayout')`` end to end.  No
+    shipped YAML sets it; the reference then hands ``context=None`` to UNet1DModel.forward, which overwrites it (denoise_net.py:791)."""
+    case_scene_e2e(concat=False, name='scene_e2e_norel_tiny', types=('echolayout',), relation_condition=False)
+
+
+def case_scene_e2e(concat=False, O=8, name=None, types=None, relation_condition=True):
     """The full boundary: the reference's ``SGDiff`` API end to end on CPU (SURVEY.md section 8(c)
     recipe) with a tiny-width config -- setup GCNs, 100-step layout loop, 4-step DDIM, VQ-VAE decode."""
     import tempfile
@@ -899,13 +905,14 @@ def case_scene_e2e(concat=False, O=8, name=None):
     torch.save(vq.state_dict(), vq_path)
     opt = escfg.tiny_diff_opt(device='cpu', logs_dir=tmp, vq_ckpt=vq_path, concat=concat)
     opt.misc.debug = 0
+    opt.layout_branch.relation_condition = relation_condition
     import model.networks.diffusion_shape.echo2shape as e2s
     e2s.init_mesh_renderer = lambda **k: None
     from model.networks.diffusion_shape.samplers.ddim import DDIMSampler
     DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
     from model.SGDiff import SGDiff
     out = {}
-    for typ in (('echoscene',) if concat else ('echoscene', 'echolayout')):
+    for typ in (types or (('echoscene',) if concat else ('echoscene', 'echolayout'))):
         m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
                    gconv_pooling='avg', with_angles=True, clip=True, separated=False)
         synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), seed=0, prefix='e2e.diff.')
@@ -1007,7 +1014,7 @@ def case_gcn_pooling():
 CASES = dict(unet1d_mc384=case_unet1d_mc384, sampler_variants=case_sampler_variants, gcn_pooling=case_gcn_pooling, sampler_options=case_sampler_options, unet1d_no_temb=case_unet1d_no_temb, scene_flags=case_scene_flags, gcn_ragged=case_gcn_ragged, scene_e2e_O2=case_scene_e2e_O2, box_post=case_box_post, nomp=case_nomp, concat=case_concat, gcn=case_gcn, unet1d_tiny=case_unet1d_tiny, layout_loop_tiny=case_layout_loop_tiny,
              ddpm_tables=case_ddpm_tables, unet1d_full=case_unet1d_full, unet3d_tiny=case_unet3d_tiny,
              ddim_tiny=case_ddim_tiny, unet3d_full=case_unet3d_full, vqvae=case_vqvae,
-             scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat,
+             scene_e2e=case_scene_e2e, scene_e2e_concat=case_scene_e2e_concat, scene_e2e_norel=case_scene_e2e_norel,
              layout_traj_full=case_layout_traj_full, shape_traj_full=case_shape_traj_full,
              scene_edit=case_scene_edit, temb=case_temb, manifest=case_manifest,
              unet3d_full_O32=case_unet3d_full_O32, shape_traj_full_O16=case_shape_traj_full_O16)

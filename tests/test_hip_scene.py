@@ -41,17 +41,21 @@ def test_vqvae_decode_vs_reference_golden(tag):
 
 
 @pytest.mark.parametrize('typ,concat,gold', [('echolayout', False, None), ('echoscene', False, None), ('echoscene', True, None),
-                                             ('echoscene', False, 'scene_e2e_O2_tiny')])
+                                             ('echoscene', False, 'scene_e2e_O2_tiny'), ('echolayout', False, 'scene_e2e_norel_tiny')])
 def test_sgdiff_api_end_to_end_vs_reference_golden(typ, concat, gold):
     """model.SGDiff.SGDiff(...).sample_box_and_shape on the GPU == the reference's own call (tiny widths);
-    ``concat``: the config/full_concat_mp.yaml model family; ``scene_e2e_O2_tiny``: the smallest scene (one object + the scene node)."""
+    ``concat``: the config/full_concat_mp.yaml model family; ``scene_e2e_O2_tiny``: the smallest scene (one object + the scene node);
+    ``scene_e2e_norel_tiny`` (round 6): ``layout_branch.relation_condition: false`` -- golden from the reference built that way."""
     import sys
     from model.SGDiff import SGDiff          # the drop-in import path eval_3dfront.py uses
     g = load_golden(gold or ('scene_e2e_concat_tiny' if concat else 'scene_e2e_tiny'))
     objs, triples = g['objs'], g['triples']
     O = objs.shape[0]
     tf, rf = synth.synthetic_features(O, triples.shape[0], seed=9)
-    m = SGDiff(typ, escfg.tiny_diff_opt('cuda', concat=concat), synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
+    opt = escfg.tiny_diff_opt('cuda', concat=concat)
+    if gold == 'scene_e2e_norel_tiny':
+        opt.layout_branch.relation_condition = False
+    m = SGDiff(typ, opt, synth.VOCAB, replace_latent=False, with_changes=True, residual=True,
                gconv_pooling='avg', with_angles=True, clip=True, separated=False)
     synth.seeded_fill_(torch.nn.Module.state_dict(m.diff), prefix='e2e.diff.')
     if typ == 'echoscene':

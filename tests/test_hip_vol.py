@@ -98,6 +98,17 @@ def test_small_linear_launches_on_the_deep_ring_kernel(dev, O, dims, Cin, N, geg
     kernel entry, no split K, no reduction kernel.  Against torch on the fp16-rounded operands, and BIT-identical to the unsplit launch
     of the ordinary 64-row tile kernel (`splitk=1` keeps the launch off the deep-ring route: same K order, same accumulation chain)."""
     from echoscene_amd import hip
+    # (round 6: the few-objects routes take these shapes in the default routing -- k_conv_kw or 64-row producer/consumer tiles,
+    #  test_conv_few_objects_kernels_bit_for_bit; the deep-ring kernel is the route of `conv_few = 0`)
+    hip.check(hip.lib().es_vol_set_option(b'conv_few', 0), 'es_vol_set_option')
+    try:
+        _deep_ring_case(dev, O, dims, Cin, N, geglu)
+    finally:
+        hip.check(hip.lib().es_vol_set_option(b'conv_few', 1), 'es_vol_set_option')
+
+
+def _deep_ring_case(dev, O, dims, Cin, N, geglu):
+    from echoscene_amd import hip
     from echoscene_amd.plan import Builder, View
     from echoscene_amd.plan_vol import PackedConv
     D, H, W = dims
