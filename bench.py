@@ -116,7 +116,7 @@ def time_dominant_kernel(ss, dev, reps=5):
     return flops / us / 1e6, us / len(ops), len(ops), st
 
 
-PMC_TRAFFIC_FILES = ('r05b_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
+PMC_TRAFFIC_FILES = ('r06_pmc_traffic.json', 'r05b_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')
 
 
 def _pmc_file():
