@@ -2830,20 +2830,28 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
     // 64-row producer/consumer tiles (no split).
     int few_ref = 0, few_bm = 0;
     bool few_kw = false;
+    if (vo("conv_few") != 0 && ws && geglu && !upm && a->taps == 1 && a->splitk <= 0 && hg256 < 256 && !no256 && !force256 &&
+        !vo("conv_st_bm") && !vo("conv_kw_ks") && ((M + 127) / 128) * ntn < 320) {
+        // the GEGLU projection of a small problem (never split: its epilogue needs the whole sum): 64-row producer/consumer tiles
+        // instead of the non-specialised 64-row kernel (672 -> 5376 at 16x4x4 with 4 objects)
+        few_ref = 1; S = 1; few_bm = 64;
+    }
     if (vo("conv_few") != 0 && ws && !geglu && a->splitk < 0 && can_split && hg256 < 256 && !no256 && !force256 &&
         !vo("conv_st_bm") && !vo("conv_kw_ks")) {
         const long h128 = ((Mh + 127) / 128) * ntn, h64h = ((Mh + 63) / 64) * ((a->N + 111) / 112);
         if (a->taps == 27 || nks >= 112) {
             int s2 = (int)((256 + h128 / 2) / h128);
             s2 = s2 < 1 ? 1 : (s2 > 8 ? 8 : s2);
-            while (s2 > 1 && h128 * s2 > 272) --s2;                               // never a second round of workgroups
+            // (the split that fills the chip best must fit ONE round of workgroups: 96 tiles of 128 rows -- the 16x4x4 level at 16
+            //  objects -- want S = 3 = 288 workgroups; with S = 2 the 256-row tiles' S = 5 is the better use of the chip, 91 against 96 us)
+            const bool one_round = h128 * s2 <= 272;
             while (s2 > 1 && nks / s2 < 24) --s2;
             // (very long K on a handful of tiles -- 1344 -> 672 at 16x4x4 with 4 objects -- stays on the 256-row tiles with S = 16;
             //  an UNSPLIT launch that would leave a quarter of the CUs idle -- 192 tiles of 128 rows: the 16x4x4 level at 32 objects --
             //  stays on the 256-row tiles with S = 2: the same workgroup count on the tile that moves fewer bytes, 169 against 179 us)
-            if (!(nks >= 800 && h128 * 8 < 256) && (s2 >= 2 || h128 >= 224)) { few_ref = 1; S = s2; }
+            if (!(nks >= 800 && h128 * 8 < 256) && one_round && (s2 >= 2 || h128 >= 224)) { few_ref = 1; S = s2; }
         } else if (a->taps == 1) {
-            if (h64h <= 384 && nks >= 12) { few_ref = 2; S = 4; }
+            if (h64h <= 272 && nks >= 12) { few_ref = 2; S = 4; }          // (one round of 64 x 112 tiles: with 384 of them the 64-row tiles win)
             else { few_ref = 1; S = 1; }
         }
         if (few_ref) {

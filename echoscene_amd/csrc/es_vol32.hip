@@ -7,6 +7,7 @@
 // LDS-tiled implicit-GEMM kernel for every conv / linear shape, a flash-style fp32 attention, and fp32-output variants of the
 // normalisation kernels (es_vol.hip, `*_is_f32` flags).  Same op list, same fusion structure, same epilogue order as the fp16 route.
 #include "es_common.h"
+#include <mutex>
 #include <algorithm>
 
 namespace {
@@ -182,6 +183,103 @@ __global__ __launch_bounds__(64) void k_attention_f32(const es_attn_args a) {
     }
 }
 
+// Round 6: the same attention on the exact-fp32 MATRIX instruction (flash style) -- the scalar kernel above was 155 of the 205 ms of a
+// 32-object step on the split-operand route (precision 'fp32x'; 25 ms per launch at 1024 tokens x 8 heads x 32 objects).
+// One workgroup = 64 query rows of one (batch, head), 4 waves x 16 rows; K / V tiles of 64 keys in LDS (fp32, head dimension padded to
+// DP = 64 / 96); S = Q K^T as 4 x DP/4 v_mfma_f32_16x16x4_f32 (A = Q rows from registers, B = K rows from LDS), online softmax on the D
+// layout (a lane holds rows 4 q + r of key column i16: row maxima / sums are 16-lane reductions), P through a private LDS slab into
+// the A layout, O += P V as 16 x DP/16 MFMAs.  fp32 products, fp32 accumulation, fp32 softmax: the reference's arithmetic.
+template <int DP>
+__global__ __launch_bounds__(256) void k_attention_f32m(const es_attn_args a) {
+    constexpr int KT = 64, LDK = DP + 4, LDP = KT + 4, NKK = DP / 4, NCT = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* Ks = smf;
+    float* Vs = Ks + KT * LDK;
+    float* Ps = Vs + KT * LDK;                    // [4 waves][16 rows][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+    const int C = a.heads * a.dhead, ldq = 3 * C;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const float* base = (const float*)a.qkv + (long)b * a.Ntok * ldq + h * a.dhead;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    float qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int d = 4 * kk + q;
+        qf[kk] = (row0 + i16 < a.Ntok && d < a.dhead) ? base[(long)(row0 + i16) * ldq + d] * a.scale : 0.f;
+    }
+    f4 o[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) o[ct] = f4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lrow[4] = {0.f, 0.f, 0.f, 0.f};
+    float* Pw = Ps + wave * 16 * LDP;
+    for (int k0 = 0; k0 < a.Ntok; k0 += KT) {
+        __syncthreads();                                                      // every wave is done with the previous K / V tile
+        for (int i = tid; i < KT * NKK; i += 256) {
+            const int key = i / NKK, d4 = (i - key * NKK) * 4;
+            f4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + key < a.Ntok && d4 < a.dhead) {                          // (dhead % 4 == 0: a quad is inside or outside)
+                const float* p = base + (long)(k0 + key) * ldq + d4;
+                kv = *(const f4*)(p + C);
+                vv = *(const f4*)(p + 2 * C);
+            }
+            *(f4*)&Ks[key * LDK + d4] = kv;
+            *(f4*)&Vs[key * LDK + d4] = vv;
+        }
+        __syncthreads();
+        f4 s[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            s[st] = f4{0.f, 0.f, 0.f, 0.f};
+            const float* kr = Ks + (st * 16 + i16) * LDK + q;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) s[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kk], kr[4 * kk], s[st], 0, 0, 0);
+            if (k0 + st * 16 + i16 >= a.Ntok) s[st] = f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // keys past the end
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+            const float mn = fmaxf(mrow[r], mx);
+            const float al = __expf(mrow[r] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float p = __expf(s[st][r] - mn);
+                ps += p;
+                Pw[(q * 4 + r) * LDP + st * 16 + i16] = p;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) ps += __shfl_xor(ps, sh);
+            lrow[r] = lrow[r] * al + ps;
+            mrow[r] = mn;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) o[ct][r] *= al;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // own P slab written
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            const float pa = Pw[i16 * LDP + 4 * kk + q];
+            const float* vr = Vs + (4 * kk + q) * LDK + i16;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vr[ct * 16], o[ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* out = (float*)a.out_f16 + (long)b * a.Ntok * C + h * a.dhead;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + q * 4 + r;
+        const float inv = 1.0f / lrow[r];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int d = ct * 16 + i16;
+            if (row < a.Ntok && d < a.dhead) out[(long)row * C + d] = o[ct][r] * inv;
+        }
+    }
+}
+
 int ilog2x(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -228,6 +326,20 @@ extern "C" int es_attention_f32(const es_attn_args* a, es_stream stream) {
     ES_REQUIRE(a->dhead > 0 && a->dhead <= 96, "es_attention_f32: dhead=%d (<= 96)", a->dhead);
     dim3 grid((a->Ntok + 63) / 64, a->B * a->heads);
     hipStream_t st = (hipStream_t)stream;
+    static const char* scalar_env = getenv("ES_ATTN_F32_SCALAR");       // A/B switch (timing; both kernels are fp32 throughout): 1 = the scalar kernel
+    if (a->dhead % 4 == 0 && !(scalar_env && atoi(scalar_env) == 1)) {
+        // round 6: the matrix-instruction kernel (dhead a multiple of 4: the K / V tiles are staged in 16-byte quads)
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)k_attention_f32m<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 64 * 100 + 4 * 16 * 68) * 4);
+        });
+        ES_REQUIRE(attr_err == hipSuccess, "es_attention_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+        if (a->dhead <= 64) hipLaunchKernelGGL((k_attention_f32m<64>), grid, dim3(256), (2 * 64 * 68 + 4 * 16 * 68) * 4, st, *a);
+        else hipLaunchKernelGGL((k_attention_f32m<96>), grid, dim3(256), (2 * 64 * 100 + 4 * 16 * 68) * 4, st, *a);
+        ES_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (a->dhead <= 64) hipLaunchKernelGGL((k_attention_f32<64>), grid, dim3(64), 0, st, *a);
     else hipLaunchKernelGGL((k_attention_f32<96>), grid, dim3(64), 0, st, *a);
     ES_CHECK_HIP(hipGetLastError());
