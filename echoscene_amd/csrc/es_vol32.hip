@@ -326,8 +326,7 @@ extern "C" int es_attention_f32(const es_attn_args* a, es_stream stream) {
     ES_REQUIRE(a->dhead > 0 && a->dhead <= 96, "es_attention_f32: dhead=%d (<= 96)", a->dhead);
     dim3 grid((a->Ntok + 63) / 64, a->B * a->heads);
     hipStream_t st = (hipStream_t)stream;
-    static const char* scalar_env = getenv("ES_ATTN_F32_SCALAR");       // A/B switch (timing; both kernels are fp32 throughout): 1 = the scalar kernel
-    if (a->dhead % 4 == 0 && !(scalar_env && atoi(scalar_env) == 1)) {
+    if (a->dhead % 4 == 0) {
         // round 6: the matrix-instruction kernel (dhead a multiple of 4: the K / V tiles are staged in 16-byte quads)
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
