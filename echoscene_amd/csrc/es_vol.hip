@@ -1422,6 +1422,179 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws(const es_conv_a
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_ws3 (round 6): k_conv_ws<256, 8, 4> for 3x3x3 SAME convs with the A tile of a (channel chunk, kd, kh) group staged ONCE.
+// The three K units of such a group are the taps kw = -1, 0, +1 of the same 32 channels: their A rows are the SAME voxel line shifted
+// by one voxel along W, and a 16-row MFMA tile is one W line (W = 16; two / four lines at W = 8 / 4) -- so the A fragments of the
+// kw = -1 / +1 units are the centre fragments moved by ONE LANE inside a 16-lane row (v_mov_dpp row_shr:1 / row_shl:1, zero fill at
+// the ends of a line: exactly the zero padding of the convolution).  The producers load ONE centre A tile per group (LDS-DMA bytes
+// per group 90 -> 58 KB), the consumers read A fragments once per group (LDS reads per wave and group 33 -> 25 KB) and derive the
+// shifted operands in registers right before the MFMA row that uses them.  Why: per K unit the LDS moves 118 KB against 128 B /
+// clock = 920 clocks, next to 896 clocks of MFMA issue -- both pipes are co-critical (profiles/r06_notes.md section 4).  Same
+// products in the same order: bit-identical to k_conv_ws.  (Round 2 had tried the shared A tile with shifted LDS reads of a
+// halo'd tile: +6 %; here the shift costs 8 VALU moves per fragment pair and no LDS access.)
+// Ring: 4 B slots (one per K unit) + 2 A slots (one per group) = 96 KB, as k_conv_ws; one barrier per K unit.
+// ---------------------------------------------------------------------------------------------
+typedef int i4v __attribute__((ext_vector_type(4)));
+template <int DIR>      // -1: lane w takes lane w - 1 (tap kw = -1), +1: lane w takes lane w + 1 (tap kw = +1); zero past the row's ends
+__device__ __forceinline__ h8 a3_shift(const h8 v, const bool zero_lane) {
+    i4v x = __builtin_bit_cast(i4v, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int s = DIR < 0 ? __builtin_amdgcn_update_dpp(0, x[e], 0x111, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, x[e], 0x101, 0xf, 0xf, true);
+        x[e] = zero_lane ? 0 : s;
+    }
+    return __builtin_bit_cast(h8, x);
+}
+
+template <bool STATS_>
+__global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const ConvGeom g) {
+    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NSB = 4, NSA = 2, MI = 4;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, A_RING = NSB * B_BYTES;      // A slots behind the B ring
+    constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long M = (long)g.O * g.D * g.H * g.W;
+    int bx, by, bz;
+    conv_tile_of(a, bx, by, bz);
+    const int S = gridDim.z;
+    const int kch0 = a.Cin >> 5, nks0 = 27 * kch0;
+    int ks_begin, ks_end;
+    split_range(nks0, 0, 27, bz, S, ks_begin, ks_end);            // (cuts in whole (chunk, kd, kh) groups: multiples of 3 K units)
+    const int nloc = ks_end - ks_begin, ngrp = nloc / 3;
+    const long m0 = (long)bx * BM_;
+    const int n0 = by * BN;
+    if (wave >= NC_) {
+        // =============================== producer ===============================
+        const int pw = wave - NC_;
+        unsigned voff[NA], msk[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (pw + NP_ * j) * 64 + lane;
+            const int row = p >> 2;
+            const int lc = (p & 3) ^ f_swz(row);
+            const long m = m0 + row;
+            const bool ok = m < M;
+            const long mm = ok ? m : 0;
+            const int w = (int)(mm & (g.W - 1)), h = (int)((mm >> g.lw) & (g.H - 1)), d = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
+            const int o = (int)(mm >> (g.lw + g.lh + g.ld));
+            voff[j] = (unsigned)(((((long)o * g.D + d) * g.H + h) * g.W + w) * a.Cin * 2 + lc * 16);
+            msk[j] = ok ? tap_mask27(d, g.D, h, g.H, w, g.W) : 0u;
+        }
+        const int bias = ((g.H + 1) * g.W + 1) * a.Cin * 2;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.a - bias), (short)0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.w + ((long)by * nks0) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
+        int dtab;
+        {
+            const int t = lane < 27 ? lane : 13;
+            const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+            dtab = ((kd * g.H + kh) * g.W + kw) * a.Cin * 2 + bias;
+        }
+        int a_tap = ks_begin % 27, a_c = ks_begin / 27;               // first tap (kw = -1) and channel chunk of the next group to load
+        unsigned b_off = (unsigned)ks_begin * (unsigned)B_BYTES;
+        const unsigned voffB = (unsigned)lane * 16u;
+        auto issue_A = [&](int slot) __attribute__((always_inline)) {
+            char* dst = smem + A_RING + slot * A_BYTES;
+            const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, a_tap + 1) + (unsigned)a_c * 64u;      // the group's centre tap (kw = 0)
+            const unsigned sbit = 1u << (a_tap + 1);
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (pw + NP_ * j) * 1024), 16, (int)((msk[j] & sbit) ? voff[j] : OOB), (int)sA, 0, 0);
+            a_tap += 3;
+            if (a_tap == 27) { a_tap = 0; ++a_c; }
+        };
+        auto issue_B = [&](int slot) __attribute__((always_inline)) {
+            char* dst = smem + slot * B_BYTES;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int q = pw + NP_ * j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + q * 1024), 16, (int)(q * 16 >= BN ? OOB : voffB), (int)(b_off + (unsigned)q * 1024u), 0, 0);
+            }
+            b_off += (unsigned)B_BYTES;
+        };
+        issue_A(0);
+        issue_B(0);
+        if (nloc > 1) issue_B(1);
+        int kw3 = 0, grp = 0;
+        for (int u = 0; u < nloc; ++u) {
+            // loads issued AFTER the ones unit u needs: B(u + 1), and the next group's A tile when u is not a group's first unit
+            const int newer = (u + 1 < nloc ? NB : 0) + ((kw3 != 0 && grp + 1 < ngrp) ? NA : 0);
+            if (newer >= NA + NB) wait_vmcnt<NA + NB>(); else if (newer >= NB) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();            // unit u (and its group's A tile) visible; the slots behind released
+            if (u + 2 < nloc) issue_B((u + 2) % NSB);
+            if (kw3 == 0 && grp + 1 < ngrp) issue_A((grp + 1) % NSA);
+            if (++kw3 == 3) { kw3 = 0; ++grp; }
+        }
+        __builtin_amdgcn_s_barrier();                // (the consumers' barrier behind the last unit: their loop is straight-line)
+        f4 dummy[MI][7];
+        conv_epilogue<BM_, NC_, false, true, ES_EPI_NONE, false, STATS_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, 0);
+        return;
+    }
+    // =============================== consumer ===============================
+    static_assert(NA == NB, "the producer's wait ladder assumes equal A and B piece counts per wave");
+    const int wm = wave >> 1, wn = wave & 1;
+    f4 acc[MI][7];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, q = lane >> 4;
+    const int fragA = A_RING + (wm * 64 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const int fragB = (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
+    const bool zl = (i16 & (g.W - 1)) == 0, zr = (i16 & (g.W - 1)) == ((g.W - 1) & 15);      // first / last voxel of a W line
+    // MFMA order: B column outer, A row inner -- one B fragment is live at a time (3 in a prefetch ring) instead of all 7, which pays for
+    // the 4 shifted A fragments of the kw = -1 / +1 units inside the 168-register budget (112 accumulators + 16 centre + 16 shifted +
+    // 12 B).  The current unit's B slot is therefore read until the END of the unit, past the barrier that publishes the next one:
+    // the B ring has 4 slots (the producers refill slot u % 4 after barrier u + 2, when every consumer has left unit u).
+    h8 afc[MI], bq[3];
+    __builtin_amdgcn_s_barrier();                                           // unit 0 and group 0 published
+    bq[0] = *(const h8*)(smem + fragB);
+    bq[1] = *(const h8*)(smem + fragB + 1024);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) afc[i] = *(const h8*)(smem + fragA + i * 1024);
+    int slotB = 0;
+    for (int grp = 0; grp < ngrp; ++grp) {
+        const char* const An = smem + ((grp + 1) & 1) * A_BYTES;              // A slot of the NEXT group
+        auto unit = [&](auto kwc) __attribute__((always_inline)) {
+            constexpr int KW = decltype(kwc)::value;                         // 0, 1, 2 = taps kw -1, 0, +1
+            // (straight-line: behind the LAST unit the "next" reads fetch stale LDS that nobody uses, and its barrier is matched by
+            //  one extra barrier of the producers -- with `if (next unit exists)` around them the register allocator spilled 50 dwords)
+            const char* const Bc = smem + slotB * B_BYTES;                   // this unit's B tile
+            slotB = slotB == NSB - 1 ? 0 : slotB + 1;
+            const char* const Bn = smem + slotB * B_BYTES;                   // the next unit's
+            h8 ash[MI];
+            if constexpr (KW == 0) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) ash[i] = a3_shift<-1>(afc[i], zl);
+            } else if constexpr (KW == 2) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) ash[i] = a3_shift<1>(afc[i], zr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                constexpr int C0 = KW * 7;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(KW == 1 ? afc[i] : ash[i], bq[(C0 + j) % 3], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) __builtin_amdgcn_s_barrier();                     // the next unit (after kw = +1: the next group's A tile) published
+                if (j + 2 < 7) bq[(C0 + j + 2) % 3] = *(const h8*)(Bc + fragB + (j + 2) * 1024);
+                else bq[(C0 + j + 2) % 3] = *(const h8*)(Bn + fragB + (j + 2 - 7) * 1024);
+                if (KW == 2 && j >= 1 && j <= MI) afc[j - 1] = *(const h8*)(An + fragA + (j - 1) * 1024);     // (the shifted copies multiply; the centre registers are free)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+        unit(std::integral_constant<int, 2>{});
+    }
+    conv_epilogue<BM_, NC_, true, true, ES_EPI_NONE, false, STATS_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv_kw (round 6): K split INSIDE a workgroup -- the small problems of the few-objects regime (a shard of 4 .. 16 objects, the
 // transformer linears of every level there, the 16x4x4 level at any object count).  Such a launch has fewer 256-row tiles than the
 // chip has CUs; until round 5 it kept the big tiles and split K over workgroups: every partial tile went to HBM as an fp32 slab and a
@@ -2592,6 +2765,9 @@ extern "C" int es_pack_conv_rows_f16(const float* h_w, int N, int CinW, int taps
 // ranks -- or a process that saves a model file and one that replays it -- with different environments silently disagreed (ADVICE r4,
 // VERDICT r4 #6).  Now they are process-wide options with constant defaults that ONLY an explicit es_vol_set_option() call changes
 // (tests and A/B tools); es_model_save records them in the file and es_model_load refuses a file written under other values.
+#ifndef ES_CONV_A3_DEFAULT
+#define ES_CONV_A3_DEFAULT false
+#endif
 struct VolOpt { const char* name; int value; };
 static VolOpt g_vo[] = {
     {"conv_tile", 0},          // 128: force 128-row tiles
@@ -3028,12 +3204,30 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             static const char* ns_env = getenv("ES_CONV_NS");
             const int ns = ns_env ? atoi(ns_env) : 3;
             const bool stt = want_stats && epi_stats;
+            // 3x3x3 SAME convs on volumes with W <= 16: the A tile of a (chunk, kd, kh) group staged once, the kw = -1 / +1 operands
+            // shifted in registers (k_conv_ws3; bit-identical to k_conv_ws).  ES_CONV_A3 = 0 / 1: timing-only A/B switch
+            static const char* a3_env = getenv("ES_CONV_A3");
+            const bool a3 = (a3_env ? atoi(a3_env) != 0 : ES_CONV_A3_DEFAULT) && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && a->W <= 16 && a->W >= 4;
+            if (a3) {
+                static std::once_flag once3;
+                static hipError_t err3 = hipSuccess;
+                std::call_once(once3, [] {
+                    err3 = hipFuncSetAttribute((const void*)k_conv_ws3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+                    const hipError_t e2 = hipFuncSetAttribute((const void*)k_conv_ws3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+                    if (err3 == hipSuccess) err3 = e2;
+                });
+                ES_REQUIRE(err3 == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(err3));
+                if (stt) hipLaunchKernelGGL((k_conv_ws3<true>), grid, dim3(768), 6 * 16384, st, *a, g);
+                else hipLaunchKernelGGL((k_conv_ws3<false>), grid, dim3(768), 6 * 16384, st, *a, g);
+                if (stt) stats_done = true;
+            } else {
             int rc;
             if (ns == 4) rc = launch_ws<256, 8, 4, 4>(a, g, ncdhw, grid, st, upm, geglu, stt);
             else if (ns == 5) rc = launch_ws<256, 8, 4, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
             else rc = launch_ws<256, 8, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
             if (rc) return rc;
             if (stt) stats_done = true;
+            }
         }
         else if (upm) hipLaunchKernelGGL((k_conv_lean<256, 8, true>), grid, dim3(512), LDS256, st, *a, g, ncdhw);
         else hipLaunchKernelGGL((k_conv_lean<256, 8>), grid, dim3(512), LDS256, st, *a, g, ncdhw);

@@ -947,7 +947,10 @@ def test_splitk_reduction_leaves_the_next_groupnorm_partials(dev, monkeypatch, O
                                  # round 6: the few-objects kernels forced for EVERY eligible launch -- producer/consumer tiles of 64 and
                                  # 128 rows, and K split inside the workgroup (4 streams x 112 columns, 2 streams x 224 columns)
                                  {'ES_TEST_VOL_OPTIONS': 'conv_st_bm=64'}, {'ES_TEST_VOL_OPTIONS': 'conv_st_bm=128,conv_st_np=8'},
-                                 {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=4'}, {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=2'}])
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=4'}, {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=2'},
+                                 # k_conv_ws3 (A tile of a (chunk, kd, kh) group staged once, kw = -1 / +1 operands shifted in registers) for every
+                                 # 3x3x3 SAME conv, small ones included (conv_force256), W = 4 / 8 / 16
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_force256=1', 'ES_CONV_A3': '1'}, {'ES_CONV_A3': '1'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
     128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
