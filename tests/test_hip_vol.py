@@ -225,8 +225,12 @@ def test_conv_few_objects_kernels_bit_for_bit(dev, taps, Cin, Cs, N, dims, O):
             for k in opts:
                 hip.check(lib.es_vol_set_option(k.encode(), 4 if k == 'conv_st_np' else 0), 'es_vol_set_option')
 
-    plain = {S: run({}, S) for S in (1, 2, 4)}
+    plain = {S: run({}, S) for S in (1, 2, 3, 4, 8)}
     assert _rel(plain[1][0], ref) < 1e-4
+    # the dispatcher's own choice for this small problem (few-objects routes: 128-row tiles -- with the shared A tile of k_conv_ws3 for
+    # 3x3x3 SAME launches --, K streams, 64-row tiles) is SOME plain split, bit for bit
+    auto = run({}, None)
+    assert any(torch.equal(auto[0], plain[S][0]) and torch.equal(auto[1], plain[S][1]) for S in plain), 'auto route matches no plain split'
     for opts in ({'conv_st_bm': 64}, {'conv_st_bm': 128}, {'conv_st_bm': 128, 'conv_st_np': 8}):
         for S in (1, 2):
             got = run(opts, S)
@@ -950,7 +954,8 @@ def test_splitk_reduction_leaves_the_next_groupnorm_partials(dev, monkeypatch, O
                                  {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=4'}, {'ES_TEST_VOL_OPTIONS': 'conv_kw_ks=2'},
                                  # k_conv_ws3 (A tile of a (chunk, kd, kh) group staged once, kw = -1 / +1 operands shifted in registers) for every
                                  # 3x3x3 SAME conv, small ones included (conv_force256), W = 4 / 8 / 16
-                                 {'ES_TEST_VOL_OPTIONS': 'conv_force256=1', 'ES_CONV_A3': '1'}, {'ES_CONV_A3': '1'}])
+                                 # (the default since its A/B; ES_CONV_A3=0 = k_conv_ws for those launches: both must give the goldens' bits)
+                                 {'ES_TEST_VOL_OPTIONS': 'conv_force256=1', 'ES_CONV_A3': '1'}, {'ES_CONV_A3': '0'}])
 def test_conv_alternate_kernels(env):
     """The conv dispatcher's other routes (the non-specialised k_conv_lean for 256-row tiles, 128-row tiles forced, small problems on
     128- / 64-row tiles with split-K instead of 256-row producer/consumer tiles with split-K) must give the same results: the conv unit tests and the full-width UNet golden test are re-run in a subprocess with the A/B switch set
