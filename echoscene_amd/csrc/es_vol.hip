@@ -1446,21 +1446,9 @@ __device__ __forceinline__ h8 a3_shift(const h8 v, const bool zero_lane) {
     return __builtin_bit_cast(h8, x);
 }
 
-// run-time vmcnt (an immediate in the instruction): a producer wave of k_conv_ws3 waits until at most n of its loads are outstanding
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    if (n >= 12) wait_vmcnt<12>(); else if (n == 11) wait_vmcnt<11>(); else if (n == 10) wait_vmcnt<10>(); else if (n == 9) wait_vmcnt<9>();
-    else if (n == 8) wait_vmcnt<8>(); else if (n == 7) wait_vmcnt<7>(); else if (n == 6) wait_vmcnt<6>(); else if (n == 5) wait_vmcnt<5>();
-    else if (n == 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>(); else if (n == 1) wait_vmcnt<1>();
-    else wait_vmcnt<0>();
-}
-
-// <256, 8, 4, 2>: the 32-object step's tile (B tiles two units ahead, 4-slot B ring); <128, 4, 8, 4>: the few-objects tile (8 producer
-// waves, B tiles four units ahead, 6-slot B ring -- a small tile's K unit is bound by the landing latency over the lead, and its
-// launch by the L2 -> LDS path the shared A tile relieves)
-template <int BM_, int NC_, int NP_, int LEAD, bool STATS_>
-__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws3(const es_conv_args a, const ConvGeom g) {
-    constexpr int NSB = LEAD + 2, NSA = 2, MI = 4;
-    static_assert(BM_ / (NC_ / 2) == 64, "consumer waves hold 64 x 112 tiles");
+template <bool STATS_>
+__global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const ConvGeom g) {
+    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NSB = 4, NSA = 2, MI = 4;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, A_RING = NSB * B_BYTES;      // A slots behind the B ring
     constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_;
     constexpr unsigned OOB = 0x80000000u;
@@ -1526,32 +1514,18 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws3(const es_conv_
             }
             b_off += (unsigned)B_BYTES;
         };
-        // loads retire in order: unit u is published when at most (loads issued after the last one it needs) are outstanding.  The
-        // wave counts its issues and remembers the count behind every B tile (ring of NSB marks) and A tile (2 marks).
-        int issued = 0, markA[NSA], markB[NSB];
-        issue_A(0); issued += NA; markA[0] = issued; markA[1] = 0;
-#pragma unroll
-        for (int l = 0; l < NSB; ++l) markB[l] = 0;
-#pragma unroll
-        for (int l = 0; l < LEAD; ++l)
-            if (l < nloc) { issue_B(l); issued += NB; markB[l] = issued; }
-        int kw3 = 0, grp = 0, sb = 0, sbl = LEAD % NSB;
+        issue_A(0);
+        issue_B(0);
+        if (nloc > 1) issue_B(1);
+        int kw3 = 0, grp = 0;
         for (int u = 0; u < nloc; ++u) {
-            int need = markB[0];
-#pragma unroll
-            for (int l = 1; l < NSB; ++l) need = sb == l ? markB[l] : need;
-            if (kw3 == 0) { const int na = (grp & 1) ? markA[1] : markA[0]; need = na > need ? na : need; }
-            wait_vmcnt_dyn(issued - need);
+            // loads issued AFTER the ones unit u needs: B(u + 1), and the next group's A tile when u is not a group's first unit
+            const int newer = (u + 1 < nloc ? NB : 0) + ((kw3 != 0 && grp + 1 < ngrp) ? NA : 0);
+            if (newer >= NA + NB) wait_vmcnt<NA + NB>(); else if (newer >= NB) wait_vmcnt<NB>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();            // unit u (and its group's A tile) visible; the slots behind released
-            if (u + LEAD < nloc) {
-                issue_B(sbl); issued += NB;
-#pragma unroll
-                for (int l = 0; l < NSB; ++l) markB[l] = sbl == l ? issued : markB[l];
-            }
-            if (kw3 == 0 && grp + 1 < ngrp) { issue_A((grp + 1) % NSA); issued += NA; if ((grp + 1) & 1) markA[1] = issued; else markA[0] = issued; }
+            if (u + 2 < nloc) issue_B((u + 2) % NSB);
+            if (kw3 == 0 && grp + 1 < ngrp) issue_A((grp + 1) % NSA);
             if (++kw3 == 3) { kw3 = 0; ++grp; }
-            sb = sb == NSB - 1 ? 0 : sb + 1;
-            sbl = sbl == NSB - 1 ? 0 : sbl + 1;
         }
         __builtin_amdgcn_s_barrier();                // (the consumers' barrier behind the last unit: their loop is straight-line)
         f4 dummy[MI][7];
@@ -1559,6 +1533,7 @@ __global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws3(const es_conv_
         return;
     }
     // =============================== consumer ===============================
+    static_assert(NA == NB, "the producer's wait ladder assumes equal A and B piece counts per wave");
     const int wm = wave >> 1, wn = wave & 1;
     f4 acc[MI][7];
 #pragma unroll
@@ -2863,29 +2838,6 @@ static int launch_ws(const es_conv_args* a, const ConvGeom& g, int ncdhw, dim3 g
     return 0;
 }
 
-// k_conv_ws3 (shared A tile of a (chunk, kd, kh) group): 3x3x3 SAME convs without a fused skip phase on volumes with 4 <= W <= 16
-static inline bool ws3_takes(const es_conv_args* a) {
-    static const char* a3_env = getenv("ES_CONV_A3");            // timing-only A/B switch (bit-identical to k_conv_ws): 0 = off
-    return (a3_env ? atoi(a3_env) != 0 : ES_CONV_A3_DEFAULT) && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && a->W <= 16 && a->W >= 4;
-}
-template <int BM_, int NC_, int NP_, int LEAD>
-static int launch_ws3(const es_conv_args* a, const ConvGeom& g, dim3 grid, hipStream_t st, bool stats) {
-    constexpr int LDS = (LEAD + 2) * (BNP * BK * 2) + 2 * (BM_ * BK * 2);
-    static_assert(LDS <= 160 * 1024, "rings exceed the CU's LDS");
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void*)k_conv_ws3<BM_, NC_, NP_, LEAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        const hipError_t e2 = hipFuncSetAttribute((const void*)k_conv_ws3<BM_, NC_, NP_, LEAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (err == hipSuccess) err = e2;
-    });
-    ES_REQUIRE(err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(err));
-    const dim3 blk(64 * (NC_ + NP_));
-    if (stats) hipLaunchKernelGGL((k_conv_ws3<BM_, NC_, NP_, LEAD, true>), grid, blk, LDS, st, *a, g);
-    else hipLaunchKernelGGL((k_conv_ws3<BM_, NC_, NP_, LEAD, false>), grid, blk, LDS, st, *a, g);
-    return 0;
-}
-
 // k_conv_kw: K split inside the workgroup (KS_ streams x NCH_ column halves of 112)
 template <int KS_, int NCH_>
 static int launch_kw(const es_conv_args* a, const ConvGeom& g, int ncdhw, long M, int ntn, int S, hipStream_t st, bool upm, bool geglu) {
@@ -3210,7 +3162,6 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         const bool stt = want_stats && epi_stats;
         int rc;
         if (few_bm == 64) rc = launch_ws<64, 4, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (ws3_takes(a) && !geglu) rc = launch_ws3<128, 4, 8, 4>(a, g, grid, st, stt);
         else rc = launch_ws<128, 4, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
         if (rc) return rc;
         stats_done = stt;
@@ -3254,9 +3205,20 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
             const int ns = ns_env ? atoi(ns_env) : 3;
             const bool stt = want_stats && epi_stats;
             // 3x3x3 SAME convs on volumes with W <= 16: the A tile of a (chunk, kd, kh) group staged once, the kw = -1 / +1 operands
-            // shifted in registers (k_conv_ws3; bit-identical to k_conv_ws)
-            if (ws3_takes(a)) {
-                if (int rc3 = launch_ws3<256, 8, 4, 2>(a, g, grid, st, stt)) return rc3;
+            // shifted in registers (k_conv_ws3; bit-identical to k_conv_ws).  ES_CONV_A3 = 0 / 1: timing-only A/B switch
+            static const char* a3_env = getenv("ES_CONV_A3");
+            const bool a3 = (a3_env ? atoi(a3_env) != 0 : ES_CONV_A3_DEFAULT) && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && a->W <= 16 && a->W >= 4;
+            if (a3) {
+                static std::once_flag once3;
+                static hipError_t err3 = hipSuccess;
+                std::call_once(once3, [] {
+                    err3 = hipFuncSetAttribute((const void*)k_conv_ws3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+                    const hipError_t e2 = hipFuncSetAttribute((const void*)k_conv_ws3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+                    if (err3 == hipSuccess) err3 = e2;
+                });
+                ES_REQUIRE(err3 == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(err3));
+                if (stt) hipLaunchKernelGGL((k_conv_ws3<true>), grid, dim3(768), 6 * 16384, st, *a, g);
+                else hipLaunchKernelGGL((k_conv_ws3<false>), grid, dim3(768), 6 * 16384, st, *a, g);
                 if (stt) stats_done = true;
             } else {
             int rc;
