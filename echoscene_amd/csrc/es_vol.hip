@@ -1595,188 +1595,6 @@ __global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_ws3b (round 6): the shared A tile for the FEW-OBJECTS tiles (128 rows: 4 consumer waves, one per SIMD).  There the launch is
-// bound by the L2 -> LDS path (86 GB/s per CU), so what counts is the LDS-DMA bytes: one centre A tile per (chunk, kd, kh) group
-// instead of three (66 -> 50 KB per group at 128 rows).  The consumers keep k_conv_ws's loop -- A row outer, all fragments of the next
-// unit read under the MFMAs of this one (with ONE consumer wave per SIMD nothing else covers an LDS read: k_conv_ws3's B-column-outer
-// order lost 6 % on this tile) -- and re-read the group's A tile for each of its three units; the kw = -1 / +1 operands are the centre
-// fragments shifted IN PLACE (v_mov_dpp) right before their MFMA row: no extra registers.  Same products, same order: bit-identical.
-// Rings: NSB = LEAD + 1 B slots (one per K unit), 2 A slots (one per group); producer loads retire in order and are counted at run time.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    if (n >= 12) wait_vmcnt<12>(); else if (n == 11) wait_vmcnt<11>(); else if (n == 10) wait_vmcnt<10>(); else if (n == 9) wait_vmcnt<9>();
-    else if (n == 8) wait_vmcnt<8>(); else if (n == 7) wait_vmcnt<7>(); else if (n == 6) wait_vmcnt<6>(); else if (n == 5) wait_vmcnt<5>();
-    else if (n == 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>(); else if (n == 1) wait_vmcnt<1>();
-    else wait_vmcnt<0>();
-}
-
-template <int BM_, int NC_, int NP_, int LEAD, bool STATS_>
-__global__ __launch_bounds__(64 * (NC_ + NP_), 3) void k_conv_ws3b(const es_conv_args a, const ConvGeom g) {
-    constexpr int NSB = LEAD + 1, MI = 4;
-    static_assert(BM_ / (NC_ / 2) == 64, "consumer waves hold 64 x 112 tiles");
-    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, A_RING = NSB * B_BYTES;      // A slots behind the B ring
-    constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_;
-    constexpr unsigned OOB = 0x80000000u;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long M = (long)g.O * g.D * g.H * g.W;
-    int bx, by, bz;
-    conv_tile_of(a, bx, by, bz);
-    const int S = gridDim.z;
-    const int kch0 = a.Cin >> 5, nks0 = 27 * kch0;
-    int ks_begin, ks_end;
-    split_range(nks0, 0, 27, bz, S, ks_begin, ks_end);            // (cuts in whole (chunk, kd, kh) groups: multiples of 3 K units)
-    const int nloc = ks_end - ks_begin, ngrp = nloc / 3;
-    const long m0 = (long)bx * BM_;
-    const int n0 = by * BN;
-    if (wave >= NC_) {
-        // =============================== producer ===============================
-        const int pw = wave - NC_;
-        unsigned voff[NA], msk[NA];
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int p = (pw + NP_ * j) * 64 + lane;
-            const int row = p >> 2;
-            const int lc = (p & 3) ^ f_swz(row);
-            const long m = m0 + row;
-            const bool ok = m < M;
-            const long mm = ok ? m : 0;
-            const int w = (int)(mm & (g.W - 1)), h = (int)((mm >> g.lw) & (g.H - 1)), d = (int)((mm >> (g.lw + g.lh)) & (g.D - 1));
-            const int o = (int)(mm >> (g.lw + g.lh + g.ld));
-            voff[j] = (unsigned)(((((long)o * g.D + d) * g.H + h) * g.W + w) * a.Cin * 2 + lc * 16);
-            msk[j] = ok ? tap_mask27(d, g.D, h, g.H, w, g.W) : 0u;
-        }
-        const int bias = ((g.H + 1) * g.W + 1) * a.Cin * 2;
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.a - bias), (short)0, (int)OOB, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)a.w + ((long)by * nks0) * (BNP * BK)), (short)0, (int)OOB, 0x00020000);
-        int dtab;
-        {
-            const int t = lane < 27 ? lane : 13;
-            const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
-            dtab = ((kd * g.H + kh) * g.W + kw) * a.Cin * 2 + bias;
-        }
-        int a_tap = ks_begin % 27, a_c = ks_begin / 27;               // first tap (kw = -1) and channel chunk of the next group to load
-        unsigned b_off = (unsigned)ks_begin * (unsigned)B_BYTES;
-        const unsigned voffB = (unsigned)lane * 16u;
-        auto issue_A = [&](int slot) __attribute__((always_inline)) {
-            char* dst = smem + A_RING + slot * A_BYTES;
-            const unsigned sA = (unsigned)__builtin_amdgcn_readlane(dtab, a_tap + 1) + (unsigned)a_c * 64u;      // the group's centre tap (kw = 0)
-            const unsigned sbit = 1u << (a_tap + 1);
-#pragma unroll
-            for (int j = 0; j < NA; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(dst + (pw + NP_ * j) * 1024), 16, (int)((msk[j] & sbit) ? voff[j] : OOB), (int)sA, 0, 0);
-            a_tap += 3;
-            if (a_tap == 27) { a_tap = 0; ++a_c; }
-        };
-        auto issue_B = [&](int slot) __attribute__((always_inline)) {
-            char* dst = smem + slot * B_BYTES;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int q = pw + NP_ * j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(dst + q * 1024), 16, (int)(q * 16 >= BN ? OOB : voffB), (int)(b_off + (unsigned)q * 1024u), 0, 0);
-            }
-            b_off += (unsigned)B_BYTES;
-        };
-        // loads retire in order: unit u is published when at most (loads issued after the last one it needs) are outstanding.  The
-        // wave counts its issues and remembers the count behind every B tile (ring of NSB marks) and A tile (2 marks).
-        int issued = 0, markA0 = 0, markA1 = 0, markB[NSB];
-        issue_A(0); issued += NA; markA0 = issued;
-#pragma unroll
-        for (int l = 0; l < NSB; ++l) markB[l] = 0;
-#pragma unroll
-        for (int l = 0; l < LEAD; ++l)
-            if (l < nloc) { issue_B(l); issued += NB; markB[l] = issued; }
-        int kw3 = 0, grp = 0, sb = 0, sbl = LEAD % NSB;
-        for (int u = 0; u < nloc; ++u) {
-            int need = markB[0];
-#pragma unroll
-            for (int l = 1; l < NSB; ++l) need = sb == l ? markB[l] : need;
-            if (kw3 == 0) { const int na = (grp & 1) ? markA1 : markA0; need = na > need ? na : need; }
-            wait_vmcnt_dyn(issued - need);
-            __builtin_amdgcn_s_barrier();            // unit u (and its group's A tile) visible; the slots behind released
-            if (u + LEAD < nloc) {
-                issue_B(sbl); issued += NB;
-#pragma unroll
-                for (int l = 0; l < NSB; ++l) markB[l] = sbl == l ? issued : markB[l];
-            }
-            if (kw3 == 0 && grp + 1 < ngrp) { issue_A((grp + 1) & 1); issued += NA; if ((grp + 1) & 1) markA1 = issued; else markA0 = issued; }
-            if (++kw3 == 3) { kw3 = 0; ++grp; }
-            sb = sb == NSB - 1 ? 0 : sb + 1;
-            sbl = sbl == NSB - 1 ? 0 : sbl + 1;
-        }
-        __builtin_amdgcn_s_barrier();                // (the consumers' barrier behind the last unit: their loop is straight-line)
-        f4 dummy[MI][7];
-        conv_epilogue<BM_, NC_, false, true, ES_EPI_NONE, false, STATS_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, 0);
-        return;
-    }
-    // =============================== consumer ===============================
-    const int wm = wave >> 1, wn = wave & 1;
-    f4 acc[MI][7];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    const int i16 = lane & 15, q = lane >> 4;
-    const int fragA = A_RING + (wm * 64 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
-    const int fragB = (wn * 112 + i16) * 64 + ((q ^ f_swz(i16)) << 4);
-    const bool zl = (i16 & (g.W - 1)) == 0, zr = (i16 & (g.W - 1)) == ((g.W - 1) & 15);      // first / last voxel of a W line
-    h8 af[MI], bfr[7];
-    __builtin_amdgcn_s_barrier();                                           // unit 0 and group 0 published
-#pragma unroll
-    for (int j = 0; j < 7; ++j) bfr[j] = *(const h8*)(smem + fragB + j * 1024);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = *(const h8*)(smem + fragA + i * 1024);
-    int slotB = 0;
-    for (int grp = 0; grp < ngrp; ++grp) {
-        auto unit = [&](auto kwc) __attribute__((always_inline)) {
-            constexpr int KW = decltype(kwc)::value;                         // 0, 1, 2 = taps kw -1, 0, +1
-            // (straight-line: behind the LAST unit the "next" reads fetch stale LDS nobody uses; its barrier is matched by the producers)
-            slotB = slotB == NSB - 1 ? 0 : slotB + 1;
-            const char* const Bn = smem + slotB * B_BYTES;                   // the next unit's B tile
-            const char* const An = smem + ((KW == 2 ? grp + 1 : grp) & 1) * A_BYTES;      // the A tile the next unit multiplies
-            auto shift_in_place = [&](int i) __attribute__((always_inline)) {
-                if constexpr (KW == 0) af[i] = a3_shift<-1>(af[i], zl);
-                else if constexpr (KW == 2) af[i] = a3_shift<1>(af[i], zr);
-            };
-            shift_in_place(0);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfr[j], acc[0][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                   // the next unit published; this unit's B slot released
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 1; i < MI; ++i) {
-                af[i - 1] = *(const h8*)(An + fragA + (i - 1) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-                shift_in_place(i);
-                if (i < MI - 1) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        bfr[j] = *(const h8*)(Bn + fragB + j * 1024);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            af[MI - 1] = *(const h8*)(An + fragA + (MI - 1) * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        unit(std::integral_constant<int, 0>{});
-        unit(std::integral_constant<int, 1>{});
-        unit(std::integral_constant<int, 2>{});
-    }
-    conv_epilogue<BM_, NC_, true, true, ES_EPI_NONE, false, STATS_>(a, g, acc, smem, M, m0, n0, wave, lane, S, bz, 0);
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_conv_kw (round 6): K split INSIDE a workgroup -- the small problems of the few-objects regime (a shard of 4 .. 16 objects, the
 // transformer linears of every level there, the 16x4x4 level at any object count).  Such a launch has fewer 256-row tiles than the
 // chip has CUs; until round 5 it kept the big tiles and split K over workgroups: every partial tile went to HBM as an fp32 slab and a
@@ -3020,29 +2838,6 @@ static int launch_ws(const es_conv_args* a, const ConvGeom& g, int ncdhw, dim3 g
     return 0;
 }
 
-// k_conv_ws3b: the few-objects 128-row tile with the shared A tile (3x3x3 SAME convs without a fused skip phase, 4 <= W <= 16)
-static inline bool ws3b_takes(const es_conv_args* a) {
-    static const char* env = getenv("ES_CONV_A3B");              // timing-only A/B switch (bit-identical to k_conv_ws): 0 = off
-    return (env ? atoi(env) != 0 : true) && a->taps == 27 && a->mode == ES_CONV_SAME && !a->a2 && a->W <= 16 && a->W >= 4;
-}
-template <int BM_, int NC_, int NP_, int LEAD>
-static int launch_ws3b(const es_conv_args* a, const ConvGeom& g, dim3 grid, hipStream_t st, bool stats) {
-    constexpr int LDS = (LEAD + 1) * (BNP * BK * 2) + 2 * (BM_ * BK * 2);
-    static_assert(LDS <= 160 * 1024, "rings exceed the CU's LDS");
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute((const void*)k_conv_ws3b<BM_, NC_, NP_, LEAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        const hipError_t e2 = hipFuncSetAttribute((const void*)k_conv_ws3b<BM_, NC_, NP_, LEAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (err == hipSuccess) err = e2;
-    });
-    ES_REQUIRE(err == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(err));
-    const dim3 blk(64 * (NC_ + NP_));
-    if (stats) hipLaunchKernelGGL((k_conv_ws3b<BM_, NC_, NP_, LEAD, true>), grid, blk, LDS, st, *a, g);
-    else hipLaunchKernelGGL((k_conv_ws3b<BM_, NC_, NP_, LEAD, false>), grid, blk, LDS, st, *a, g);
-    return 0;
-}
-
 // k_conv_kw: K split inside the workgroup (KS_ streams x NCH_ column halves of 112)
 template <int KS_, int NCH_>
 static int launch_kw(const es_conv_args* a, const ConvGeom& g, int ncdhw, long M, int ntn, int S, hipStream_t st, bool upm, bool geglu) {
@@ -3367,7 +3162,6 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         const bool stt = want_stats && epi_stats;
         int rc;
         if (few_bm == 64) rc = launch_ws<64, 4, 4, 3>(a, g, ncdhw, grid, st, upm, geglu, stt);
-        else if (ws3b_takes(a) && !geglu) rc = launch_ws3b<128, 4, 8, 4>(a, g, grid, st, stt);
         else rc = launch_ws<128, 4, 8, 5>(a, g, ncdhw, grid, st, upm, geglu, stt);
         if (rc) return rc;
         stats_done = stt;
