@@ -2901,7 +2901,20 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
         if (per_obj_in2 > 0) omax = std::min(omax, lim / per_obj_in2);
         ES_REQUIRE(omax >= 1, "es_conv_mfma_f16: one object exceeds 2 GiB of input (%ld bytes)", per_obj_in);
         if (omax < a->O) {
-            if (emits) { *emits = 0; return 0; }
+            if (emits) {
+                // a chunked launch forms no GroupNorm sums in its epilogues; its chunks split K as launches of omax objects do (with
+                // O_hint: as the whole / the reference problem does) and write their slabs into the SAME workspace: report the slab
+                // count in units of the whole launch's M x N (es_conv_split_of: the planner sizes the workspace with it)
+                es_conv_args c = *a;
+                c.O = (int32_t)omax;
+                c.O_hint = a->O_hint < 0 ? a->O_hint : (a->O_hint > a->O ? a->O_hint : a->O);
+                c.gn_stats_out = nullptr; c.gn_part_out = nullptr;
+                int e2 = 0;
+                if (int rc = conv_dispatch(&c, nullptr, &e2)) return rc;
+                const long sc = e2 >> 8;
+                *emits = (int)((sc * omax + a->O - 1) / a->O) << 8;
+                return 0;
+            }
             const long V = (long)a->D * a->H * a->W;
             for (long o0 = 0; o0 < a->O; o0 += omax) {
                 es_conv_args c = *a;

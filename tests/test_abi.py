@@ -190,6 +190,34 @@ def test_conv_route_query_for_groupnorm_sums_is_host_only():
     assert L.es_conv_emits_gn_part(C.byref(bad)) == -1
 
 
+def test_conv_split_of_reports_the_slabs_a_launch_writes():
+    """es_conv_split_of (round 6): how many fp32 slabs a launch writes into `workspace` -- the planner sizes the workspace with it.  A
+    32-object launch of the 16^3 / 16x8x8 levels writes none; 4 objects split 2 / 4 / 8 ways on 128-row tiles; O_hint = -4 (the
+    canonical arithmetic) gives every object count the reference shard's splits; a K-short linear on k_conv_kw writes none (its four
+    K streams meet in LDS); a launch too large for 31-bit offsets is chunked and reports its chunks' slabs in units of its own M x N."""
+    import ctypes as C
+    from echoscene_amd import hip
+    L = hip.lib()
+
+    def args(O, dims, Cin, N, taps=27, oh=0):
+        a = hip.ConvArgs()
+        a.a, a.w = 0x1000, 0x2000
+        a.O, a.D, a.H, a.W = O, dims[0], dims[1], dims[2]
+        a.Cin, a.N, a.taps, a.mode = Cin, N, taps, 0
+        a.out_f32, a.bias, a.out_ld = 0x3000, 0x5000, N
+        a.workspace, a.splitk, a.O_hint = 0x6000, -1, oh
+        return a
+    lv = [((16, 16, 16), 672, 224), ((16, 8, 8), 448, 448), ((16, 4, 4), 672, 672)]
+    f = lambda O, oh: [L.es_conv_split_of(C.byref(args(O, d, ci, n, oh=oh))) for d, ci, n in lv]
+    assert f(32, 0) == [1, 1, 2] and f(4, 0) == [2, 4, 8]
+    assert f(32, -4) == f(4, 0) == f(4, -4) == f(256, -4)
+    assert L.es_conv_split_of(C.byref(args(4, (16, 8, 8), 448, 448, taps=1))) == 1          # k_conv_kw: no slabs
+    big = args(1024, (16, 16, 16), 672, 224, oh=-4)                                           # 5.6 GB of input: chunks of 390 objects
+    assert L.es_conv_split_of(C.byref(big)) == 1                                              # ceil(2 slabs x 390 / 1024)
+    bad = args(4, (16, 16, 16), 100, 224)
+    assert L.es_conv_split_of(C.byref(bad)) == -1
+
+
 def test_route_options_are_explicit_and_recorded(L, tmp_path):
     """VERDICT r4 #6 / ADVICE r4: everything that decides where an fp32 sum is cut is a process-wide OPTION with a constant default,
     set only through the API -- the library reads no environment variable for it -- and the options string is what es_model_save writes
