@@ -1446,9 +1446,12 @@ __device__ __forceinline__ h8 a3_shift(const h8 v, const bool zero_lane) {
     return __builtin_bit_cast(h8, x);
 }
 
-template <bool STATS_>
+// GB_: ONE barrier per (chunk, kd, kh) group instead of one per K unit -- the producers issue a whole group (its A tile and three B
+// tiles) right after the barrier that publishes the previous one; 7 B slots (the tile still being read + one group published + one
+// landing) + 2 A slots = 144 KB.
+template <bool STATS_, bool GB_ = false>
 __global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const ConvGeom g) {
-    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NSB = 4, NSA = 2, MI = 4;
+    constexpr int BM_ = 256, NC_ = 8, NP_ = 4, NSB = GB_ ? 7 : 4, NSA = 2, MI = 4;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BNP * BK * 2, A_RING = NSB * B_BYTES;      // A slots behind the B ring
     constexpr int NA = (BM_ / 16) / NP_, NB = (BNP / 16) / NP_;
     constexpr unsigned OOB = 0x80000000u;
@@ -1514,6 +1517,24 @@ __global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const
             }
             b_off += (unsigned)B_BYTES;
         };
+        if constexpr (GB_) {
+            int sb = 0;
+            auto issue_group = [&](int gi) __attribute__((always_inline)) {
+                issue_A(gi & 1);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { issue_B(sb); sb = sb == NSB - 1 ? 0 : sb + 1; }
+            };
+            issue_group(0);
+            for (int gi = 0; gi < ngrp; ++gi) {
+                wait_vmcnt<0>();                     // group gi landed (it is the only one in flight)
+                __builtin_amdgcn_s_barrier();        // group gi visible; every consumer is past the first two units of group gi - 1
+                if (gi + 1 < ngrp) issue_group(gi + 1);
+            }
+            __builtin_amdgcn_s_barrier();            // (the consumers' barrier behind the last group)
+            f4 dummy[MI][7];
+            conv_epilogue<BM_, NC_, false, true, ES_EPI_NONE, false, STATS_>(a, g, dummy, smem, M, m0, n0, wave, lane, S, bz, 0);
+            return;
+        }
         issue_A(0);
         issue_B(0);
         if (nloc > 1) issue_B(1);
@@ -1580,7 +1601,7 @@ __global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const
                 for (int i = 0; i < MI; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(KW == 1 ? afc[i] : ash[i], bq[(C0 + j) % 3], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (j == 0) __builtin_amdgcn_s_barrier();                     // the next unit (after kw = +1: the next group's A tile) published
+                if (j == 0 && (!GB_ || KW == 2)) __builtin_amdgcn_s_barrier();   // the next unit (after kw = +1: the next group's A tile) published; GB_: the next GROUP
                 if (j + 2 < 7) bq[(C0 + j + 2) % 3] = *(const h8*)(Bc + fragB + (j + 2) * 1024);
                 else bq[(C0 + j + 2) % 3] = *(const h8*)(Bn + fragB + (j + 2 - 7) * 1024);
                 if (KW == 2 && j >= 1 && j <= MI) afc[j - 1] = *(const h8*)(An + fragA + (j - 1) * 1024);     // (the shifted copies multiply; the centre registers are free)
@@ -3226,11 +3247,19 @@ static int conv_dispatch(const es_conv_args* a, es_stream stream, int* emits) {
                 static hipError_t err3 = hipSuccess;
                 std::call_once(once3, [] {
                     err3 = hipFuncSetAttribute((const void*)k_conv_ws3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
-                    const hipError_t e2 = hipFuncSetAttribute((const void*)k_conv_ws3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
-                    if (err3 == hipSuccess) err3 = e2;
+                    for (auto fl : {std::pair<const void*, int>{(const void*)k_conv_ws3<true>, 6 * 16384}, {(const void*)k_conv_ws3<false, true>, 9 * 16384},
+                                    {(const void*)k_conv_ws3<true, true>, 9 * 16384}}) {
+                        const hipError_t e2 = hipFuncSetAttribute(fl.first, hipFuncAttributeMaxDynamicSharedMemorySize, fl.second);
+                        if (err3 == hipSuccess) err3 = e2;
+                    }
                 });
+                static const char* gb_env = getenv("ES_CONV_GB");          // timing-only A/B switch: 0 = one barrier per K unit instead of one per (chunk, kd, kh) group
                 ES_REQUIRE(err3 == hipSuccess, "es_conv_mfma_f16: hipFuncSetAttribute failed: %s", hipGetErrorString(err3));
-                if (stt) hipLaunchKernelGGL((k_conv_ws3<true>), grid, dim3(768), 6 * 16384, st, *a, g);
+                if (!gb_env || atoi(gb_env) != 0) {
+                    if (stt) hipLaunchKernelGGL((k_conv_ws3<true, true>), grid, dim3(768), 9 * 16384, st, *a, g);
+                    else hipLaunchKernelGGL((k_conv_ws3<false, true>), grid, dim3(768), 9 * 16384, st, *a, g);
+                }
+                else if (stt) hipLaunchKernelGGL((k_conv_ws3<true>), grid, dim3(768), 6 * 16384, st, *a, g);
                 else hipLaunchKernelGGL((k_conv_ws3<false>), grid, dim3(768), 6 * 16384, st, *a, g);
                 if (stt) stats_done = true;
             } else {

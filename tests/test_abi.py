@@ -250,7 +250,7 @@ def test_route_options_are_explicit_and_recorded(L, tmp_path):
             del os.environ[name]
     # no getenv of a numerics-affecting switch is left in the sources: the remaining ones are listed as timing-only / debugging
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    allowed = {'ES_CONV_N16', 'ES_CONV_LINWS', 'ES_LIN_RING', 'ES_LIN_NCB_MAX', 'ES_CONV_NS', 'ES_CONV_A3', 'ES_DEBUG_SYNC', 'ES_ROWS_FUSE', 'ES_ROWS_PREFETCH', 'ES_ROWS_NT2', 'ES_ROWS_U1', 'ES_ROWS_DBG'}
+    allowed = {'ES_CONV_N16', 'ES_CONV_LINWS', 'ES_LIN_RING', 'ES_LIN_NCB_MAX', 'ES_CONV_NS', 'ES_CONV_A3', 'ES_CONV_GB', 'ES_DEBUG_SYNC', 'ES_ROWS_FUSE', 'ES_ROWS_PREFETCH', 'ES_ROWS_NT2', 'ES_ROWS_U1', 'ES_ROWS_DBG'}
     found = set()
     for f in os.listdir(os.path.join(here, 'echoscene_amd', 'csrc')):
         if f.endswith(('.hip', '.h')):
