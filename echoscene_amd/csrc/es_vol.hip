@@ -1602,6 +1602,10 @@ __global__ __launch_bounds__(768, 3) void k_conv_ws3(const es_conv_args a, const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(KW == 1 ? afc[i] : ash[i], bq[(C0 + j) % 3], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == 0 && (!GB_ || KW == 2)) __builtin_amdgcn_s_barrier();   // the next unit (after kw = +1: the next group's A tile) published; GB_: the next GROUP
+                // the fragment of column j + 3 into the buffer column j has just released: two columns of MFMAs (of both SIMD partners) cover
+                // the read (with "column j + 2 into the buffer of column j - 1" the compiler's waitcnt sat one column behind every read)
+                // (the fragment of column j + 2 into the buffer of column j - 1.  Three columns ahead -- into the buffer column j has just
+                //  released -- measured the same: 54.91 vs 54.84 steps/s, profiles/r06_conv_launch_ab.txt)
                 if (j + 2 < 7) bq[(C0 + j + 2) % 3] = *(const h8*)(Bc + fragB + (j + 2) * 1024);
                 else bq[(C0 + j + 2) % 3] = *(const h8*)(Bn + fragB + (j + 2 - 7) * 1024);
                 if (KW == 2 && j >= 1 && j <= MI) afc[j - 1] = *(const h8*)(An + fragA + (j - 1) * 1024);     // (the shifted copies multiply; the centre registers are free)
